@@ -1,0 +1,360 @@
+"""CPU oracle for the GotenNet interaction hot path.
+
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import this module, and only as the *checker*.  The product path
+(``gotennet_amd``) never imports it and fails loudly when the HIP library is
+missing.
+
+This is a plain-torch (CPU, fp32 or fp64) restatement of the reference's
+algorithm with no PyG / torch_cluster dependency.  Every function cites the
+reference file:line (relative to the reference checkout) it follows.  Parity
+pin: ``tools/make_golden.py`` runs the *real* reference (imported through
+``tools/ref_shims.py`` in the survey container) and commits inputs, weights,
+per-layer and final outputs under ``tests/golden/``;
+``tests/test_oracle_golden.py`` holds this oracle to those vectors.  The
+reference itself ships no tests or golden vectors, and
+its PyG/torch_cluster boundaries are un-vendored and unpinned, so the shim
+semantics documented in ``tools/ref_shims.py`` (= documented PyG 2.x behaviour)
+are the definition used here.
+
+Parameter naming follows the reference ``state_dict`` exactly, so a reference
+checkpoint can be fed to the oracle unchanged.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------- config
+def default_config(**kw) -> dict:
+    """Hyper-parameters with the reference *class* defaults (gotennet.py:767-793)."""
+    cfg = dict(
+        n_atom_basis=128, n_interactions=8, n_rbf=32, cutoff=5.0, max_z=100,
+        epsilon=1e-8, num_heads=8, scale_edge=True, lmax=1,
+        sep_htr=True, sep_dir=False, sep_tensor=False,
+    )
+    cfg.update(kw)
+    return cfg
+
+
+def multiplier(cfg: dict) -> int:
+    """gotennet.py:197-203."""
+    m = 3
+    if cfg["sep_dir"]:
+        m += cfg["lmax"] - 1
+    if cfg["sep_tensor"]:
+        m += cfg["lmax"] - 1
+    return m
+
+
+def degree_sizes(lmax: int) -> List[int]:
+    """gotennet.py:37-51."""
+    return [2 * l + 1 for l in range(1, lmax + 1)]
+
+
+# --------------------------------------------------------------------------- edge basis
+def cosine_cutoff(d: Tensor, cutoff: float) -> Tensor:
+    """layers.py:149-152."""
+    c = 0.5 * (torch.cos(d * math.pi / cutoff) + 1.0)
+    return c * (d < cutoff).to(d.dtype)
+
+
+def expnorm_params(cutoff: float, n_rbf: int) -> Tuple[Tensor, Tensor]:
+    """layers.py:733-737 (fp32 buffers, as the reference registers them)."""
+    start = torch.exp(torch.scalar_tensor(-cutoff))
+    means = torch.linspace(start, 1, n_rbf)
+    betas = torch.tensor([(2 / n_rbf * (1 - start)) ** -2] * n_rbf)
+    return means, betas
+
+
+def expnorm_smearing(d: Tensor, means: Tensor, betas: Tensor, cutoff: float) -> Tensor:
+    """layers.py:744-746.  d is 1-D [E]; returns [E, R]."""
+    alpha = 5.0 / cutoff
+    d = d.unsqueeze(-1)
+    return cosine_cutoff(d, cutoff) * torch.exp(-betas * (torch.exp(alpha * (-d)) - means) ** 2)
+
+
+def real_harmonics(lmax: int, u: Tensor) -> Tensor:
+    """layers.py:805-902 for lmax <= 4: literal polynomial formulas on the unit
+    vector ``u[..., 3]``, l = 0 omitted, order (x, y, z) for l = 1."""
+    if not 1 <= lmax <= 4:
+        raise NotImplementedError("oracle restates TensorInit for 1 <= lmax <= 4")
+    x, y, z = u[..., 0], u[..., 1], u[..., 2]
+    out = [x, y, z]
+    if lmax >= 2:
+        r3 = math.sqrt(3.0)
+        y2 = y.pow(2)
+        x2z2 = x.pow(2) + z.pow(2)
+        s2 = [r3 * x * z, r3 * x * y, y2 - 0.5 * x2z2, r3 * y * z, r3 / 2.0 * (z.pow(2) - x.pow(2))]
+        out += s2
+    if lmax >= 3:
+        a = (1 / 6) * math.sqrt(42)
+        b = math.sqrt(7)
+        c = (1 / 8) * math.sqrt(168)
+        s3 = [
+            a * (s2[0] * z + s2[4] * x),
+            b * s2[0] * y,
+            c * (4.0 * y2 - x2z2) * x,
+            (1 / 2) * b * y * (2.0 * y2 - 3.0 * x2z2),
+            c * z * (4.0 * y2 - x2z2),
+            b * s2[4] * y,
+            a * (s2[4] * z - s2[0] * x),
+        ]
+        out += s3
+    if lmax >= 4:
+        q2, q6, q14, q21 = math.sqrt(2), math.sqrt(6), math.sqrt(14), math.sqrt(21)
+        q42, q70, q105, q210, q7 = math.sqrt(42), math.sqrt(70), math.sqrt(105), math.sqrt(210), math.sqrt(7)
+        s4 = [
+            (3 / 4) * q2 * (s3[0] * z + s3[6] * x),
+            (3 / 4) * s3[0] * y + (3 / 8) * q6 * s3[1] * z + (3 / 8) * q6 * s3[5] * x,
+            (-3 / 56 * q14 * s3[0] * z + (3 / 14) * q21 * s3[1] * y + (3 / 56) * q210 * s3[2] * z
+             + (3 / 56) * q210 * s3[4] * x + (3 / 56) * q14 * s3[6] * x),
+            (-3 / 56 * q42 * s3[1] * z + (3 / 28) * q105 * s3[2] * y + (3 / 28) * q70 * s3[3] * x
+             + (3 / 56) * q42 * s3[5] * x),
+            -3 / 28 * q42 * s3[2] * x + (3 / 7) * q7 * s3[3] * y - 3 / 28 * q42 * s3[4] * z,
+            (-3 / 56 * q42 * s3[1] * x + (3 / 28) * q70 * s3[3] * z + (3 / 28) * q105 * s3[4] * y
+             - 3 / 56 * q42 * s3[5] * z),
+            (-3 / 56 * q14 * s3[0] * x - 3 / 56 * q210 * s3[2] * x + (3 / 56) * q210 * s3[4] * z
+             + (3 / 14) * q21 * s3[5] * y - 3 / 56 * q14 * s3[6] * z),
+            -3 / 8 * q6 * s3[1] * x + (3 / 8) * q6 * s3[5] * z + (3 / 4) * s3[6] * y,
+            (3 / 4) * q2 * (-s3[0] * x + s3[6] * z),
+        ]
+        out += s4
+    return torch.stack(out, dim=-1)
+
+
+# --------------------------------------------------------------------------- dense helpers
+def linear(x: Tensor, sd: Dict[str, Tensor], key: str) -> Tensor:
+    """layers.py:457-529 (Dense without norm/activation): y = x W^T + b, W is [out, in]."""
+    return F.linear(x, sd[key + ".weight"], sd.get(key + ".bias"))
+
+
+def segment_softmax(s: Tensor, index: Tensor, n: int) -> Tensor:
+    """PyG ``utils.softmax`` (call site gotennet.py:503):
+    exp(s - segmax) / (segsum + 1e-16), segments = target node, along dim 0."""
+    shape = list(s.shape)
+    shape[0] = n
+    idx = index.view(-1, *([1] * (s.dim() - 1))).expand_as(s)
+    smax = s.new_full(shape, float("-inf")).scatter_reduce(0, idx, s.detach(), reduce="amax", include_self=True)
+    e = (s - smax.gather(0, idx)).exp()
+    den = s.new_zeros(shape).scatter_add_(0, idx, e) + 1e-16
+    return e / den.gather(0, idx)
+
+
+# --------------------------------------------------------------------------- init layers
+def node_init(sd, cfg, z, h0, edge_index, edge_diff, phi) -> Tensor:
+    """layers.py:1658-1675 (NodeInit.forward/message) with proj_ln='layer' (gotennet.py:841-850)."""
+    mask = edge_index[0] != edge_index[1]
+    ei = edge_index[:, mask]
+    r = edge_diff[mask]
+    ph = phi[mask]
+    h_src = sd["node_init.A_nbr.weight"][z]
+    feat = linear(ph, sd, "node_init.W_ndp.dense_layers.0") * cosine_cutoff(r, cfg["cutoff"]).view(-1, 1)
+    msg = h_src.index_select(0, ei[0]) * feat
+    m = torch.zeros_like(h0).index_add_(0, ei[1], msg)
+    y = linear(torch.cat([h0, m], dim=1), sd, "node_init.W_nrd_nru.dense_layers.0")
+    y = F.layer_norm(y, (y.shape[-1],), sd["node_init.W_nrd_nru.dense_layers.0.norm.weight"],
+                     sd["node_init.W_nrd_nru.dense_layers.0.norm.bias"], 1e-5)
+    y = F.silu(y)
+    return linear(y, sd, "node_init.W_nrd_nru.dense_layers.1")
+
+
+def edge_init(sd, edge_index, phi, h) -> Tensor:
+    """layers.py:1704-1714: t_ij = (h_i + h_j) * W_erp(phi) on every edge (self-loops included)."""
+    h_i = h.index_select(0, edge_index[1])
+    h_j = h.index_select(0, edge_index[0])
+    return (h_i + h_j) * linear(phi, sd, "edge_init.W_erp")
+
+
+# --------------------------------------------------------------------------- GATA
+def _mlp2(x, sd, key):
+    """nn.Sequential(Dense(act=SiLU), Dense(act=None)) -- gotennet.py:209-224."""
+    return linear(F.silu(linear(x, sd, key + ".0")), sd, key + ".1")
+
+
+def gata_message_aggregate(sd, cfg, p, edge_index, h, X, rl, t, r, n_edges):
+    """gotennet.py:400-427 + message 452-559 + aggregate 613-640.
+
+    h [N,F], X [N,D,F], rl [E,D], t [E,F], r [E], n_edges [E].  Returns h', X'.
+    """
+    Fd, H, lmax = cfg["n_atom_basis"], cfg["num_heads"], cfg["lmax"]
+    M = multiplier(cfg)
+    N = h.shape[0]
+    j, i = edge_index[0], edge_index[1]
+    q = linear(h, sd, p + "W_q").reshape(-1, H, Fd // H)
+    k = linear(h, sd, p + "W_k").reshape(-1, H, Fd // H)
+    x = _mlp2(h, sd, p + "gamma_s")                              # [N, M F]
+    v = _mlp2(h, sd, p + "gamma_v")
+    t_attn = F.silu(linear(t, sd, p + "W_re")).reshape(-1, H, Fd // H)
+    t_filter = linear(t, sd, p + "W_rs")                         # [E, M F]
+
+    attn = (q.index_select(0, i) * k.index_select(0, j) * t_attn).sum(dim=-1, keepdim=True)  # [E,H,1]
+    attn = segment_softmax(attn, i, N)
+    if cfg["scale_edge"]:
+        norm = torch.sqrt(n_edges.reshape(-1, 1, 1)) / math.sqrt(Fd)
+    else:
+        norm = 1.0 / math.sqrt(Fd)
+    attn = attn * norm
+    sea = (attn * v.index_select(0, j).reshape(-1, H, (Fd * M) // H)).reshape(-1, Fd * M)
+    spatial = t_filter * x.index_select(0, j) * cosine_cutoff(r, cfg["cutoff"]).unsqueeze(-1)
+    out = spatial + sea
+    comps = list(torch.split(out, Fd, dim=-1))
+    o_s, comps = comps[0], comps[1:]
+    sizes = degree_sizes(lmax)
+    rl_split = torch.split(rl, sizes, dim=1)
+    X_j = X.index_select(0, j)
+    X_split = torch.split(X_j, sizes, dim=1)
+    if cfg["sep_dir"]:
+        o_d, comps = comps[:lmax], comps[lmax:]
+        dX_R = torch.cat([rl_split[a].unsqueeze(-1) * o_d[a].unsqueeze(1) for a in range(lmax)], dim=1)
+    else:
+        o_d, comps = comps[0], comps[1:]
+        dX_R = o_d.unsqueeze(1) * rl.unsqueeze(-1)
+    if cfg["sep_tensor"]:
+        o_t = comps[:lmax]
+        dX_X = torch.cat([X_split[a] * o_t[a].unsqueeze(1) for a in range(lmax)], dim=1)
+    else:
+        dX_X = comps[0].unsqueeze(1) * X_j
+    dX = dX_R + dX_X
+    d_h = torch.zeros_like(h).index_add_(0, i, o_s)
+    d_X = torch.zeros_like(X).index_add_(0, i, dX)
+    return h + d_h, X + d_X
+
+
+def _rejection(rep: Tensor, rl: Tensor) -> Tensor:
+    """gotennet.py:351-364.  rep [E,m,F], rl [E,m]."""
+    proj = (rep * rl.unsqueeze(2)).sum(dim=1, keepdim=True)
+    return rep - proj * rl.unsqueeze(2)
+
+
+def gata_htr(sd, cfg, p, edge_index, X, rl, t):
+    """gotennet.py:429-445 + edge_update 561-611 (sep_htr=True, edge_updates=True:
+    rejection on, gamma_w = identity, gamma_t = SiLU(Dense))."""
+    lmax = cfg["lmax"]
+    sizes = degree_sizes(lmax)
+    j, i = edge_index[0], edge_index[1]
+    EQ = F.linear(X, sd[p + "W_vq.weight"])
+    X_split = torch.split(X, sizes, dim=1)
+    EK = torch.cat([F.linear(X_split[a], sd[p + f"W_vk.{a}.weight"]) for a in range(lmax)], dim=1)
+    EQ_i = torch.split(EQ.index_select(0, i), sizes, dim=1)
+    EK_j = torch.split(EK.index_select(0, j), sizes, dim=1)
+    rl_s = torch.split(rl, sizes, dim=1)
+    w = None
+    for a in range(lmax):
+        eq = _rejection(EQ_i[a], rl_s[a])
+        ek = _rejection(EK_j[a], -rl_s[a])
+        wl = (eq * ek).sum(dim=1)
+        w = wl if w is None else w + wl
+    return t + F.silu(linear(t, sd, p + "gamma_t.dense_layers.0")) * w
+
+
+def eqff(sd, cfg, p, h, X):
+    """gotennet.py:716-748."""
+    Fd = cfg["n_atom_basis"]
+    X_p = F.linear(X, sd[p + "W_vu.weight"])
+    X_pn = torch.sqrt(torch.sum(X_p ** 2, dim=-2) + cfg["epsilon"])
+    ctx = torch.cat([h, X_pn], dim=-1)
+    m = _mlp2(ctx, sd, p + "gamma_m")
+    m1, m2 = torch.split(m, Fd, dim=-1)
+    return h + m1, X + m2.unsqueeze(1) * X_p
+
+
+# --------------------------------------------------------------------------- stack driver
+def gotennet_forward(sd: Dict[str, Tensor], cfg: dict, z: Tensor, edge_index: Tensor,
+                     edge_diff: Tensor, edge_vec: Tensor, return_trace: bool = False):
+    """gotennet.py:956-1010.  Inputs are NOT modified (the reference normalises
+    ``edge_vec`` in place at 978-980; callers of the reference must clone)."""
+    Fd, L, lmax = cfg["n_atom_basis"], cfg["n_interactions"], cfg["lmax"]
+    dt = sd["A_na.weight"].dtype
+    h = sd["A_na.weight"][z]
+    phi = expnorm_smearing(edge_diff, sd["radial_basis.means"], sd["radial_basis.betas"], cfg["cutoff"])
+    h = node_init(sd, cfg, z, h, edge_index, edge_diff, phi)
+    t = edge_init(sd, edge_index, phi, h)
+    mask = (edge_index[0] != edge_index[1]).unsqueeze(1)
+    nrm = torch.norm(edge_vec, dim=1, keepdim=True)
+    unit = torch.where(mask, edge_vec / torch.where(mask, nrm, torch.ones_like(nrm)), edge_vec)
+    rl = real_harmonics(lmax, unit)
+    N = h.shape[0]
+    deg = torch.zeros(N, dtype=edge_diff.dtype).index_add_(0, edge_index[0], torch.ones_like(edge_diff))
+    n_edges = deg[edge_index[0]]
+    D = (lmax + 1) ** 2 - 1
+    X = torch.zeros((N, D, Fd), dtype=torch.promote_types(dt, torch.float32))
+    trace = []
+    for li in range(L):
+        p = f"gata_list.{li}."
+        h, X = gata_message_aggregate(sd, cfg, p, edge_index, h, X, rl, t, edge_diff, n_edges)
+        if li != L - 1:
+            t = gata_htr(sd, cfg, p, edge_index, X, rl, t)
+        h, X = eqff(sd, cfg, f"eqff_list.{li}.", h, X)
+        if return_trace:
+            trace.append((h, X, t))
+    if return_trace:
+        return h, X, dict(phi=phi, rl=rl, layers=trace)
+    return h, X
+
+
+# --------------------------------------------------------------------------- graph builder (adjacent)
+def radius_graph(pos: Tensor, batch: Tensor, cutoff: float, max_num_neighbors: int = 32,
+                 loop: bool = True) -> Tensor:
+    """torch_cluster.radius_graph as used at layers.py:1589-1590: edges j->i for
+    ||pos_j - pos_i|| < cutoff within one molecule, target-major, sources
+    ascending, at most ``max_num_neighbors`` sources per target (first-k)."""
+    n = pos.shape[0]
+    diff = pos.unsqueeze(1) - pos.unsqueeze(0)
+    d2 = (diff * diff).sum(-1)
+    ok = (d2 < cutoff * cutoff) & (batch.unsqueeze(1) == batch.unsqueeze(0))
+    if not loop:
+        ok &= ~torch.eye(n, dtype=torch.bool)
+    ok &= ok.long().cumsum(dim=1) <= max_num_neighbors
+    tgt, src = ok.nonzero(as_tuple=True)
+    return torch.stack([src, tgt], dim=0)
+
+
+def distance(pos: Tensor, batch: Tensor, cutoff: float, max_num_neighbors: int = 32):
+    """layers.py:1588-1604 (Distance.forward, loop=True): edge_vec = pos[j]-pos[i];
+    edge_weight = norm for non-self edges, 0 for self-loops."""
+    ei = radius_graph(pos, batch, cutoff, max_num_neighbors, loop=True)
+    vec = pos[ei[0]] - pos[ei[1]]
+    mask = ei[0] != ei[1]
+    # same value as the reference's masked assignment; written so autograd never
+    # sees norm'(0) on the self-loops.
+    safe = torch.where(mask.unsqueeze(1), vec, torch.ones_like(vec))
+    w = torch.where(mask, torch.norm(safe, dim=-1), torch.zeros_like(vec[:, 0]))
+    return ei, w, vec
+
+
+# --------------------------------------------------------------------------- energy / forces
+def shifted_softplus(x: Tensor) -> Tensor:
+    """layers.py:40-50."""
+    return F.softplus(x) - math.log(2.0)
+
+
+def atomwise_energy(head: Dict[str, Tensor], h: Tensor, batch: Tensor, n_mol: int,
+                    activation: str = "silu") -> Tensor:
+    """outputs.py:323-376 (Atomwise, standardize=identity unless given):
+    y_i = W2 act(W1 h_i + b1) + b2; y = sum_{i in molecule} (stddev*y_i + mean)."""
+    act = F.silu if activation == "silu" else shifted_softplus
+    y = F.linear(act(F.linear(h, head["out_net.1.out_net.0.weight"], head["out_net.1.out_net.0.bias"])),
+                 head["out_net.1.out_net.1.weight"], head["out_net.1.out_net.1.bias"])
+    if "standardize.stddev" in head:
+        y = y * head["standardize.stddev"] + head["standardize.mean"]
+    return torch.zeros((n_mol, y.shape[1]), dtype=y.dtype).index_add_(0, batch, y)
+
+
+def energy_and_forces(sd, cfg, head, z, pos, batch, n_mol, max_num_neighbors: int = 32,
+                      activation: str = "silu"):
+    """GotenNetWrapper.forward (gotennet.py:1043-1045) + Atomwise with
+    derivative (outputs.py:365-375): F = -dE/dpos."""
+    pos = pos.detach().clone().requires_grad_(True)
+    ei, w, vec = distance(pos, batch, cfg["cutoff"], max_num_neighbors)
+    h, X = gotennet_forward(sd, cfg, z, ei, w, vec)
+    e = atomwise_energy(head, h, batch, n_mol, activation)
+    (g,) = torch.autograd.grad(e.sum(), pos)
+    return e.detach(), -g, (h.detach(), X.detach(), ei)

@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""Generate golden input/output vectors from the REAL reference.
+
+Runs only in the survey/build container (needs /root/reference and
+tools/ref_shims.py).  Writes small ``.npz`` fixtures under ``tests/golden/``:
+inputs, the full reference ``state_dict`` (randomised, including biases and
+LayerNorm affine so nothing is hidden by zero-initialisation), the reference's
+per-layer and final outputs in fp32, the same forward evaluated by the
+reference in fp64 (the "truth" used to rank fp32 implementations), and energy
+/ forces through the reference ``Atomwise`` head with autograd.
+
+    python tools/make_golden.py            # regenerate every fixture
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import ref_shims  # noqa: E402
+
+ref = ref_shims.import_reference()
+from gotennet.models.components import layers as ref_layers  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+# name -> (hyper-parameters, graph spec)
+CASES = {
+    # repo-yaml flavour (sep_dir/sep_tensor, scale_edge off), l = 2
+    "l2_sep_f32": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=2, num_heads=8, scale_edge=False,
+                        sep_dir=True, sep_tensor=True, max_z=10), dict(mols=[7, 5], box=3.2, seed=1)),
+    # class-default flavour (no sep, scale_edge on), l = 1
+    "l1_nosep_scale_f32": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=1, num_heads=4, scale_edge=True,
+                                sep_dir=False, sep_tensor=False, max_z=10), dict(mols=[6, 6], box=3.0, seed=2)),
+    "l3_sep_scale_f32": (dict(n_atom_basis=32, n_interactions=3, n_rbf=8, lmax=3, num_heads=8, scale_edge=True,
+                              sep_dir=True, sep_tensor=True, max_z=10), dict(mols=[5, 4], box=2.8, seed=3)),
+    "l4_sep_f32": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=4, num_heads=8, scale_edge=False,
+                        sep_dir=True, sep_tensor=True, max_z=10), dict(mols=[6], box=2.6, seed=4)),
+    # mixed flags + wider features + a molecule partly outside the cutoff + isolated atom
+    "l2_mixed_f64ch": (dict(n_atom_basis=64, n_interactions=2, n_rbf=16, lmax=2, num_heads=8, scale_edge=True,
+                            sep_dir=True, sep_tensor=False, max_z=10), dict(mols=[9, 1, 4], box=6.5, seed=5)),
+    # edge list shuffled (not target-sorted) and without self-loops
+    "l2_sep_shuffled_noloop": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=2, num_heads=8,
+                                    scale_edge=False, sep_dir=True, sep_tensor=True, max_z=10),
+                               dict(mols=[6, 5], box=3.0, seed=6, shuffle=True, loop=False)),
+}
+
+CUTOFF = 5.0
+
+
+def make_molecules(spec):
+    g = torch.Generator().manual_seed(spec["seed"])
+    pos, batch, z = [], [], []
+    for b, n in enumerate(spec["mols"]):
+        pos.append(torch.rand((n, 3), generator=g) * spec["box"] + 10.0 * b)
+        batch += [b] * n
+        z.append(torch.randint(1, 9, (n,), generator=g))
+    return torch.cat(pos), torch.tensor(batch), torch.cat(z)
+
+
+def randomise(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if name.endswith("norm.weight"):
+                p.copy_(1.0 + 0.2 * (torch.rand(p.shape, generator=g) - 0.5))
+            elif p.dim() == 1:  # biases
+                p.copy_(0.1 * (torch.rand(p.shape, generator=g) - 0.5))
+            elif "A_na" in name or "A_nbr" in name:
+                p.copy_(0.5 * torch.randn(p.shape, generator=g))
+                if "A_na" in name:
+                    p[0].zero_()  # padding_idx row
+            else:
+                fan_out, fan_in = p.shape
+                a = (6.0 / (fan_in + fan_out)) ** 0.5  # xavier-uniform bound
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * a)
+
+
+def run_reference(net, z, ei, w, vec, trace=False):
+    """Reference forward; returns h, X and (optionally) per-layer (h, X, t)."""
+    layers = []
+    hooks = []
+    if trace:
+        state = {}
+
+        def gata_hook(_m, _i, out):
+            state["t"] = out[2]
+
+        def eqff_hook(_m, _i, out):
+            layers.append((out[0].squeeze(1).detach().clone(), out[1].detach().clone(), state["t"].detach().clone()))
+
+        for g_, e_ in zip(net.gata_list, net.eqff_list):
+            hooks.append(g_.register_forward_hook(gata_hook))
+            hooks.append(e_.register_forward_hook(eqff_hook))
+    h, X = net(z, ei, w.clone(), vec.clone())  # clone: the reference normalises edge_vec in place
+    for hk in hooks:
+        hk.remove()
+    return h, X, layers
+
+
+def build(name, hp, spec):
+    torch.manual_seed(0)
+    net = ref.GotenNet(cutoff_fn=ref_layers.CosineCutoff(CUTOFF), **hp)
+    randomise(net, 1000 + spec["seed"])
+    net.eval()
+    pos, batch, z = make_molecules(spec)
+    n_mol = len(spec["mols"])
+
+    dist = ref_layers.Distance(CUTOFF, max_num_neighbors=32, loop=spec.get("loop", True))
+    ei, w, vec = dist(pos, batch)
+    if spec.get("shuffle"):
+        perm = torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(99))
+        ei, w, vec = ei[:, perm], w[perm], vec[perm]
+
+    with torch.no_grad():
+        h, X, layers = run_reference(net, z, ei, w, vec, trace=True)
+        phi = net.radial_basis(w)
+        mask = ei[0] != ei[1]
+        unit = vec.clone()
+        unit[mask] = unit[mask] / torch.norm(unit[mask], dim=1, keepdim=True)
+        rl = net.sphere(unit)
+        net64 = ref.GotenNet(cutoff_fn=ref_layers.CosineCutoff(CUTOFF), **hp).double()
+        net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+        net64.eval()
+        h64, X64, _ = run_reference(net64, z, ei, w.double(), vec.double())
+
+    # energy + forces through the reference Atomwise head (outputs.py:323-376); only
+    # for loop=True unshuffled cases (the wrapper path).
+    extra = {}
+    if spec.get("loop", True) and not spec.get("shuffle"):
+        sys.modules.setdefault("torch_scatter", types.ModuleType("torch_scatter"))
+        sys.modules["torch_scatter"].scatter = ref_shims._scatter
+        sys.modules.setdefault("ase", types.ModuleType("ase"))
+        sys.modules.setdefault("ase.data", types.ModuleType("ase.data"))
+        sys.modules["ase.data"].atomic_masses = np.ones(120)
+        sys.modules["ase"].data = sys.modules["ase.data"]
+        from gotennet.models.components import outputs as ref_out
+        head = ref_out.Atomwise(n_in=hp["n_atom_basis"], n_hidden=16, activation=torch.nn.functional.silu,
+                                property="property", derivative="forces")
+        randomise(head, 2000 + spec["seed"])
+        for tag, nn_, hd_, dt in (("", net, head, torch.float32),
+                                  ("_f64", net64, ref_out.Atomwise(n_in=hp["n_atom_basis"], n_hidden=16,
+                                                                   activation=torch.nn.functional.silu,
+                                                                   property="property", derivative="forces").double(), torch.float64)):
+            if tag:
+                hd_.load_state_dict({k: v.double() for k, v in head.state_dict().items()})
+            p = pos.to(dt).clone().requires_grad_(True)
+            if dt == torch.float32:
+                dist_ = ref_layers.Distance(CUTOFF, max_num_neighbors=32, loop=True)
+                ei_, w_, vec_ = dist_(p, batch)
+                assert torch.equal(ei_, ei)
+            else:  # Distance.forward (layers.py:1588-1604) allocates fp32; same arithmetic in fp64
+                ei_ = ei
+                vec_ = p[ei_[0]] - p[ei_[1]]
+                m_ = ei_[0] != ei_[1]
+                w_ = torch.zeros(vec_.size(0), dtype=dt)
+                w_[m_] = torch.norm(vec_[m_], dim=-1)
+            hh, XX = nn_(z, ei_, w_, vec_ * 1.0)  # fresh non-leaf: the reference writes edge_vec in place
+
+            class _D(dict):
+                __getattr__ = dict.__getitem__
+            inp = _D(z=z, pos=p, batch=batch, representation=hh, vector_representation=XX)
+            res = hd_(inp)
+            extra["energy" + tag] = res["property"].detach().numpy()
+            extra["forces" + tag] = res["forces"].detach().numpy()
+        for k, v in head.state_dict().items():
+            extra["head/" + k] = v.numpy()
+
+    arrays = dict(
+        z=z.numpy(), pos=pos.numpy(), batch=batch.numpy(), edge_index=ei.numpy(),
+        edge_diff=w.numpy(), edge_vec=vec.numpy(),
+        h=h.numpy(), X=X.numpy(), h_f64=h64.numpy(), X_f64=X64.numpy(),
+        phi=phi.numpy(), rl=rl.numpy(),
+        cfg=np.frombuffer(json.dumps(dict(cutoff=CUTOFF, epsilon=1e-8, sep_htr=True, n_mol=n_mol, **hp)).encode(), dtype=np.uint8),
+    )
+    for li, (lh, lX, lt) in enumerate(layers):
+        arrays[f"layer{li}/h"] = lh.numpy()
+        arrays[f"layer{li}/X"] = lX.numpy()
+        arrays[f"layer{li}/t"] = lt.numpy()
+    for k, v in net.state_dict().items():
+        arrays["sd/" + k] = v.numpy()
+    arrays.update(extra)
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: N={len(z)} E={ei.shape[1]} |h|max={h.abs().max():.3f} |X|max={X.abs().max():.4f} "
+          f"fp32-vs-fp64 dh={float((h.double()-h64).abs().max()):.2e} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
+def sh_kat():
+    """Known-answer table for TensorInit (layers.py:805-902) on fixed unit vectors, l <= 4,
+    and for ExpNormalSmearing/CosineCutoff incl. d = 0 and d >= cutoff."""
+    g = torch.Generator().manual_seed(7)
+    v = torch.randn((32, 3), generator=g, dtype=torch.float64)
+    v = v / v.norm(dim=1, keepdim=True)
+    v = torch.cat([v, torch.eye(3, dtype=torch.float64), torch.zeros((1, 3), dtype=torch.float64)])
+    out = {"unit": v.numpy()}
+    for l in (1, 2, 3, 4):
+        out[f"sh{l}"] = ref_layers.TensorInit(l=l)(v).numpy()
+    d = torch.tensor([0.0, 0.3, 1.0, 2.5, 4.0, 4.999, 5.0, 5.5], dtype=torch.float64)
+    for R in (8, 32):
+        rb = ref_layers.ExpNormalSmearing(cutoff=CUTOFF, n_rbf=R)
+        out[f"rbf{R}_means"] = rb.means.numpy()
+        out[f"rbf{R}_betas"] = rb.betas.numpy()
+        out[f"rbf{R}"] = rb.double()(d).numpy()
+    out["d"] = d.numpy()
+    out["cut"] = ref_layers.CosineCutoff(CUTOFF)(d).numpy()
+    np.savez_compressed(os.path.join(OUT, "kat_basis.npz"), **out)
+    print("kat_basis written")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)  # deterministic reduction order for the goldens
+    for name, (hp, spec) in CASES.items():
+        build(name, hp, spec)
+    sh_kat()
