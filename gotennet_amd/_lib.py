@@ -1,0 +1,75 @@
+"""ctypes binding of libgotennet_hip.so (the C ABI in include/gotennet_hip.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  Loading
+fails loudly when the shared object is missing (run ``python gotennet_amd/build.py``
+or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libgotennet_hip.so")
+
+GN_ERR_BAD_ARG = 10001
+ABI_VERSION = 1
+
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+
+# symbol -> argtypes (mirrors include/gotennet_hip.h one for one)
+SIGNATURES = {
+    "gn_abi_version": [C.POINTER(C.c_char_p)],
+    "gn_build_csr": [_P, _I, _I, _P, _P, _P, _P],
+    "gn_out_degree": [_P, _I, _P, _P],
+    "gn_edge_geometry": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P],
+    "gn_node_init": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P],
+    "gn_edge_init": [_P, _P, _P, _P, _I, _I, _I, _P, _P],
+    "gn_layernorm_silu": [_P, _P, _P, _F, _I, _I, _P, _P],
+    "gn_gemm": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "gn_attn_softmax": [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P],
+    "gn_message_aggregate": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gn_htr_edge": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
+    "gn_eqff_context": [_P, _P, _F, _I, _I, _I, _P, _P],
+    "gn_eqff_update": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "gn_radius_count": [_P, _P, _I, _F, _I, _P, _P],
+    "gn_radius_fill": [_P, _P, _I, _F, _I, _P, C.c_int64, _P, _P, _P, _P],
+}
+
+_lib = None
+
+
+class GotenNetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GotenNetHipError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(python gotennet_amd/build.py). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if lib.gn_abi_version(None) != ABI_VERSION:
+        raise GotenNetHipError("libgotennet_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        what = "unsupported shape/flag combination" if rc == GN_ERR_BAD_ARG else f"hipError_t {rc}"
+        raise GotenNetHipError(f"{name} failed: {what}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,40 @@
+"""Build libgotennet_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import glob
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libgotennet_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-variable"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(PKG, "..", "include", "gotennet_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + FLAGS + sources() + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

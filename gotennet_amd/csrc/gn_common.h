@@ -1,0 +1,64 @@
+// gn_common.h -- shared device helpers for libgotennet_hip (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gotennet_hip.h"
+
+#define GN_WAVE 64
+
+#define GN_LAUNCH_CHECK()                         \
+    do {                                          \
+        hipError_t e__ = hipGetLastError();       \
+        if (e__ != hipSuccess) return (int)e__;   \
+    } while (0)
+
+namespace gn {
+
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 fma4(float s, float4 b, float4 c) {
+    return make_float4(fmaf(s, b.x, c.x), fmaf(s, b.y, c.y), fmaf(s, b.z, c.z), fmaf(s, b.w, c.w));
+}
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// Fixed-order sum over the `ns` slot partials red[s * F + c0 .. c0+3] (deterministic).
+__device__ __forceinline__ float4 red4(const float* red, int c0, int F, int ns) {
+    float4 s = ld4(red + c0);
+    for (int k = 1; k < ns; ++k) s = s + ld4(red + k * F + c0);
+    return s;
+}
+
+// Sum over aligned groups of `width` lanes (power of two, <= 64); every lane gets its group's sum.
+__device__ __forceinline__ float group_sum(float v, int width) {
+    for (int o = 1; o < width; o <<= 1) v += __shfl_xor(v, o, GN_WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 1; o < GN_WAVE; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, GN_WAVE));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 1; o < GN_WAVE; o <<= 1) v += __shfl_xor(v, o, GN_WAVE);
+    return v;
+}
+
+// XCD-aware block -> work-item map.  Blocks are dealt round-robin to the 8 XCDs
+// (block b -> XCD b % 8, observed, speed only); give every XCD a contiguous range of
+// items so the neighbours of a molecule are gathered through ONE L2.
+// grid must be 8 * ceil(n / 8); returns -1 for the padding blocks.
+__device__ __forceinline__ int xcd_item(int b, int n) {
+    const int per = (n + 7) >> 3;
+    const int i = (b & 7) * per + (b >> 3);
+    return ((b >> 3) < per && i < n) ? i : -1;
+}
+static inline int xcd_grid(int n) { return 8 * ((n + 7) / 8); }
+
+static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace gn

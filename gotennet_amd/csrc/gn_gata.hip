@@ -1,0 +1,256 @@
+// gn_gata.hip -- the GATA interaction kernels: attention scores + segment softmax,
+// the fused message / segmented-reduction / residual kernel (K6, the HBM-bound
+// gather-scatter stage this library is measured on) and the HTR edge weights (K7).
+//
+// All three use the per-target "slot" layout described in gn_edge.hip: CSR rows by
+// target, one workgroup per target atom, F/4 lanes per incoming edge with 16-byte
+// loads, register accumulation, fixed-order LDS reduction across slots (no atomics).
+// Workgroup -> target mapping is XCD-aware (gn::xcd_item) so the source rows of one
+// molecule are re-read through a single XCD's L2.
+#include "gn_common.h"
+
+namespace gn {
+
+// ------------------------------------------------------------------ attention weights
+// reference gotennet.py:497-511 + PyG softmax.  a[e,h] holds raw scores between the two phases.
+__global__ __launch_bounds__(256) void attn_softmax_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, int ldqk,
+    const float* __restrict__ ta, int ldt,
+    const int* __restrict__ rowptr, const int* __restrict__ src, const int* __restrict__ outdeg,
+    int N, int F, int H, float inv_sqrt_f, float* __restrict__ a) {
+    const int i = xcd_item(blockIdx.x, N);
+    if (i < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
+    const int lph = lps / H;                       // lanes per head (power of two, >= 1)
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    const float4 qi = ld4(q + (size_t)i * ldqk + c0);
+    for (int e = e0 + slot; e < e1; e += ns) {
+        const float4 kj = ld4(k + (size_t)src[e] * ldqk + c0);
+        const float4 te = ld4(ta + (size_t)e * ldt + c0);
+        float p = qi.x * kj.x * te.x;
+        p += qi.y * kj.y * te.y;
+        p += qi.z * kj.z * te.z;
+        p += qi.w * kj.w * te.w;
+        p = group_sum(p, lph);
+        if ((lp & (lph - 1)) == 0) a[(size_t)e * H + lp / lph] = p;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int h = wave; h < H; h += 4) {
+        float mx = -INFINITY;
+        for (int e = e0 + lane; e < e1; e += 64) mx = fmaxf(mx, a[(size_t)e * H + h]);
+        mx = wave_max(mx);
+        float sm = 0.f;
+        for (int e = e0 + lane; e < e1; e += 64) {
+            const float ex = expf(a[(size_t)e * H + h] - mx);
+            a[(size_t)e * H + h] = ex;
+            sm += ex;
+        }
+        sm = wave_sum(sm) + 1e-16f;
+        for (int e = e0 + lane; e < e1; e += 64) {
+            const float nrm = outdeg ? sqrtf((float)outdeg[src[e]]) * inv_sqrt_f : inv_sqrt_f;
+            a[(size_t)e * H + h] = a[(size_t)e * H + h] / sm * nrm;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K6 message + aggregate
+// M F-wide blocks of the value vector: 0 = scalar; direction gate of degree l: block
+// (SEP_DIR ? l : 1); tensor gate: block TB0 + (SEP_TENSOR ? l-1 : 0), TB0 = 1 + (SEP_DIR ? LMAX : 1).
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
+__global__ __launch_bounds__(256) void message_aggregate_kernel(
+    const float* __restrict__ x, const float* __restrict__ v, int ldxv,
+    const float* __restrict__ tf, int ldt, const float* __restrict__ a,
+    const float* __restrict__ rl, const float* __restrict__ cut,
+    const int* __restrict__ rowptr, const int* __restrict__ src,
+    const float* __restrict__ h_in, const float* __restrict__ X_in,
+    float* __restrict__ h_out, float* __restrict__ X_out, int N, int F, int H) {
+    constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
+    constexpr int ND = SEP_DIR ? LMAX : 1;
+    constexpr int NT = SEP_TENSOR ? LMAX : 1;
+    constexpr int M = 1 + ND + NT;
+    constexpr int ROWS = 1 + D;
+    constexpr int CH = ROWS < 9 ? ROWS : 9;         // rows reduced per LDS pass (<= 36 KiB)
+    __shared__ __attribute__((aligned(16))) float red[CH * 1024];
+
+    const int i = xcd_item(blockIdx.x, N);
+    if (i < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    const int per_head = (M * F) / H;
+
+    int hb[M];
+#pragma unroll
+    for (int b = 0; b < M; ++b) hb[b] = (b * F + c0) / per_head;
+
+    float4 acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = zero4();
+
+    for (int e = e0 + slot; e < e1; e += ns) {
+        const int j = src[e];
+        const float ce = cut[e];
+        const float* xr = x + (size_t)j * ldxv + c0;
+        const float* vr = v + (size_t)j * ldxv + c0;
+        const float* tr = tf + (size_t)e * ldt + c0;
+        const float* ar = a + (size_t)e * H;
+        const float* Xj = X_in + (size_t)j * D * F + c0;
+        const float* re = rl + (size_t)e * D;
+        float4 o[M];
+#pragma unroll
+        for (int b = 0; b < M; ++b) {
+            // gotennet.py:516-529: (t_filter * x_j) * cutoff + attn * v_j
+            const float4 sp = (ld4(tr + b * F) * ld4(xr + b * F)) * ce;
+            o[b] = fma4(ar[hb[b]], ld4(vr + b * F), sp);
+        }
+        acc[0] = acc[0] + o[0];
+        int m = 0;
+#pragma unroll
+        for (int l = 1; l <= LMAX; ++l) {
+            const float4 od = o[SEP_DIR ? l : 1];
+            const float4 ot = o[1 + ND + (SEP_TENSOR ? l - 1 : 0)];
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm, ++m) {
+                // gotennet.py:538-558: rl * o_d + X_j * o_t
+                acc[1 + m] = acc[1 + m] + fma4(ld4(Xj + (size_t)m * F), ot, od * re[m]);
+            }
+        }
+    }
+
+    // fixed-order reduction over slots, CH rows per pass; slot s finishes rows s, s+ns, ...
+#pragma unroll
+    for (int base = 0; base < ROWS; base += CH) {
+        if (base) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CH; ++r)
+            if (base + r < ROWS) st4(&red[r * 1024 + slot * F + c0], acc[base + r]);
+        __syncthreads();
+        for (int r = slot; r < CH && base + r < ROWS; r += ns) {
+            const float4 s = red4(red + r * 1024, c0, F, ns);
+            const int row = base + r;
+            if (row == 0) {
+                st4(h_out + (size_t)i * F + c0, ld4(h_in + (size_t)i * F + c0) + s);
+            } else {
+                const size_t off = ((size_t)i * D + (row - 1)) * F + c0;
+                st4(X_out + off, ld4(X_in + off) + s);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K7 HTR edge weights
+// gotennet.py:351-364, 580-609 (sep_htr, rejection on): literal two-rejection form.
+template <int LMAX>
+__global__ __launch_bounds__(256) void htr_edge_kernel(
+    const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
+    const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F, float* __restrict__ w) {
+    constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
+    const int i = xcd_item(blockIdx.x, N);
+    if (i < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    float4 eq[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) eq[m] = ld4(EQ + ((size_t)i * D + m) * F + c0);
+    for (int e = e0 + slot; e < e1; e += ns) {
+        const float* kj = EK + (size_t)src[e] * D * F + c0;
+        const float* re = rl + (size_t)e * D;
+        float4 wsum = zero4();
+        int m0 = 0;
+#pragma unroll
+        for (int l = 1; l <= LMAX; ++l) {
+            constexpr int dummy = 0; (void)dummy;
+            float4 ek[2 * LMAX + 1];
+            float r[2 * LMAX + 1];
+            float4 pq = zero4(), pk = zero4();
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                ek[mm] = ld4(kj + (size_t)(m0 + mm) * F);
+                r[mm] = re[m0 + mm];
+                pq = fma4(r[mm], eq[m0 + mm], pq);
+                pk = fma4(-r[mm], ek[mm], pk);
+            }
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                const float4 a_ = eq[m0 + mm] + pq * (-r[mm]);       // EQ - proj * rl
+                const float4 b_ = ek[mm] + pk * r[mm];               // EK - proj' * (-rl)
+                wsum = fma4(a_, b_, wsum);
+            }
+            m0 += 2 * l + 1;
+        }
+        st4(w + (size_t)e * F + c0, wsum);
+    }
+}
+
+}  // namespace gn
+
+// ====================================================================================== C ABI
+static bool feature_dim_ok(int F) { return F >= 16 && F <= 1024 && gn::is_pow2(F); }
+
+extern "C" int gn_attn_softmax(const float* q, const float* k, int ldqk, const float* t_attn, int ldt,
+                               const int* rowptr, const int* src, const int* outdeg,
+                               int N, int F, int H, float* a, void* stream) {
+    if (!feature_dim_ok(F) || N < 0 || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || (F / 4) / H > 64 ||
+        (ldqk & 3) || (ldt & 3))
+        return GN_ERR_BAD_ARG;
+    if (N == 0) return GN_OK;
+    const float inv_sqrt_f = (float)(1.0 / sqrt((double)F));
+    hipLaunchKernelGGL(gn::attn_softmax_kernel, dim3(gn::xcd_grid(N)), dim3(256), 0, (hipStream_t)stream,
+                       q, k, ldqk, t_attn, ldt, rowptr, src, outdeg, N, F, H, inv_sqrt_f, a);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+#define GN_MSG_LAUNCH(L, SD, ST)                                                                          \
+    hipLaunchKernelGGL((gn::message_aggregate_kernel<L, SD, ST>), dim3(gn::xcd_grid(N)), dim3(256), 0,    \
+                       (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in,     \
+                       X_in, h_out, X_out, N, F, H)
+
+extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, const float* t_filter, int ldt,
+                                    const float* a, const float* rl, const float* cut,
+                                    const int* rowptr, const int* src,
+                                    const float* h_in, const float* X_in, float* h_out, float* X_out,
+                                    int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream) {
+    if (!feature_dim_ok(F) || N < 0 || H <= 0 || lmax < 1 || lmax > 4 || (ldxv & 3) || (ldt & 3) || X_in == X_out)
+        return GN_ERR_BAD_ARG;
+    const int M = 1 + (sep_dir ? lmax : 1) + (sep_tensor ? lmax : 1);
+    if ((M * F) % H || ((M * F) / H) % 4) return GN_ERR_BAD_ARG;
+    if (N == 0) return GN_OK;
+    const int key = lmax * 4 + (sep_dir ? 2 : 0) + (sep_tensor ? 1 : 0);
+    switch (key) {
+        case 4: case 5: case 6: case 7: GN_MSG_LAUNCH(1, false, false); break;   // lmax = 1: flags are no-ops
+        case 8: GN_MSG_LAUNCH(2, false, false); break;
+        case 9: GN_MSG_LAUNCH(2, false, true); break;
+        case 10: GN_MSG_LAUNCH(2, true, false); break;
+        case 11: GN_MSG_LAUNCH(2, true, true); break;
+        case 12: GN_MSG_LAUNCH(3, false, false); break;
+        case 13: GN_MSG_LAUNCH(3, false, true); break;
+        case 14: GN_MSG_LAUNCH(3, true, false); break;
+        case 15: GN_MSG_LAUNCH(3, true, true); break;
+        case 16: GN_MSG_LAUNCH(4, false, false); break;
+        case 17: GN_MSG_LAUNCH(4, false, true); break;
+        case 18: GN_MSG_LAUNCH(4, true, false); break;
+        default: GN_MSG_LAUNCH(4, true, true); break;
+    }
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+extern "C" int gn_htr_edge(const float* EQ, const float* EK, const float* rl, const int* rowptr, const int* src,
+                           int N, int F, int lmax, float* w, void* stream) {
+    if (!feature_dim_ok(F) || N < 0 || lmax < 1 || lmax > 4) return GN_ERR_BAD_ARG;
+    if (N == 0) return GN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(gn::xcd_grid(N)), block(256);
+    switch (lmax) {
+        case 1: hipLaunchKernelGGL(gn::htr_edge_kernel<1>, grid, block, 0, st, EQ, EK, rl, rowptr, src, N, F, w); break;
+        case 2: hipLaunchKernelGGL(gn::htr_edge_kernel<2>, grid, block, 0, st, EQ, EK, rl, rowptr, src, N, F, w); break;
+        case 3: hipLaunchKernelGGL(gn::htr_edge_kernel<3>, grid, block, 0, st, EQ, EK, rl, rowptr, src, N, F, w); break;
+        default: hipLaunchKernelGGL(gn::htr_edge_kernel<4>, grid, block, 0, st, EQ, EK, rl, rowptr, src, N, F, w); break;
+    }
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}

@@ -1,0 +1,288 @@
+"""MI355X-native GotenNet representation: same constructor, forward signature and
+state_dict as the reference (gotennet/models/representation/gotennet.py: GATA
+77-657, EQFF 660-748, GotenNet 751-1010, GotenNetWrapper 1013-1045), with the
+whole forward executed by the hand-written HIP kernels in libgotennet_hip.so.
+
+The nn.Modules below only *hold parameters under the reference's names*; there
+is no eager-PyTorch or CPU implementation of the arithmetic in this package.
+Calling ``forward`` on CPU tensors, or without the built library, raises.
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Callable, Mapping, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import engine
+from ._lib import GotenNetHipError
+from .layers import (MLP, CosineCutoff, Dense, EdgeInit, NodeInit, get_weight_init_by_string,
+                     resolve_activation, str2basis)
+
+
+class GATA(nn.Module):
+    """Parameter container for one GATA layer (reference gotennet.py:78-317)."""
+
+    def __init__(self, n_atom_basis: int, activation: Callable, weight_init=nn.init.xavier_uniform_,
+                 bias_init=nn.init.zeros_, aggr: str = "add", epsilon: float = 1e-7, layer_norm: str = "",
+                 steerable_norm: str = "", cutoff: float = 5.0, num_heads: int = 8, dropout: float = 0.0,
+                 edge_updates: Union[bool, str] = True, last_layer: bool = False, scale_edge: bool = True,
+                 evec_dim: Optional[int] = None, emlp_dim: Optional[int] = None, sep_htr: bool = True,
+                 sep_dir: bool = True, sep_tensor: bool = True, lmax: int = 2, edge_ln: str = ""):
+        super().__init__()
+        if isinstance(edge_updates, str):
+            allowed = ["gated", "gatedt", "norej", "norm", "mlp", "mlpa", "act", "linw", "linwa", "ln", "postln"]
+            if not all(p in allowed for p in edge_updates.split("_")):
+                raise ValueError(f"Invalid edge update parts. Allowed parts are {allowed}")
+            raise NotImplementedError("string edge_updates variants are not on the accelerated path (only True)")
+        if aggr != "add":
+            raise NotImplementedError("aggr must be 'add'")
+        if layer_norm or steerable_norm or edge_ln:
+            raise NotImplementedError("layernorm / steerable_norm / edge_ln are not on the accelerated path yet")
+        if not sep_htr:
+            raise NotImplementedError("sep_htr=False is not on the accelerated path yet")
+        if evec_dim not in (None, n_atom_basis) or emlp_dim not in (None, n_atom_basis):
+            raise NotImplementedError("evec_dim / emlp_dim must equal n_atom_basis")
+        if not edge_updates:
+            raise NotImplementedError("edge_updates=False is not on the accelerated path yet")
+        self.n_atom_basis, self.lmax, self.num_heads = n_atom_basis, lmax, num_heads
+        self.last_layer, self.edge_updates, self.scale_edge = last_layer, edge_updates, scale_edge
+        self.sep_htr, self.sep_dir, self.sep_tensor = sep_htr, sep_dir, sep_tensor
+        self.dropout, self.epsilon = dropout, epsilon
+        multiplier = 3 + (lmax - 1 if sep_dir else 0) + (lmax - 1 if sep_tensor else 0)
+        self.multiplier = multiplier
+        D_ = partial(Dense, weight_init=weight_init, bias_init=bias_init)
+        self.gamma_s = nn.Sequential(D_(n_atom_basis, n_atom_basis, activation=activation),
+                                     D_(n_atom_basis, multiplier * n_atom_basis, activation=None))
+        self.W_q = D_(n_atom_basis, n_atom_basis, activation=None)
+        self.W_k = D_(n_atom_basis, n_atom_basis, activation=None)
+        self.gamma_v = nn.Sequential(D_(n_atom_basis, n_atom_basis, activation=activation),
+                                     D_(n_atom_basis, multiplier * n_atom_basis, activation=None))
+        self.W_re = D_(n_atom_basis, n_atom_basis, activation=activation)
+        if not last_layer and edge_updates:
+            self.gamma_t = MLP([n_atom_basis, n_atom_basis], activation=activation, last_activation=activation,
+                               weight_init=weight_init, bias_init=bias_init, norm=edge_ln)
+            self.W_vq = D_(n_atom_basis, n_atom_basis, activation=None, bias=False)
+            self.W_vk = nn.ModuleList([D_(n_atom_basis, n_atom_basis, activation=None, bias=False)
+                                       for _ in range(lmax)])
+            self.gamma_w = nn.Sequential()
+        self.W_rs = D_(n_atom_basis, n_atom_basis * multiplier, activation=None)
+
+    def reset_parameters(self):
+        for m in self.modules():
+            if isinstance(m, Dense):
+                m.reset_parameters()
+
+
+class EQFF(nn.Module):
+    """Parameter container (reference gotennet.py:672-714)."""
+
+    def __init__(self, n_atom_basis: int, activation: Callable, lmax: int, epsilon: float = 1e-8,
+                 weight_init=nn.init.xavier_uniform_, bias_init=nn.init.zeros_):
+        super().__init__()
+        self.lmax, self.n_atom_basis, self.epsilon = lmax, n_atom_basis, epsilon
+        D_ = partial(Dense, weight_init=weight_init, bias_init=bias_init)
+        self.gamma_m = nn.Sequential(D_(2 * n_atom_basis, n_atom_basis, activation=activation),
+                                     D_(n_atom_basis, 2 * n_atom_basis, activation=None))
+        self.W_vu = D_(n_atom_basis, n_atom_basis, activation=None, bias=False)
+
+    def reset_parameters(self):
+        self.W_vu.reset_parameters()
+        for l in self.gamma_m:
+            l.reset_parameters()
+
+
+class GotenNet(nn.Module):
+    """Drop-in for the reference ``GotenNet`` (gotennet.py:751-1010).
+
+    ``forward(atomic_numbers, edge_index, edge_diff, edge_vec) -> (h [N,F], X [N,D,F])``.
+    Differences from the reference, by design: inputs are left untouched (the
+    reference normalises ``edge_vec`` in place, 978-980); inference only (attention
+    dropout is inactive, as in ``eval()``); fp32; runs on a ROCm device only.
+    """
+
+    def __init__(self, n_atom_basis: int = 128, n_interactions: int = 8,
+                 radial_basis: Union[Callable, str] = "expnorm", n_rbf: int = 32,
+                 cutoff_fn: Optional[Union[Callable, str]] = None,
+                 activation: Optional[Union[Callable, str]] = F.silu, max_z: int = 100, epsilon: float = 1e-8,
+                 weight_init: Callable = nn.init.xavier_uniform_, bias_init: Callable = nn.init.zeros_,
+                 layernorm: str = "", steerable_norm: str = "", num_heads: int = 8, attn_dropout: float = 0.0,
+                 edge_updates: Union[bool, str] = True, scale_edge: bool = True, lmax: int = 1, aggr: str = "add",
+                 evec_dim: Optional[int] = None, emlp_dim: Optional[int] = None, sep_htr: bool = True,
+                 sep_dir: bool = False, sep_tensor: bool = False, edge_ln: str = ""):
+        super().__init__()
+        self.scale_edge = scale_edge
+        if type(weight_init) == str:
+            weight_init = get_weight_init_by_string(weight_init)
+        if type(bias_init) == str:
+            bias_init = get_weight_init_by_string(bias_init)
+        activation = resolve_activation(activation)
+        if not 1 <= lmax <= 4:
+            raise NotImplementedError("the MI355X kernels are instantiated for 1 <= lmax <= 4")
+
+        self.n_atom_basis = self.hidden_dim = n_atom_basis
+        self.n_interactions = n_interactions
+        self.cutoff_fn = cutoff_fn
+        self.cutoff = cutoff_fn.cutoff
+        self.lmax, self.num_heads, self.n_rbf, self.epsilon = lmax, num_heads, n_rbf, epsilon
+        self.sep_dir, self.sep_tensor = sep_dir, sep_tensor
+        self.attn_dropout = attn_dropout
+
+        self.node_init = NodeInit([self.hidden_dim, self.hidden_dim], n_rbf, self.cutoff, max_z=max_z,
+                                  weight_init=weight_init, bias_init=bias_init, proj_ln="layer", activation=activation)
+        self.edge_init = EdgeInit(n_rbf, self.hidden_dim)
+        self.radial_basis = str2basis(radial_basis)(cutoff=self.cutoff, n_rbf=n_rbf)
+        self.A_na = nn.Embedding(max_z, n_atom_basis, padding_idx=0)
+        self.gata_list = nn.ModuleList([
+            GATA(n_atom_basis=n_atom_basis, activation=activation, aggr=aggr, weight_init=weight_init,
+                 bias_init=bias_init, layer_norm=layernorm, steerable_norm=steerable_norm, cutoff=self.cutoff,
+                 epsilon=epsilon, num_heads=num_heads, dropout=attn_dropout, edge_updates=edge_updates,
+                 last_layer=(i == n_interactions - 1), scale_edge=scale_edge, evec_dim=evec_dim,
+                 emlp_dim=emlp_dim, sep_htr=sep_htr, sep_dir=sep_dir, sep_tensor=sep_tensor, lmax=lmax,
+                 edge_ln=edge_ln)
+            for i in range(n_interactions)])
+        self.eqff_list = nn.ModuleList([
+            EQFF(n_atom_basis=n_atom_basis, activation=activation, lmax=lmax, epsilon=epsilon,
+                 weight_init=weight_init, bias_init=bias_init) for _ in range(n_interactions)])
+        self.reset_parameters()
+
+        #: set True when the caller guarantees ``edge_index[1]`` is non-decreasing (what
+        #: radius_graph emits); skips the device->host sortedness check (one sync).
+        self.assume_sorted_edges = False
+        self._packed = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------ parameters
+    def reset_parameters(self):
+        self.node_init.reset_parameters()
+        self.edge_init.reset_parameters()
+        for l in self.gata_list:
+            l.reset_parameters()
+        for l in self.eqff_list:
+            l.reset_parameters()
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path: str, device="cpu"):
+        """Reference gotennet.py:904-946 (Lightning checkpoint -> representation)."""
+        import os
+        if not os.path.exists(checkpoint_path):
+            raise FileNotFoundError(f"Checkpoint file {checkpoint_path} does not exist.")
+        ck = torch.load(checkpoint_path, map_location=device)
+        if "representation" in ck:
+            ck = ck["representation"]
+        assert "hyper_parameters" in ck, "Checkpoint must contain 'hyper_parameters' key."
+        assert "representation" in ck["hyper_parameters"], "Hyperparameters must contain 'representation' key."
+        conf = dict(ck["hyper_parameters"]["representation"])
+        conf.pop("_target_", None)
+        conf.pop("__target__", None)
+        if isinstance(conf.get("cutoff_fn"), Mapping):
+            conf["cutoff_fn"] = CosineCutoff(conf["cutoff_fn"]["cutoff"])
+        assert "state_dict" in ck, "Checkpoint must contain 'state_dict' key."
+        sd = {}
+        for k, v in ck["state_dict"].items():
+            if k.startswith("output_modules."):
+                continue
+            sd[k[len("representation."):] if k.startswith("representation.") else k] = v
+        net = cls(**conf)
+        net.load_state_dict(sd, strict=True)
+        return net
+
+    def config(self) -> engine.Config:
+        g0 = self.gata_list[0]
+        return engine.Config(F=self.n_atom_basis, L=self.n_interactions, R=self.n_rbf, H=self.num_heads,
+                             lmax=self.lmax, M=g0.multiplier, cutoff=float(self.cutoff), eps=float(self.epsilon),
+                             scale_edge=bool(self.scale_edge), sep_dir=bool(self.sep_dir),
+                             sep_tensor=bool(self.sep_tensor))
+
+    def packed_weights(self) -> engine.PackedWeights:
+        """Concatenate the projections that share an input into single GEMM operands
+        (cached; rebuilt when any parameter is modified or moved)."""
+        params = list(self.parameters()) + list(self.buffers())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        c = lambda *ts: torch.cat([t.detach() for t in ts], dim=0).contiguous()
+        d = lambda t: t.detach().contiguous()
+        ni, ei = self.node_init, self.edge_init
+        mlp = ni.W_nrd_nru.dense_layers
+        pw = engine.PackedWeights(
+            A_na=d(self.A_na.weight), A_nbr=d(ni.A_nbr.weight),
+            Winit=c(ni.W_ndp.dense_layers[0].weight, ei.W_erp.weight),
+            binit=c(ni.W_ndp.dense_layers[0].bias, ei.W_erp.bias),
+            Wa=d(mlp[0].weight), ba=d(mlp[0].bias), ln_w=d(mlp[0].norm.weight), ln_b=d(mlp[0].norm.bias),
+            Wb=d(mlp[1].weight), bb=d(mlp[1].bias),
+            means=d(self.radial_basis.means), betas=d(self.radial_basis.betas))
+        for gata, eq in zip(self.gata_list, self.eqff_list):
+            lw = engine.LayerWeights(
+                Wn1=c(gata.W_q.weight, gata.W_k.weight, gata.gamma_s[0].weight, gata.gamma_v[0].weight),
+                bn1=c(gata.W_q.bias, gata.W_k.bias, gata.gamma_s[0].bias, gata.gamma_v[0].bias),
+                Ws2=d(gata.gamma_s[1].weight), bs2=d(gata.gamma_s[1].bias),
+                Wv2=d(gata.gamma_v[1].weight), bv2=d(gata.gamma_v[1].bias),
+                We=c(gata.W_re.weight, gata.W_rs.weight), be=c(gata.W_re.bias, gata.W_rs.bias),
+                Wvu=d(eq.W_vu.weight),
+                Wm0=d(eq.gamma_m[0].weight), bm0=d(eq.gamma_m[0].bias),
+                Wm1=d(eq.gamma_m[1].weight), bm1=d(eq.gamma_m[1].bias))
+            if not gata.last_layer:
+                lw.Wt, lw.bt = d(gata.gamma_t.dense_layers[0].weight), d(gata.gamma_t.dense_layers[0].bias)
+                lw.Wvq = d(gata.W_vq.weight)
+                lw.Wvk = [d(wk.weight) for wk in gata.W_vk]
+            pw.layers.append(lw)
+        self._packed, self._packed_key = pw, key
+        return pw
+
+    # ------------------------------------------------------------------ forward
+    def _check_inputs(self, atomic_numbers, edge_index, edge_diff, edge_vec):
+        if not atomic_numbers.is_cuda:
+            raise GotenNetHipError("gotennet_amd runs on a ROCm device only: move the module and its inputs to "
+                                   "'cuda' (there is no CPU fallback; the CPU oracle lives in oracle/ for tests)")
+        p = next(self.parameters())
+        if p.device != atomic_numbers.device or p.dtype != torch.float32:
+            raise GotenNetHipError("module parameters must be fp32 on the same device as the inputs")
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2 or edge_index.dtype != torch.int64:
+            raise ValueError("edge_index must be int64 [2, E]")
+        E = edge_index.shape[1]
+        if edge_diff.shape != (E,):
+            raise ValueError("edge_diff must be 1-D [E] (reference layers.py:745 unsqueezes it)")
+        if edge_vec.shape != (E, 3):
+            raise ValueError("edge_vec must be [E, 3]")
+        if self.training and self.attn_dropout > 0:
+            raise NotImplementedError("attention dropout (training mode) is not on the accelerated path; call .eval()")
+
+    def forward(self, atomic_numbers: Tensor, edge_index: Tensor, edge_diff: Tensor, edge_vec: Tensor,
+                _trace: Optional[list] = None) -> Tuple[Tensor, Tensor]:
+        self._check_inputs(atomic_numbers, edge_index, edge_diff, edge_vec)
+        cfg, pw = self.config(), self.packed_weights()
+        N = atomic_numbers.shape[0]
+        edge_index = edge_index.contiguous()
+        edge_diff = edge_diff.to(torch.float32).contiguous()
+        edge_vec = edge_vec.to(torch.float32).contiguous()
+        if not self.assume_sorted_edges and edge_index.shape[1] > 1:
+            tgt = edge_index[1]
+            if not bool((tgt[1:] >= tgt[:-1]).all()):       # one host sync; skipped when assume_sorted_edges
+                order = torch.sort(tgt, stable=True).indices  # keeps the relative order inside a target row
+                edge_index, edge_diff, edge_vec = edge_index[:, order].contiguous(), edge_diff[order], edge_vec[order]
+        with torch.no_grad():
+            z32 = atomic_numbers.to(torch.int32)
+            g = engine.Graph(cfg, pw, N, edge_index, edge_diff, edge_vec)
+            return engine.forward(cfg, pw, z32, g, trace=_trace)
+
+
+class GotenNetWrapper(GotenNet):
+    """Reference gotennet.py:1013-1045: builds the radius graph from ``inputs.z/.pos/.batch``."""
+
+    def __init__(self, *args, max_num_neighbors=32, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.max_num_neighbors = max_num_neighbors
+
+    def forward(self, inputs) -> Tuple[Tensor, Tensor]:
+        from .graph import distance
+        atomic_numbers, pos, batch = inputs.z, inputs.pos, inputs.batch
+        edge_index, edge_diff, edge_vec = distance(pos, batch, self.cutoff, self.max_num_neighbors)
+        sorted_flag, self.assume_sorted_edges = self.assume_sorted_edges, True   # radius graph is target-major
+        try:
+            return super().forward(atomic_numbers, edge_index, edge_diff, edge_vec)
+        finally:
+            self.assume_sorted_edges = sorted_flag

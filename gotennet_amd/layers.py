@@ -1,0 +1,156 @@
+"""Host-side mirror of the reference layer primitives that sit on the hot path.
+
+These classes are *parameter containers with the reference's names and
+state_dict layout* (reference gotennet/models/components/layers.py: Dense
+457-529, MLP 533-581, CosineCutoff 133-152, ExpNormalSmearing 703-746, NodeInit
+1607-1675, EdgeInit 1677-1714).  They hold no compute: the arithmetic runs in
+the HIP kernels behind gotennet_amd._lib, driven by gotennet_amd.engine.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class CosineCutoff(nn.Module):
+    """Carries ``.cutoff`` (the only thing GotenNet reads, reference gotennet.py:839)."""
+
+    def __init__(self, cutoff: float):
+        super().__init__()
+        if isinstance(cutoff, torch.Tensor):
+            cutoff = cutoff.item()
+        self.cutoff = cutoff
+
+
+def _is_silu(act) -> bool:
+    if act is None:
+        return False
+    if isinstance(act, str):
+        return act.lower().replace("-", "").replace("_", "").replace(" ", "") in ("silu", "swish")
+    return act is F.silu or isinstance(act, nn.SiLU) or act is nn.SiLU
+
+
+def resolve_activation(act):
+    """The HIP kernels fuse SiLU (= 'swish', the reference yaml default and class default)."""
+    if _is_silu(act):
+        return F.silu
+    raise NotImplementedError(
+        f"activation {act!r}: the MI355X path implements SiLU/swish only (reference default)")
+
+
+def get_weight_init_by_string(name: str) -> Callable:
+    """Reference layers.py:423-452 (names only; 'glo_orthogonal'/'he_orthogonal' not needed for inference)."""
+    if name == "":
+        return lambda x: x
+    if name == "zeros":
+        return nn.init.zeros_
+    if name == "xavier_uniform":
+        return nn.init.xavier_uniform_
+    raise ValueError(f"Unknown initialization {name}")
+
+
+class Dense(nn.Linear):
+    """nn.Linear with the reference's extra attributes (weight [out, in])."""
+
+    def __init__(self, in_features, out_features, bias=True, activation=None,
+                 weight_init=nn.init.xavier_uniform_, bias_init=nn.init.zeros_, norm=None):
+        self.weight_init = weight_init
+        self.bias_init = bias_init
+        super().__init__(in_features, out_features, bias)
+        self.activation = activation
+        self.norm = nn.LayerNorm(out_features) if norm == "layer" else None
+        if norm not in (None, "", "layer"):
+            raise NotImplementedError(f"Dense norm={norm!r} is not on the accelerated path")
+
+    def reset_parameters(self):
+        self.weight_init(self.weight)
+        if self.bias is not None:
+            self.bias_init(self.bias)
+
+
+class MLP(nn.Module):
+    """Registers its layers twice (``dense_layers`` and ``layers``) exactly like the
+    reference (layers.py:566-571) so state_dict keys match with strict=True."""
+
+    def __init__(self, hidden_dims: List[int], bias=True, activation=None, last_activation=None,
+                 weight_init=nn.init.xavier_uniform_, bias_init=nn.init.zeros_, norm=""):
+        super().__init__()
+        n = len(hidden_dims)
+        mk = lambda i, o, act, nm: Dense(i, o, bias=bias, activation=act, weight_init=weight_init,
+                                         bias_init=bias_init, norm=nm)
+        self.dense_layers = nn.ModuleList(
+            [mk(hidden_dims[i], hidden_dims[i + 1], activation, norm) for i in range(n - 2)]
+            + [mk(hidden_dims[-2], hidden_dims[-1], last_activation, None)])
+        self.layers = nn.Sequential(*self.dense_layers)
+
+    def reset_parameters(self):
+        for m in self.dense_layers:
+            m.reset_parameters()
+
+
+class ExpNormalSmearing(nn.Module):
+    """Buffers ``means``/``betas`` as in reference layers.py:714-737."""
+
+    def __init__(self, cutoff=5.0, n_rbf=50, trainable=False):
+        super().__init__()
+        if trainable:
+            raise NotImplementedError("trainable radial basis")
+        self.cutoff, self.n_rbf = float(cutoff), n_rbf
+        self.alpha = 5.0 / self.cutoff
+        means, betas = self._initial_params()
+        self.register_buffer("means", means)
+        self.register_buffer("betas", betas)
+
+    def _initial_params(self):
+        start = torch.exp(torch.scalar_tensor(-self.cutoff))
+        means = torch.linspace(start, 1, self.n_rbf)
+        betas = torch.tensor([(2 / self.n_rbf * (1 - start)) ** -2] * self.n_rbf)
+        return means, betas
+
+    def reset_parameters(self):
+        means, betas = self._initial_params()
+        self.means.data.copy_(means)
+        self.betas.data.copy_(betas)
+
+
+def str2basis(basis: Union[str, Callable]):
+    if not isinstance(basis, str):
+        return basis
+    if basis.lower() == "expnorm":
+        return ExpNormalSmearing
+    if basis.lower().replace("_", "") in ("besselbasis", "gaussianrbf"):
+        raise NotImplementedError(f"radial basis {basis!r}: only 'expnorm' is on the accelerated path")
+    raise ValueError("Unknown radial basis: {}".format(basis))
+
+
+class NodeInit(nn.Module):
+    def __init__(self, hidden_channels, num_rbf, cutoff, max_z=100, activation=F.silu, proj_ln="",
+                 weight_init=nn.init.xavier_uniform_, bias_init=nn.init.zeros_):
+        super().__init__()
+        if isinstance(hidden_channels, int):
+            hidden_channels = [hidden_channels]
+        last = hidden_channels[-1]
+        self.A_nbr = nn.Embedding(max_z, last)
+        self.W_ndp = MLP([num_rbf, last], activation=None, norm="", weight_init=weight_init, bias_init=bias_init)
+        self.W_nrd_nru = MLP([2 * last] + hidden_channels, activation=activation, norm=proj_ln,
+                             weight_init=weight_init, bias_init=bias_init)
+
+    def reset_parameters(self):
+        self.A_nbr.reset_parameters()
+        self.W_ndp.reset_parameters()
+        self.W_nrd_nru.reset_parameters()
+
+
+class EdgeInit(nn.Module):
+    def __init__(self, num_rbf, hidden_channels):
+        super().__init__()
+        self.W_erp = nn.Linear(num_rbf, hidden_channels)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.W_erp.weight)
+        self.W_erp.bias.data.fill_(0)

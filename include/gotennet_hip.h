@@ -1,0 +1,143 @@
+/*
+ * gotennet_hip.h -- C ABI of libgotennet_hip.so (gfx950 / MI355X only).
+ *
+ * Drop-in boundary for ONE path of sarpaykent/GotenNet: the equivariant
+ * interaction stack GotenNet.forward(atomic_numbers, edge_index, edge_diff,
+ * edge_vec) -> (h, X)   (reference gotennet/models/representation/gotennet.py:956-1010).
+ * The reference has no FFI of its own (it is pure Python on ATen); each entry
+ * point below replaces the run of ATen/PyG ops cited next to it, and is what a
+ * ctypes binding on the reference side would bind.
+ *
+ * Contract:
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch
+ *     `tensor.data_ptr()`), fp32 row-major with the feature axis F fastest;
+ *     indices are int32 unless stated; the library never allocates, frees or
+ *     synchronises (safe inside hipGraph capture);
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
+ *   - return value: 0 on success, otherwise a hipError_t (launch errors) or
+ *     GN_ERR_* (argument errors); no C++ exceptions cross the ABI;
+ *   - re-entrant, no global mutable state.
+ *
+ * Symbols: N atoms, E directed edges in CSR-by-target order (edge e runs
+ * src[e] = j  ->  dst = i, rowptr[i] <= e < rowptr[i+1]), F = n_atom_basis,
+ * H = num_heads, lmax in [1,4], D = (lmax+1)^2 - 1, M = multiplier (number of
+ * F-wide blocks in the value vector, gotennet.py:197-203), R = n_rbf.
+ */
+#ifndef GOTENNET_HIP_H
+#define GOTENNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GN_OK 0
+#define GN_ERR_BAD_ARG 10001     /* shape/flag combination the kernels do not implement */
+#define GN_ABI_VERSION 1
+
+/* Library identity: returns GN_ABI_VERSION; *arch_out (if non-NULL) receives "gfx950". */
+int gn_abi_version(const char** arch_out);
+
+/* ---- graph plumbing ------------------------------------------------------------------ */
+
+/* CSR row pointer from the target column of a target-sorted edge list, plus int32
+ * copies of both columns.  edge_index is the reference's int64 [2,E] tensor
+ * (row 0 = source j, row 1 = target i; gotennet.py:412-424 gathers _j/_i this way).
+ * Replaces PyG's implicit index handling in MessagePassing.propagate. */
+int gn_build_csr(const int64_t* edge_index, int E, int N, int* src, int* dst, int* rowptr, void* stream);
+
+/* Out-degree of every node counted over ALL edges incl. self-loops
+ * (gotennet.py:986-989: scatter(ones, edge_index[0])).  outdeg must be zeroed by the caller. */
+int gn_out_degree(const int* src, int E, int* outdeg, void* stream);
+
+/* ---- K1 edge geometry ---------------------------------------------------------------- */
+/* unit vector on non-self edges (gotennet.py:978-980), TensorInit real harmonics
+ * (layers.py:805-902), ExpNormalSmearing (layers.py:744-746), CosineCutoff (layers.py:149-152).
+ * rl [E,D], phi [E,R], cut [E]. edge_vec is NOT modified. */
+int gn_edge_geometry(const float* edge_vec, const float* edge_diff, const int* src, const int* dst, int E,
+                     int lmax, int R, const float* means, const float* betas, float cutoff,
+                     float* rl, float* phi, float* cut, void* stream);
+
+/* ---- K2/K3 initialisation ------------------------------------------------------------ */
+/* The two radial projections W_ndp phi + b (layers.py:1668) and W_erp phi + b (layers.py:1710) are
+ * plain gn_gemm calls on phi [E,R]; `feat` below is a row of that product (leading dim ldf). */
+
+/* NodeInit message + aggregate (layers.py:1658-1675) fused with the A_na embedding
+ * lookup (gotennet.py:973): ctx[n, 0:F] = A_na[z[n]],
+ * ctx[n, F:2F] = sum_{j->n, j!=n} A_nbr[z_j] * (feat_e * cut_e).  ctx is [N, 2F]. */
+int gn_node_init(const int* z, const int* rowptr, const int* src, const float* feat, int ldf,
+                 const float* cut, const float* A_na, const float* A_nbr,
+                 int N, int F, float* ctx, void* stream);
+
+/* EdgeInit.message (layers.py:1709-1710): t[e] = (h[i] + h[j]) * feat_e for all edges. */
+int gn_edge_init(const float* h, const int* rowptr, const int* src, const float* feat, int ldf,
+                 int N, int F, float* t, void* stream);
+
+/* y = SiLU(LayerNorm(x) * gamma + beta) row-wise over F (Dense with norm='layer',
+ * layers.py:518-529, inside NodeInit's W_nrd_nru).  In place allowed (y == x). */
+int gn_layernorm_silu(const float* x, const float* gamma, const float* beta, float eps,
+                      int N, int F, float* y, void* stream);
+
+/* ---- dense projections (K4/K5/K7/K8), fp32 MFMA --------------------------------------- */
+/* C[r, n] = epi( sum_k A[r, k] * W[n, k] + bias[n] )      (nn.Linear layout W[out,in]; Dense, layers.py:457-529)
+ *   rows:  logical row r in [0, Mrows) maps to physical row (r / row_cnt) * row_gstride + row_goff + r % row_cnt
+ *          in both A (leading dim lda) and C (ldc); pass (1,1,0) for the identity.  This addresses the
+ *          degree-l' rows of an [N, D, F] tensor for W_vk[l'] (gotennet.py:432-441).
+ *   epi:   SiLU on output columns [act_lo, act_hi); then, if gate != NULL,
+ *          C = res + value * gate  (res, gate: same addressing as C; HTR update t += SiLU(W t + b) * w,
+ *          gotennet.py:445,611).  bias may be NULL.  K must be a multiple of 4. */
+int gn_gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc,
+            int Mrows, int Nout, int K, int act_lo, int act_hi,
+            int row_cnt, int row_gstride, int row_goff,
+            const float* res, const float* gate, void* stream);
+
+/* ---- K6 GATA message / softmax / aggregate -------------------------------------------- */
+/* Attention weights (gotennet.py:497-511): s[e,h] = sum_{c in head h} q[i,c] k[j,c] t_attn[e,c];
+ * a = exp(s - max) / (sum + 1e-16) over the incoming edges of i (PyG softmax), then
+ * a *= 1/sqrt(F)  or  sqrt(outdeg[j])/sqrt(F) when outdeg != NULL (scale_edge).  a is [E,H].
+ * q,k are rows of ldqk floats, t_attn rows of ldt floats. */
+int gn_attn_softmax(const float* q, const float* k, int ldqk, const float* t_attn, int ldt,
+                    const int* rowptr, const int* src, const int* outdeg,
+                    int N, int F, int H, float* a, void* stream);
+
+/* Message + segmented reduction + residual (gotennet.py:516-559, 613-640, 426-427):
+ *   o[c]   = t_filter[e,c] * x[j,c] * cut[e] + a[e, c / (M F / H)] * v[j,c],  c in [0, M F)
+ *   h_out[i]     = h_in[i] + sum_e o[0:F]
+ *   X_out[i,m,:] = X_in[i,m,:] + sum_e ( rl[e,m] * o[dblk(l(m))] + X_in[j,m,:] * o[tblk(l(m))] )
+ * with dblk/tblk the F-wide block of the direction / tensor gate of degree l (sep_dir / sep_tensor).
+ * x, v rows of ldxv floats; t_filter rows of ldt floats.  X_out must not alias X_in. */
+int gn_message_aggregate(const float* x, const float* v, int ldxv, const float* t_filter, int ldt,
+                         const float* a, const float* rl, const float* cut,
+                         const int* rowptr, const int* src,
+                         const float* h_in, const float* X_in, float* h_out, float* X_out,
+                         int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream);
+
+/* ---- K7 HTR edge weights -------------------------------------------------------------- */
+/* w[e,f] = sum_l sum_m P(EQ[i])_m * P(EK[j])_m with P(a) = a - (a . rl_l) rl_l per degree block
+ * (gotennet.py:351-364, 580-609; sep_htr=True, rejection on).  EQ, EK are [N,D,F]; w is [E,F]. */
+int gn_htr_edge(const float* EQ, const float* EK, const float* rl, const int* rowptr, const int* src,
+                int N, int F, int lmax, float* w, void* stream);
+
+/* ---- K8 EQFF node-local pieces -------------------------------------------------------- */
+/* ctx[n, 0:F] = h[n]; ctx[n, F:2F] = sqrt(sum_m Xp[n,m,:]^2 + eps)   (gotennet.py:731-735) */
+int gn_eqff_context(const float* h, const float* Xp, float eps, int N, int F, int D, float* ctx, void* stream);
+/* h += m[:, 0:F];  X += m[:, F:2F] (broadcast over D) * Xp           (gotennet.py:741-746); m is [N,2F] */
+int gn_eqff_update(const float* m, const float* Xp, int N, int F, int D, float* h, float* X, void* stream);
+
+/* ---- adjacent: radius graph (Distance.forward, layers.py:1588-1604) ----------------------- */
+/* torch_cluster.radius_graph(pos, r, batch, loop=True, max_num_neighbors) semantics: edges j->i with
+ * ||pos_j - pos_i||^2 < cutoff^2 (fp32) inside one molecule (batch sorted, int64), target-major,
+ * sources ascending, first max_nbr sources per target.  Pass 1 counts deg[i]; the caller scans it
+ * into rowptr[N+1] (int64) and sizes the outputs; pass 2 writes edge_index int64 [2,E],
+ * edge_vec = pos[j]-pos[i] [E,3] and edge_diff [E] (norm; 0 on self-loops). */
+int gn_radius_count(const float* pos, const int64_t* batch, int N, float cutoff, int max_nbr,
+                    int* deg, void* stream);
+int gn_radius_fill(const float* pos, const int64_t* batch, int N, float cutoff, int max_nbr,
+                   const int64_t* rowptr, int64_t E, int64_t* edge_index, float* edge_vec,
+                   float* edge_diff, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOTENNET_HIP_H */

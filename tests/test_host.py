@@ -1,0 +1,74 @@
+"""CPU: host-side logic and the C-ABI surface (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gotennet_amd import _lib
+    from gotennet_amd.build import build_library
+    build_library()
+    hdr = open(os.path.join(ROOT, "include", "gotennet_hip.h")).read()
+    declared = set(re.findall(r"^int (gn_\w+)\(", hdr, flags=re.M))
+    assert declared, "header parse failed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    arch = ctypes.c_char_p()
+    assert _lib.load().gn_abi_version(ctypes.byref(arch)) == _lib.ABI_VERSION
+    assert arch.value == b"gfx950"
+
+
+def test_state_dict_layout_matches_golden_checkpoint():
+    """Reference weights load with strict=True (key names incl. the duplicated MLP keys)."""
+    import gotennet_amd
+    from tests.golden_util import case_names, load_case
+    for name in case_names():
+        cfg, sd, _, _ = load_case(name)
+        net = gotennet_amd.GotenNet(
+            n_atom_basis=cfg["n_atom_basis"], n_interactions=cfg["n_interactions"], n_rbf=cfg["n_rbf"],
+            cutoff_fn=gotennet_amd.CosineCutoff(cfg["cutoff"]), max_z=cfg["max_z"], num_heads=cfg["num_heads"],
+            scale_edge=cfg["scale_edge"], lmax=cfg["lmax"], sep_dir=cfg["sep_dir"], sep_tensor=cfg["sep_tensor"])
+        assert list(net.state_dict().keys()) == list(sd.keys())
+        net.load_state_dict(sd, strict=True)
+        assert net.hidden_dim == cfg["n_atom_basis"] and net.cutoff == cfg["cutoff"]
+
+
+def test_product_path_fails_loudly_on_cpu():
+    import gotennet_amd
+    from gotennet_amd._lib import GotenNetHipError
+    net = gotennet_amd.GotenNet(n_atom_basis=32, n_interactions=1, n_rbf=8, cutoff_fn=gotennet_amd.CosineCutoff(5.0))
+    ei = torch.zeros((2, 1), dtype=torch.long)
+    with pytest.raises(GotenNetHipError):
+        net(torch.ones(1, dtype=torch.long), ei, torch.zeros(1), torch.zeros(1, 3))
+
+
+def test_unsupported_flags_raise_before_launch():
+    import gotennet_amd
+    cut = gotennet_amd.CosineCutoff(5.0)
+    with pytest.raises(NotImplementedError):
+        gotennet_amd.GotenNet(cutoff_fn=cut, activation="relu")
+    with pytest.raises(NotImplementedError):
+        gotennet_amd.GotenNet(cutoff_fn=cut, lmax=5)
+    with pytest.raises(NotImplementedError):
+        gotennet_amd.GotenNet(cutoff_fn=cut, layernorm="layer")
+    with pytest.raises(ValueError):
+        gotennet_amd.GotenNet(cutoff_fn=cut, edge_updates="bogus")
+    with pytest.raises(ValueError):
+        gotennet_amd.GotenNet(cutoff_fn=cut, radial_basis="nope")
+
+
+def test_no_oracle_import_in_product():
+    """The product package must never import oracle/ (or the reference)."""
+    pkg = os.path.join(ROOT, "gotennet_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+            assert "/root/reference" not in src, fn
