@@ -32,6 +32,19 @@ SIGNATURES = {
     "gn_htr_edge": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "gn_eqff_context": [_P, _P, _F, _I, _I, _I, _P, _P],
     "gn_eqff_update": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "gn_gemm_ex": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P],
+    "gn_htr_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "gn_message_backward": [_P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                            _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gn_eqff_backward_a": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "gn_eqff_backward_b": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "gn_edge_init_backward": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    "gn_node_init_backward": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    "gn_layernorm_silu_backward": [_P, _P, _P, _F, _P, _I, _I, _P, _P],
+    "gn_edge_geometry_backward": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P],
+    "gn_pos_scatter": [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P],
+    "gn_head_energy": [_P, _P, _F, _F, _F, _P, _P, _P, _I, _I, _P, _P, _P],
+    "gn_head_grad": [_P, _P, _F, _I, _I, _P, _P],
     "gn_radius_count": [_P, _P, _I, _F, _I, _P, _P],
     "gn_radius_fill": [_P, _P, _I, _F, _I, _P, C.c_int64, _P, _P, _P, _P],
 }

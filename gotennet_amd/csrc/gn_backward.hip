@@ -1,0 +1,774 @@
+// gn_backward.hip -- hand-written input-gradient kernels for the force path
+// F = -dE/dpos (reference: torch.autograd.grad through GotenNet.forward,
+// outputs.py:365-375).  Only gradients w.r.t. activations are needed (no weight
+// gradients), so the backward costs about one forward of GEMMs plus two gather
+// passes per stage: a by-target pass over the CSR rows (gradients of target-side
+// operands q_i, EQ_i and of per-edge quantities) and a by-source pass over the CSC
+// columns (gradients of the gathered source rows x_j, v_j, k_j, X_j, EK_j).  Both
+// recompute the per-edge message from saved pre-activations instead of storing
+// [E, D, F] tensors (the reference's autograd OOMs at 62 GB on this workload).
+// Same slot layout as the forward (gn_edge.hip); every sum is a fixed-order
+// register/LDS reduction: no float atomics, bit-reproducible forces.
+//
+// Forward equations being differentiated: gotennet.py:452-559 (message),
+// 351-364 + 561-611 (HTR), 716-748 (EQFF), layers.py:1658-1714 (init),
+// layers.py:133-152, 744-746, 805-902 (cutoff, RBF, harmonics).
+#include "gn_common.h"
+#include "gn_sh.h"
+
+namespace gn {
+
+__device__ __forceinline__ float4 silu4(float4 v) { return make_float4(silu(v.x), silu(v.y), silu(v.z), silu(v.w)); }
+
+// cross-slot fixed-order reduction of ROWS float4 accumulators; `wr(row, sum)` is called by
+// exactly one slot per row.  red: >= min(ROWS, 9) * 1024 floats of LDS.
+template <int ROWS, typename Writer>
+__device__ __forceinline__ void reduce_rows(float4 (&acc)[ROWS], float* red, int slot, int c0, int F, int ns, Writer wr) {
+    constexpr int CH = ROWS < 9 ? ROWS : 9;
+#pragma unroll
+    for (int base = 0; base < ROWS; base += CH) {
+        if (base) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CH; ++r)
+            if (base + r < ROWS) st4(&red[r * 1024 + slot * F + c0], acc[base + r]);
+        __syncthreads();
+        for (int r = slot; r < CH && base + r < ROWS; r += ns) wr(base + r, red4(red + r * 1024, c0, F, ns));
+    }
+}
+
+// =========================================================================== HTR backward
+// w = sum_l [ A.B - (2 - r.r)(A.r)(B.r) ],  A = EQ_i block, B = EK_j block, r = rl block
+template <int LMAX>
+__global__ __launch_bounds__(256) void htr_bwd_target_kernel(
+    const float* __restrict__ gtp, const float* __restrict__ pre_t,
+    const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
+    const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F,
+    float* __restrict__ gEQ, float* __restrict__ g_rl) {
+    constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
+    constexpr int CH = D < 9 ? D : 9;
+    __shared__ __attribute__((aligned(16))) float red[CH * 1024];
+    const int i = xcd_item(blockIdx.x, N);
+    if (i < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    float4 eq[D], acc[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) { eq[m] = ld4(EQ + ((size_t)i * D + m) * F + c0); acc[m] = zero4(); }
+    for (int e = e0 + slot; e < e1; e += ns) {
+        const float4 gw = ld4(gtp + (size_t)e * F + c0) * silu4(ld4(pre_t + (size_t)e * F + c0));
+        const float* kj = EK + (size_t)src[e] * D * F + c0;
+        const float* re = rl + (size_t)e * D;
+        int m0 = 0;
+#pragma unroll
+        for (int l = 1; l <= LMAX; ++l) {
+            float4 ek[2 * LMAX + 1];
+            float r[2 * LMAX + 1];
+            float4 pa = zero4(), pb = zero4();
+            float rr = 0.f;
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                ek[mm] = ld4(kj + (size_t)(m0 + mm) * F);
+                r[mm] = re[m0 + mm];
+                pa = fma4(r[mm], eq[m0 + mm], pa);
+                pb = fma4(r[mm], ek[mm], pb);
+                rr = fmaf(r[mm], r[mm], rr);
+            }
+            const float c = 2.0f - rr;
+            const float4 papb = pa * pb;
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                acc[m0 + mm] = fma4(gw, ek[mm] + pb * (-c * r[mm]), acc[m0 + mm]);
+                const float4 t4 = gw * ((eq[m0 + mm] * pb + pa * ek[mm]) * (-c) + papb * (2.0f * r[mm]));
+                const float s = group_sum(hsum4(t4), lps);
+                if (lp == 0) g_rl[(size_t)e * D + m0 + mm] += s;
+            }
+            m0 += 2 * l + 1;
+        }
+    }
+    reduce_rows<D>(acc, red, slot, c0, F, ns, [&](int row, float4 s) { st4(gEQ + ((size_t)i * D + row) * F + c0, s); });
+}
+
+template <int LMAX>
+__global__ __launch_bounds__(256) void htr_bwd_source_kernel(
+    const float* __restrict__ gtp, const float* __restrict__ pre_t,
+    const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
+    const int* __restrict__ colptr, const int* __restrict__ perm, const int* __restrict__ dst, int N, int F,
+    float* __restrict__ gEK) {
+    constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
+    constexpr int CH = D < 9 ? D : 9;
+    __shared__ __attribute__((aligned(16))) float red[CH * 1024];
+    const int j = xcd_item(blockIdx.x, N);
+    if (j < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    const int p0 = colptr[j], p1 = colptr[j + 1];
+    float4 ek[D], acc[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) { ek[m] = ld4(EK + ((size_t)j * D + m) * F + c0); acc[m] = zero4(); }
+    for (int pp = p0 + slot; pp < p1; pp += ns) {
+        const int e = perm[pp];
+        const float4 gw = ld4(gtp + (size_t)e * F + c0) * silu4(ld4(pre_t + (size_t)e * F + c0));
+        const float* qi = EQ + (size_t)dst[e] * D * F + c0;
+        const float* re = rl + (size_t)e * D;
+        int m0 = 0;
+#pragma unroll
+        for (int l = 1; l <= LMAX; ++l) {
+            float4 eq[2 * LMAX + 1];
+            float r[2 * LMAX + 1];
+            float4 pa = zero4();
+            float rr = 0.f;
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                eq[mm] = ld4(qi + (size_t)(m0 + mm) * F);
+                r[mm] = re[m0 + mm];
+                pa = fma4(r[mm], eq[mm], pa);
+                rr = fmaf(r[mm], r[mm], rr);
+            }
+            const float c = 2.0f - rr;
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm)
+                acc[m0 + mm] = fma4(gw, eq[mm] + pa * (-c * r[mm]), acc[m0 + mm]);
+            m0 += 2 * l + 1;
+        }
+    }
+    reduce_rows<D>(acc, red, slot, c0, F, ns, [&](int row, float4 s) { st4(gEK + ((size_t)j * D + row) * F + c0, s); });
+}
+
+// =========================================================================== message backward
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
+struct MsgShape {
+    static constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
+    static constexpr int ND = SEP_DIR ? LMAX : 1;
+    static constexpr int NT = SEP_TENSOR ? LMAX : 1;
+    static constexpr int M = 1 + ND + NT;
+    // degrees [lo, hi] served by gate block b (b >= 1)
+    __host__ __device__ static constexpr bool is_dir(int b) { return b >= 1 && b < 1 + ND; }
+    __host__ __device__ static constexpr int lo(int b) { return is_dir(b) ? (SEP_DIR ? b : 1) : (SEP_TENSOR ? b - ND : 1); }
+    __host__ __device__ static constexpr int hi(int b) { return is_dir(b) ? (SEP_DIR ? b : LMAX) : (SEP_TENSOR ? b - ND : LMAX); }
+    __host__ __device__ static constexpr int first_row(int l) { return l * l - 1; }     // first m of degree l
+};
+
+struct MsgBwdArgs {
+    // saved forward tensors
+    const float* x; const float* v; int ldxv;          // [N, M F]
+    const float* eproj; int lde;                       // [E, (1+M) F]: pre_ta | t_filter
+    const float* a;                                    // [E, H] attention weights (softmax * norm)
+    const float* qk; int ldqk;                         // q at col 0, k at col F
+    const float* X_in;                                 // [N, D, F] layer input X
+    const float* rl; const float* cut;
+    const int* outdeg;                                 // scale_edge (or NULL)
+    // upstream gradients
+    const float* g_h1; const float* g_X1;              // [N,F], [N,D,F]
+    // graph
+    const int* rowptr; const int* src; const int* dst; const int* colptr; const int* perm;
+    // outputs
+    float* g_eproj;                                    // [E, (1+M) F]: g_ta (before SiLU') | g_tf
+    float* g_s;                                        // [E, H] scratch: g_a then g_s
+    float* g_nproj; int ldn;                           // [N, 4F]: g_q at col 0, g_k at col F
+    float* g_x; float* g_v;                            // [N, M F]
+    float* g_X_out;                                    // [N, D, F] = g_X1 + source part
+    float* g_rl; float* g_cut;                         // accumulated
+    int N, F, H;
+    float inv_sqrt_f;
+};
+
+// by-target pass: g_tf, g_cut, g_rl, attention backward (g_a -> g_s), g_ta, g_q
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
+__global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p) {
+    using S = MsgShape<LMAX, SEP_DIR, SEP_TENSOR>;
+    constexpr int D = S::D, M = S::M;
+    __shared__ __attribute__((aligned(16))) float red[1024];
+    const int N = p.N, F = p.F, H = p.H;
+    const int i = xcd_item(blockIdx.x, N);
+    if (i < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
+    const int e0 = p.rowptr[i], e1 = p.rowptr[i + 1];
+    const int per_head = (M * F) / H;
+    int hb[M];
+#pragma unroll
+    for (int b = 0; b < M; ++b) hb[b] = (b * F + c0) / per_head;
+
+    const float4 gdh = ld4(p.g_h1 + (size_t)i * F + c0);
+    float4 gdX[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) gdX[m] = ld4(p.g_X1 + ((size_t)i * D + m) * F + c0);
+
+    // ---- phase 1: per-edge gate gradients
+    for (int e = e0 + slot; e < e1; e += ns) {
+        const int j = p.src[e];
+        const float ce = p.cut[e];
+        const float* xr = p.x + (size_t)j * p.ldxv + c0;
+        const float* vr = p.v + (size_t)j * p.ldxv + c0;
+        const float* tr = p.eproj + (size_t)e * p.lde + F + c0;
+        float* gtr = p.g_eproj + (size_t)e * p.lde + F + c0;
+        const float* ar = p.a + (size_t)e * H;
+        const float* Xj = p.X_in + (size_t)j * D * F + c0;
+        const float* re = p.rl + (size_t)e * D;
+        float pa_h[M];
+        float cutp = 0.f;
+        float rlp[D];
+#pragma unroll
+        for (int b = 0; b < M; ++b) {
+            float4 go;
+            if (b == 0) {
+                go = gdh;
+            } else {
+                go = zero4();
+#pragma unroll
+                for (int l = S::lo(b); l <= S::hi(b); ++l)
+#pragma unroll
+                    for (int m = S::first_row(l); m < S::first_row(l) + 2 * l + 1; ++m)
+                        go = S::is_dir(b) ? fma4(re[m], gdX[m], go) : fma4(gdX[m], ld4(Xj + (size_t)m * F), go);
+            }
+            const float4 tfb = ld4(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
+            st4(gtr + b * F, (go * xb) * ce);
+            cutp += hsum4(go * tfb * xb);
+            pa_h[b] = hsum4(go * vb);
+            if (S::is_dir(b)) {
+                const float4 od = fma4(ar[hb[b]], vb, (tfb * xb) * ce);      // forward direction gate
+#pragma unroll
+                for (int l = S::lo(b); l <= S::hi(b); ++l)
+#pragma unroll
+                    for (int m = S::first_row(l); m < S::first_row(l) + 2 * l + 1; ++m) rlp[m] = hsum4(gdX[m] * od);
+            }
+        }
+        cutp = group_sum(cutp, lps);
+        if (lp == 0) p.g_cut[e] += cutp;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            const float s = group_sum(rlp[m], lps);
+            if (lp == 0) p.g_rl[(size_t)e * D + m] += s;
+        }
+        for (int h = 0; h < H; ++h) {
+            float val = 0.f;
+#pragma unroll
+            for (int b = 0; b < M; ++b) val += (hb[b] == h) ? pa_h[b] : 0.f;
+            val = group_sum(val, lps);
+            if (lp == 0) p.g_s[(size_t)e * H + h] = val;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: softmax backward per head:  g_s = a g_a - (a / nrm) sum_e' a g_a
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int h = wave; h < H; h += 4) {
+            float dot = 0.f;
+            for (int e = e0 + lane; e < e1; e += 64) dot += p.a[(size_t)e * H + h] * p.g_s[(size_t)e * H + h];
+            dot = wave_sum(dot);
+            for (int e = e0 + lane; e < e1; e += 64) {
+                const float nrm = p.outdeg ? sqrtf((float)p.outdeg[p.src[e]]) * p.inv_sqrt_f : p.inv_sqrt_f;
+                const float av = p.a[(size_t)e * H + h];
+                p.g_s[(size_t)e * H + h] = av * p.g_s[(size_t)e * H + h] - (av / nrm) * dot;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: scores backward: g_ta (pre-SiLU' factor), g_q
+    const int hq = c0 / (F / H);
+    const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
+    float4 gq = zero4();
+    for (int e = e0 + slot; e < e1; e += ns) {
+        const float gs = p.g_s[(size_t)e * H + hq];
+        const float4 kj = ld4(p.qk + (size_t)p.src[e] * p.ldqk + F + c0);
+        const float4 ta = silu4(ld4(p.eproj + (size_t)e * p.lde + c0));
+        gq = fma4(gs, kj * ta, gq);
+        st4(p.g_eproj + (size_t)e * p.lde + c0, (qi * kj) * gs);
+    }
+    st4(&red[slot * F + c0], gq);
+    __syncthreads();
+    if (slot == 0) st4(p.g_nproj + (size_t)i * p.ldn + c0, red4(red, c0, F, ns));
+}
+
+// by-source pass: g_x, g_v, g_k, and g_X (tensor-gate path) of the gathered source rows
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
+__global__ __launch_bounds__(256) void msg_bwd_source_kernel(const MsgBwdArgs p) {
+    using S = MsgShape<LMAX, SEP_DIR, SEP_TENSOR>;
+    constexpr int D = S::D, M = S::M;
+    constexpr int ROWS = 2 * M + D + 1;
+    constexpr int CH = ROWS < 9 ? ROWS : 9;
+    __shared__ __attribute__((aligned(16))) float red[CH * 1024];
+    const int N = p.N, F = p.F, H = p.H;
+    const int j = xcd_item(blockIdx.x, N);
+    if (j < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    const int p0 = p.colptr[j], p1 = p.colptr[j + 1];
+    const int per_head = (M * F) / H;
+    const int hq = c0 / (F / H);
+    int hb[M];
+#pragma unroll
+    for (int b = 0; b < M; ++b) hb[b] = (b * F + c0) / per_head;
+
+    // rows: [0,M) g_x, [M,2M) g_v, [2M, 2M+D) g_X, 2M+D g_k
+    float4 acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = zero4();
+
+    for (int pp = p0 + slot; pp < p1; pp += ns) {
+        const int e = p.perm[pp];
+        const int i = p.dst[e];
+        const float ce = p.cut[e];
+        // own rows re-read per edge (L1-resident) instead of pinned in registers
+        const float* xr = p.x + (size_t)j * p.ldxv + c0;
+        const float* vr = p.v + (size_t)j * p.ldxv + c0;
+        const float* Xj = p.X_in + (size_t)j * D * F + c0;
+        asm volatile("" : "+v"(xr), "+v"(vr), "+v"(Xj));
+        const float* tr = p.eproj + (size_t)e * p.lde + F + c0;
+        const float* ar = p.a + (size_t)e * H;
+        const float* re = p.rl + (size_t)e * D;
+        const float* gXi = p.g_X1 + (size_t)i * D * F + c0;
+#pragma unroll
+        for (int b = 0; b < M; ++b) {
+            const float4 tfb = ld4(tr + b * F);
+            const float ab = ar[hb[b]];
+            float4 go;
+            if (b == 0) {
+                go = ld4(p.g_h1 + (size_t)i * F + c0);
+            } else {
+                go = zero4();
+                float4 ot = zero4();
+                if (!S::is_dir(b)) ot = fma4(ab, ld4(vr + b * F), (tfb * ld4(xr + b * F)) * ce);   // forward tensor gate
+#pragma unroll
+                for (int l = S::lo(b); l <= S::hi(b); ++l)
+#pragma unroll
+                    for (int m = S::first_row(l); m < S::first_row(l) + 2 * l + 1; ++m) {
+                        const float4 gx = ld4(gXi + (size_t)m * F);
+                        if (S::is_dir(b)) {
+                            go = fma4(re[m], gx, go);
+                        } else {
+                            go = fma4(gx, ld4(Xj + (size_t)m * F), go);
+                            acc[2 * M + m] = fma4(gx, ot, acc[2 * M + m]);
+                        }
+                    }
+            }
+            acc[b] = fma4(go, tfb * ce, acc[b]);
+            acc[M + b] = fma4(ab, go, acc[M + b]);
+        }
+        const float gs = p.g_s[(size_t)e * H + hq];
+        const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
+        const float4 ta = silu4(ld4(p.eproj + (size_t)e * p.lde + c0));
+        acc[2 * M + D] = fma4(gs, qi * ta, acc[2 * M + D]);
+    }
+    reduce_rows<ROWS>(acc, red, slot, c0, F, ns, [&](int row, float4 s) {
+        if (row < M) st4(p.g_x + (size_t)j * p.ldxv + row * F + c0, s);
+        else if (row < 2 * M) st4(p.g_v + (size_t)j * p.ldxv + (row - M) * F + c0, s);
+        else if (row < 2 * M + D) {
+            const size_t off = ((size_t)j * D + (row - 2 * M)) * F + c0;
+            st4(p.g_X_out + off, ld4(p.g_X1 + off) + s);
+        } else st4(p.g_nproj + (size_t)j * p.ldn + F + c0, s);
+    });
+}
+
+// =========================================================================== EQFF backward
+// part a: gm = [gh' | sum_m gX' Xp],  gXp = gX' * m2
+__global__ void eqff_bwd_a_kernel(const float* __restrict__ gh, const float* __restrict__ gX,
+                                  const float* __restrict__ mm, const float* __restrict__ Xp,
+                                  int N, int F, int D, float* __restrict__ gm, float* __restrict__ gXp) {
+    const int f4 = F >> 2;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * f4) return;
+    const int n = (int)(idx / f4), c0 = (int)(idx % f4) * 4;
+    const float4 m2 = ld4(mm + (size_t)n * 2 * F + F + c0);
+    float4 s = zero4();
+    for (int m = 0; m < D; ++m) {
+        const size_t off = ((size_t)n * D + m) * F + c0;
+        const float4 g = ld4(gX + off);
+        s = fma4(g, ld4(Xp + off), s);
+        st4(gXp + off, g * m2);
+    }
+    st4(gm + (size_t)n * 2 * F + c0, ld4(gh + (size_t)n * F + c0));
+    st4(gm + (size_t)n * 2 * F + F + c0, s);
+}
+
+// part b: gXp += g_n * Xp / n ;  gh1 = gh' + g_ctx[:, :F]     (n = ctx[:, F:2F])
+__global__ void eqff_bwd_b_kernel(const float* __restrict__ gctx, const float* __restrict__ ctx,
+                                  const float* __restrict__ Xp, const float* __restrict__ gh,
+                                  int N, int F, int D, float* __restrict__ gXp, float* __restrict__ gh1) {
+    const int f4 = F >> 2;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * f4) return;
+    const int n = (int)(idx / f4), c0 = (int)(idx % f4) * 4;
+    const float4 gn = ld4(gctx + (size_t)n * 2 * F + F + c0);
+    const float4 nn = ld4(ctx + (size_t)n * 2 * F + F + c0);
+    const float4 sc = make_float4(gn.x / nn.x, gn.y / nn.y, gn.z / nn.z, gn.w / nn.w);
+    for (int m = 0; m < D; ++m) {
+        const size_t off = ((size_t)n * D + m) * F + c0;
+        st4(gXp + off, fma4(sc, ld4(Xp + off), ld4(gXp + off)));
+    }
+    st4(gh1 + (size_t)n * F + c0, ld4(gh + (size_t)n * F + c0) + ld4(gctx + (size_t)n * 2 * F + c0));
+}
+
+// =========================================================================== init backward
+// EdgeInit: t0[e] = (h_i + h_j) fe[e].  g_fe[e] = gt0 (h_i + h_j);  gh[n] += sum_{in(n)} gt0 fe + sum_{out(n)} gt0 fe
+__global__ __launch_bounds__(256) void edge_init_bwd_kernel(
+    const float* __restrict__ gt0, const float* __restrict__ h, const float* __restrict__ feat, int ldf,
+    const int* __restrict__ rowptr, const int* __restrict__ src,
+    const int* __restrict__ colptr, const int* __restrict__ perm,
+    int N, int F, float* __restrict__ g_feat, float* __restrict__ gh) {
+    __shared__ __attribute__((aligned(16))) float red[1024];
+    const int i = xcd_item(blockIdx.x, N);
+    if (i < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    const float4 hi = ld4(h + (size_t)i * F + c0);
+    float4 acc = zero4();
+    for (int e = rowptr[i] + slot; e < rowptr[i + 1]; e += ns) {
+        const float4 g = ld4(gt0 + (size_t)e * F + c0);
+        const float4 fe = ld4(feat + (size_t)e * ldf + F + c0);
+        st4(g_feat + (size_t)e * ldf + F + c0, g * (hi + ld4(h + (size_t)src[e] * F + c0)));
+        acc = fma4(g, fe, acc);
+    }
+    for (int pp = colptr[i] + slot; pp < colptr[i + 1]; pp += ns) {
+        const int e = perm[pp];
+        acc = fma4(ld4(gt0 + (size_t)e * F + c0), ld4(feat + (size_t)e * ldf + F + c0), acc);
+    }
+    st4(&red[slot * F + c0], acc);
+    __syncthreads();
+    if (slot == 0) {
+        float* o = gh + (size_t)i * F + c0;
+        st4(o, ld4(o) + red4(red, c0, F, ns));
+    }
+}
+
+// NodeInit: m_i = sum_{j != i} A_nbr[z_j] (fn[e] cut_e).  g_fn[e] = g_m[i] A_nbr[z_j] cut_e;  g_cut[e] += sum_f g_m A fn
+__global__ __launch_bounds__(256) void node_init_bwd_kernel(
+    const float* __restrict__ g_ctx, const int* __restrict__ z, const float* __restrict__ feat, int ldf,
+    const float* __restrict__ cut, const float* __restrict__ A_nbr,
+    const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F,
+    float* __restrict__ g_feat, float* __restrict__ g_cut) {
+    const int i = xcd_item(blockIdx.x, N);
+    if (i < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
+    const float4 gmi = ld4(g_ctx + (size_t)i * 2 * F + F + c0);
+    for (int e = rowptr[i] + slot; e < rowptr[i + 1]; e += ns) {
+        const int j = src[e];
+        float4 gfn = zero4();
+        float gc = 0.f;
+        if (j != i) {
+            const float4 ga = gmi * ld4(A_nbr + (size_t)z[j] * F + c0);
+            gfn = ga * cut[e];
+            gc = hsum4(ga * ld4(feat + (size_t)e * ldf + c0));
+        }
+        st4(g_feat + (size_t)e * ldf + c0, gfn);
+        gc = group_sum(gc, lps);
+        if (lp == 0) g_cut[e] += gc;
+    }
+}
+
+// y = SiLU(LN(x) gamma + beta): gx = rstd (g_xh - mean(g_xh) - xh mean(g_xh xh)), g_xh = g_out SiLU'(v) gamma
+__global__ __launch_bounds__(256) void layernorm_silu_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    const float* __restrict__ gout, int N, int F, float* __restrict__ gx) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* xr = x + (size_t)row * F;
+    const float* gr = gout + (size_t)row * F;
+    float s = 0.f;
+    for (int f = lane; f < F; f += 64) s += xr[f];
+    const float mean = wave_sum(s) / (float)F;
+    float q = 0.f;
+    for (int f = lane; f < F; f += 64) { const float d = xr[f] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)F + eps);
+    float s1 = 0.f, s2 = 0.f;
+    for (int f = lane; f < F; f += 64) {
+        const float xh = (xr[f] - mean) * rstd;
+        const float g = gr[f] * dsilu(xh * gamma[f] + beta[f]) * gamma[f];
+        s1 += g; s2 += g * xh;
+    }
+    s1 = wave_sum(s1) / (float)F; s2 = wave_sum(s2) / (float)F;
+    for (int f = lane; f < F; f += 64) {
+        const float xh = (xr[f] - mean) * rstd;
+        const float g = gr[f] * dsilu(xh * gamma[f] + beta[f]) * gamma[f];
+        gx[(size_t)row * F + f] = rstd * (g - s1 - xh * s2);
+    }
+}
+
+// =========================================================================== geometry backward
+struct Dual3 {
+    float v, d[3];
+};
+__host__ __device__ inline Dual3 operator+(Dual3 a, Dual3 b) { return {a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2]}}; }
+__host__ __device__ inline Dual3 operator-(Dual3 a, Dual3 b) { return {a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2]}}; }
+__host__ __device__ inline Dual3 operator-(Dual3 a) { return {-a.v, {-a.d[0], -a.d[1], -a.d[2]}}; }
+__host__ __device__ inline Dual3 operator*(Dual3 a, Dual3 b) {
+    return {a.v * b.v, {a.v * b.d[0] + a.d[0] * b.v, a.v * b.d[1] + a.d[1] * b.v, a.v * b.d[2] + a.d[2] * b.v}};
+}
+__host__ __device__ inline Dual3 operator*(float s, Dual3 a) { return {s * a.v, {s * a.d[0], s * a.d[1], s * a.d[2]}}; }
+__host__ __device__ inline Dual3 operator*(Dual3 a, float s) { return s * a; }
+
+// per edge: g_phi [R], g_cut, g_rl [D]  ->  g_vec [3] (through the unit vector) and g_diff (through the distance)
+template <int LMAX>
+__global__ void edge_geometry_bwd_kernel(
+    const float* __restrict__ vec, const float* __restrict__ dist, const int* __restrict__ src, const int* __restrict__ dst,
+    int E, int R, const float* __restrict__ means, const float* __restrict__ betas, float cutoff, float alpha,
+    const float* __restrict__ g_rl, const float* __restrict__ g_cut, const float* __restrict__ g_phi,
+    float* __restrict__ g_vec, float* __restrict__ g_diff) {
+    constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    if (src[e] == dst[e]) {          // self-loop: pos_i - pos_i and d = 0 are constants
+        g_vec[3 * e] = g_vec[3 * e + 1] = g_vec[3 * e + 2] = 0.f;
+        g_diff[e] = 0.f;
+        return;
+    }
+    const float pi = 3.14159265358979323846f;
+    const float d = dist[e];
+    float gd = 0.f;
+    if (d < cutoff) {
+        const float arg = d * pi / cutoff;
+        const float c = 0.5f * (cosf(arg) + 1.0f);
+        const float dc = -0.5f * (pi / cutoff) * sinf(arg);
+        const float u = expf(alpha * (-d));
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float w = u - means[r];
+            const float G = expf(-betas[r] * (w * w));
+            // d/dd [ c G ] = dc G + c G (-2 beta w) (-alpha u)
+            s += g_phi[(size_t)e * R + r] * G * (dc + c * (2.0f * betas[r] * w * alpha * u));
+        }
+        gd = s + g_cut[e] * dc;
+    }
+    g_diff[e] = gd;
+    const float x = vec[3 * e], y = vec[3 * e + 1], z = vec[3 * e + 2];
+    const float n = sqrtf(x * x + y * y + z * z);
+    const float ux = x / n, uy = y / n, uz = z / n;
+    Dual3 o[D];
+    real_harmonics<LMAX, Dual3>(Dual3{ux, {1.f, 0.f, 0.f}}, Dual3{uy, {0.f, 1.f, 0.f}}, Dual3{uz, {0.f, 0.f, 1.f}}, o);
+    float gu0 = 0.f, gu1 = 0.f, gu2 = 0.f;
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        const float g = g_rl[(size_t)e * D + m];
+        gu0 += g * o[m].d[0]; gu1 += g * o[m].d[1]; gu2 += g * o[m].d[2];
+    }
+    const float dotp = gu0 * ux + gu1 * uy + gu2 * uz;      // u = v / |v|:  g_v = (g_u - (g_u . u) u) / |v|
+    g_vec[3 * e] = (gu0 - dotp * ux) / n;
+    g_vec[3 * e + 1] = (gu1 - dotp * uy) / n;
+    g_vec[3 * e + 2] = (gu2 - dotp * uz) / n;
+}
+
+// g_pos[n] = sum_{e: src = n} gv[e] - sum_{e: dst = n} gv[e],  gv = g_vec + g_diff * vec / |vec|
+__global__ void pos_scatter_kernel(const float* __restrict__ g_vec, const float* __restrict__ g_diff,
+                                   const float* __restrict__ vec,
+                                   const int* __restrict__ rowptr, const int* __restrict__ colptr,
+                                   const int* __restrict__ perm, int N, float sign, float* __restrict__ g_pos) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * N) return;
+    const int n = idx / 3, k = idx % 3;
+    auto gv = [&](int e) {
+        const float x = vec[3 * e], y = vec[3 * e + 1], z = vec[3 * e + 2];
+        const float gd = g_diff[e];
+        float r = g_vec[3 * e + k];
+        if (gd != 0.f) r += gd * vec[3 * e + k] / sqrtf(x * x + y * y + z * z);
+        return r;
+    };
+    float s = 0.f;
+    for (int pp = colptr[n]; pp < colptr[n + 1]; ++pp) s += gv(perm[pp]);
+    for (int e = rowptr[n]; e < rowptr[n + 1]; ++e) s -= gv(e);
+    g_pos[idx] = sign * s;
+}
+
+// =========================================================================== energy head (Atomwise)
+// y_n = scale * (sum_k SiLU(pre1[n,k]) W2[k] + b2) + shift (+ atomref[z_n]);  E_mol = sum_{n in mol} y_n
+__global__ __launch_bounds__(256) void head_energy_kernel(
+    const float* __restrict__ pre1, const float* __restrict__ W2, float b2, float scale, float shift,
+    const float* __restrict__ atomref, const int* __restrict__ z, const int* __restrict__ mol_ptr,
+    int Hd, float* __restrict__ y, float* __restrict__ energy) {
+    const int b = blockIdx.x;
+    const int n0 = mol_ptr[b], n1 = mol_ptr[b + 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int n = n0 + wave; n < n1; n += 4) {
+        float s = 0.f;
+        for (int k = lane; k < Hd; k += 64) s += silu(pre1[(size_t)n * Hd + k]) * W2[k];
+        s = wave_sum(s);
+        if (lane == 0) y[n] = (s + b2) * scale + shift + (atomref ? atomref[z[n]] : 0.f);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float s = 0.f;
+        for (int n = n0 + lane; n < n1; n += 64) s += y[n];
+        s = wave_sum(s);
+        if (lane == 0) energy[b] = s;
+    }
+}
+
+__global__ void head_grad_kernel(const float* __restrict__ pre1, const float* __restrict__ W2, float scale,
+                                 int N, int Hd, float* __restrict__ gpre1) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * Hd) return;
+    gpre1[idx] = scale * W2[idx % Hd] * dsilu(pre1[idx]);
+}
+
+}  // namespace gn
+
+// ====================================================================================== C ABI
+static bool bwd_dim_ok(int F) { return F >= 16 && F <= 256 && gn::is_pow2(F); }
+
+#define GN_SWITCH_LMAX(KERNEL, grid, block, st, ...)                                                   \
+    switch (lmax) {                                                                                    \
+        case 1: hipLaunchKernelGGL(gn::KERNEL<1>, grid, block, 0, st, __VA_ARGS__); break;             \
+        case 2: hipLaunchKernelGGL(gn::KERNEL<2>, grid, block, 0, st, __VA_ARGS__); break;             \
+        case 3: hipLaunchKernelGGL(gn::KERNEL<3>, grid, block, 0, st, __VA_ARGS__); break;             \
+        default: hipLaunchKernelGGL(gn::KERNEL<4>, grid, block, 0, st, __VA_ARGS__); break;            \
+    }
+
+extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* EQ, const float* EK,
+                               const float* rl, const int* rowptr, const int* src, const int* dst,
+                               const int* colptr, const int* perm, int N, int F, int lmax,
+                               float* gEQ, float* gEK, float* g_rl, void* stream) {
+    if (!bwd_dim_ok(F) || N < 0 || lmax < 1 || lmax > 4) return GN_ERR_BAD_ARG;
+    if (N == 0) return GN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(gn::xcd_grid(N)), block(256);
+    GN_SWITCH_LMAX(htr_bwd_target_kernel, grid, block, st, g_t_out, pre_t, EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl);
+    GN_LAUNCH_CHECK();
+    GN_SWITCH_LMAX(htr_bwd_source_kernel, grid, block, st, g_t_out, pre_t, EQ, EK, rl, colptr, perm, dst, N, F, gEK);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+#define GN_MSGB_LAUNCH(L, SD, ST)                                                                        \
+    do {                                                                                                  \
+        hipLaunchKernelGGL((gn::msg_bwd_target_kernel<L, SD, ST>), grid, block, 0, st, p);                \
+        hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST>), grid, block, 0, st, p);                \
+    } while (0)
+
+extern "C" int gn_message_backward(
+    const float* x, const float* v, int ldxv, const float* eproj, int lde, const float* a,
+    const float* qk, int ldqk, const float* X_in, const float* rl, const float* cut, const int* outdeg,
+    const float* g_h1, const float* g_X1,
+    const int* rowptr, const int* src, const int* dst, const int* colptr, const int* perm,
+    float* g_eproj, float* g_s, float* g_nproj, int ldn, float* g_x, float* g_v, float* g_X_out,
+    float* g_rl, float* g_cut,
+    int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream) {
+    if (!bwd_dim_ok(F) || N < 0 || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || lmax < 1 || lmax > 4 ||
+        (ldxv & 3) || (lde & 3) || (ldqk & 3) || (ldn & 3) || g_X_out == g_X1)
+        return GN_ERR_BAD_ARG;
+    if (N == 0) return GN_OK;
+    gn::MsgBwdArgs p{x, v, ldxv, eproj, lde, a, qk, ldqk, X_in, rl, cut, outdeg, g_h1, g_X1,
+                     rowptr, src, dst, colptr, perm, g_eproj, g_s, g_nproj, ldn, g_x, g_v, g_X_out, g_rl, g_cut,
+                     N, F, H, (float)(1.0 / sqrt((double)F))};
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(gn::xcd_grid(N)), block(256);
+    const int key = lmax * 4 + (sep_dir ? 2 : 0) + (sep_tensor ? 1 : 0);
+    switch (key) {
+        case 4: case 5: case 6: case 7: GN_MSGB_LAUNCH(1, false, false); break;
+        case 8: GN_MSGB_LAUNCH(2, false, false); break;
+        case 9: GN_MSGB_LAUNCH(2, false, true); break;
+        case 10: GN_MSGB_LAUNCH(2, true, false); break;
+        case 11: GN_MSGB_LAUNCH(2, true, true); break;
+        case 12: GN_MSGB_LAUNCH(3, false, false); break;
+        case 13: GN_MSGB_LAUNCH(3, false, true); break;
+        case 14: GN_MSGB_LAUNCH(3, true, false); break;
+        case 15: GN_MSGB_LAUNCH(3, true, true); break;
+        case 16: GN_MSGB_LAUNCH(4, false, false); break;
+        case 17: GN_MSGB_LAUNCH(4, false, true); break;
+        case 18: GN_MSGB_LAUNCH(4, true, false); break;
+        default: GN_MSGB_LAUNCH(4, true, true); break;
+    }
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+extern "C" int gn_eqff_backward_a(const float* g_h, const float* g_X, const float* m, const float* Xp,
+                                  int N, int F, int D, float* g_m, float* g_Xp, void* stream) {
+    if (N < 0 || F <= 0 || (F & 3) || D <= 0) return GN_ERR_BAD_ARG;
+    if (N == 0) return GN_OK;
+    const size_t tot = (size_t)N * (F / 4);
+    hipLaunchKernelGGL(gn::eqff_bwd_a_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       g_h, g_X, m, Xp, N, F, D, g_m, g_Xp);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+extern "C" int gn_eqff_backward_b(const float* g_ctx, const float* ctx, const float* Xp, const float* g_h,
+                                  int N, int F, int D, float* g_Xp, float* g_h1, void* stream) {
+    if (N < 0 || F <= 0 || (F & 3) || D <= 0) return GN_ERR_BAD_ARG;
+    if (N == 0) return GN_OK;
+    const size_t tot = (size_t)N * (F / 4);
+    hipLaunchKernelGGL(gn::eqff_bwd_b_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       g_ctx, ctx, Xp, g_h, N, F, D, g_Xp, g_h1);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+extern "C" int gn_edge_init_backward(const float* g_t0, const float* h, const float* feat, int ldf,
+                                     const int* rowptr, const int* src, const int* colptr, const int* perm,
+                                     int N, int F, float* g_feat, float* g_h, void* stream) {
+    if (!bwd_dim_ok(F) || N < 0 || (ldf & 3)) return GN_ERR_BAD_ARG;
+    if (N == 0) return GN_OK;
+    hipLaunchKernelGGL(gn::edge_init_bwd_kernel, dim3(gn::xcd_grid(N)), dim3(256), 0, (hipStream_t)stream,
+                       g_t0, h, feat, ldf, rowptr, src, colptr, perm, N, F, g_feat, g_h);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+extern "C" int gn_node_init_backward(const float* g_ctx, const int* z, const float* feat, int ldf, const float* cut,
+                                     const float* A_nbr, const int* rowptr, const int* src, int N, int F,
+                                     float* g_feat, float* g_cut, void* stream) {
+    if (!bwd_dim_ok(F) || N < 0 || (ldf & 3)) return GN_ERR_BAD_ARG;
+    if (N == 0) return GN_OK;
+    hipLaunchKernelGGL(gn::node_init_bwd_kernel, dim3(gn::xcd_grid(N)), dim3(256), 0, (hipStream_t)stream,
+                       g_ctx, z, feat, ldf, cut, A_nbr, rowptr, src, N, F, g_feat, g_cut);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+extern "C" int gn_layernorm_silu_backward(const float* x, const float* gamma, const float* beta, float eps,
+                                          const float* g_out, int N, int F, float* g_x, void* stream) {
+    if (N < 0 || F <= 0) return GN_ERR_BAD_ARG;
+    if (N == 0) return GN_OK;
+    hipLaunchKernelGGL(gn::layernorm_silu_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       x, gamma, beta, eps, g_out, N, F, g_x);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+extern "C" int gn_edge_geometry_backward(const float* edge_vec, const float* edge_diff, const int* src, const int* dst,
+                                         int E, int lmax, int R, const float* means, const float* betas, float cutoff,
+                                         const float* g_rl, const float* g_cut, const float* g_phi,
+                                         float* g_vec, float* g_diff, void* stream) {
+    if (E < 0 || lmax < 1 || lmax > 4 || R <= 0) return GN_ERR_BAD_ARG;
+    if (E == 0) return GN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((E + 127) / 128), block(128);
+    GN_SWITCH_LMAX(edge_geometry_bwd_kernel, grid, block, st, edge_vec, edge_diff, src, dst, E, R, means, betas,
+                   cutoff, 5.0f / cutoff, g_rl, g_cut, g_phi, g_vec, g_diff);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+extern "C" int gn_pos_scatter(const float* g_vec, const float* g_diff, const float* edge_vec,
+                              const int* rowptr, const int* colptr, const int* perm, int N, float sign,
+                              float* out, void* stream) {
+    if (N < 0) return GN_ERR_BAD_ARG;
+    if (N == 0) return GN_OK;
+    hipLaunchKernelGGL(gn::pos_scatter_kernel, dim3((3 * N + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       g_vec, g_diff, edge_vec, rowptr, colptr, perm, N, sign, out);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+extern "C" int gn_head_energy(const float* pre1, const float* W2, float b2, float scale, float shift,
+                              const float* atomref, const int* z, const int* mol_ptr, int n_mol, int Hd,
+                              float* y, float* energy, void* stream) {
+    if (n_mol < 0 || Hd <= 0) return GN_ERR_BAD_ARG;
+    if (n_mol == 0) return GN_OK;
+    hipLaunchKernelGGL(gn::head_energy_kernel, dim3(n_mol), dim3(256), 0, (hipStream_t)stream,
+                       pre1, W2, b2, scale, shift, atomref, z, mol_ptr, Hd, y, energy);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+extern "C" int gn_head_grad(const float* pre1, const float* W2, float scale, int N, int Hd, float* g_pre1, void* stream) {
+    if (N < 0 || Hd <= 0) return GN_ERR_BAD_ARG;
+    if (N == 0) return GN_OK;
+    const size_t tot = (size_t)N * Hd;
+    hipLaunchKernelGGL(gn::head_grad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       pre1, W2, scale, N, Hd, g_pre1);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}

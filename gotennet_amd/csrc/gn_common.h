@@ -15,6 +15,12 @@
 namespace gn {
 
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+// d/dx SiLU(x) = s (1 + x (1 - s)),  s = sigmoid(x)
+__device__ __forceinline__ float dsilu(float x) {
+    const float s = 1.0f / (1.0f + expf(-x));
+    return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float hsum4(float4 v) { return (v.x + v.y) + (v.z + v.w); }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

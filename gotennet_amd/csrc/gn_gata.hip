@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(
     const float4 qi = ld4(q + (size_t)i * ldqk + c0);
     for (int e = e0 + slot; e < e1; e += ns) {
         const float4 kj = ld4(k + (size_t)src[e] * ldqk + c0);
-        const float4 te = ld4(ta + (size_t)e * ldt + c0);
+        float4 te = ld4(ta + (size_t)e * ldt + c0);          // stored pre-activation: t_attn = SiLU(.)
+        te = make_float4(silu(te.x), silu(te.y), silu(te.z), silu(te.w));
         float p = qi.x * kj.x * te.x;
         p += qi.y * kj.y * te.y;
         p += qi.z * kj.z * te.z;

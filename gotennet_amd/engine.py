@@ -1,22 +1,24 @@
-"""Launch sequencer for the HIP hot path.
+"""Launch sequencer for the HIP hot path (forward, and the force backward).
 
 Takes raw device tensors + packed weights and issues the C-ABI calls of
 include/gotennet_hip.h on the current PyTorch-ROCm stream.  PyTorch is plumbing
-here (device memory from the caching allocator, the stream); all arithmetic is
-in libgotennet_hip.so.  Nothing in this file synchronises with the host, so a
-forward can be captured in a hipGraph (torch.cuda.CUDAGraph).
+here (device memory from the caching allocator, the stream, integer index
+sorting for the CSC view); all floating-point arithmetic is in
+libgotennet_hip.so.  Nothing in ``forward``/``backward`` synchronises with the
+host, so a step can be captured in a hipGraph (torch.cuda.CUDAGraph).
 
-Call order = the reference's op order in GotenNet.forward (gotennet.py:956-1010)
-and GATA.forward (366-450) / EQFF.forward (716-748).
+Call order = the reference's op order in GotenNet.forward (gotennet.py:956-1010),
+GATA.forward (366-450) and EQFF.forward (716-748); ``backward`` walks it in
+reverse (what torch.autograd.grad does for the reference at outputs.py:365-375).
+Activations are stored PRE-activation; consumers apply SiLU while loading.
 """
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 
-from . import _lib
 from ._lib import call, ptr
 
 
@@ -26,12 +28,13 @@ class LayerWeights:
     Ws2: torch.Tensor; bs2: torch.Tensor          # gamma_s.1 [MF, F]
     Wv2: torch.Tensor; bv2: torch.Tensor          # gamma_v.1 [MF, F]
     We: torch.Tensor; be: torch.Tensor            # [W_re; W_rs] [(1+M)F, F]
+    Wvu: torch.Tensor
+    Wm0: torch.Tensor; bm0: torch.Tensor
+    Wm1: torch.Tensor; bm1: torch.Tensor
     Wt: Optional[torch.Tensor] = None; bt: Optional[torch.Tensor] = None   # gamma_t
     Wvq: Optional[torch.Tensor] = None
     Wvk: List[torch.Tensor] = field(default_factory=list)
-    Wvu: torch.Tensor = None
-    Wm0: torch.Tensor = None; bm0: torch.Tensor = None
-    Wm1: torch.Tensor = None; bm1: torch.Tensor = None
+    T: dict = field(default_factory=dict)         # lazily built transposes for the backward
 
 
 @dataclass
@@ -42,6 +45,16 @@ class PackedWeights:
     Wb: torch.Tensor; bb: torch.Tensor
     means: torch.Tensor; betas: torch.Tensor
     layers: List[LayerWeights] = field(default_factory=list)
+    T: dict = field(default_factory=dict)
+
+
+def _T(holder, name: str) -> torch.Tensor:
+    """Transposed copy ([in, out] -> the GEMM's [out', in'] layout for input-gradients), cached."""
+    t = holder.T.get(name)
+    if t is None:
+        t = getattr(holder, name).t().contiguous()
+        holder.T[name] = t
+    return t
 
 
 @dataclass
@@ -59,21 +72,25 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def gemm(A, lda, W, bias, C, ldc, rows, nout, K, act=(0, 0), rowmap=(1, 1, 0), res=None, gate=None, a_off=0):
-    """C = epi(A W^T + bias); ``a_off`` = float offset of the first A column."""
-    a_ptr = A.data_ptr() + 4 * a_off
-    call("gn_gemm", a_ptr, lda, ptr(W), ptr(bias), ptr(C), ldc, rows, nout, K, act[0], act[1],
-         rowmap[0], rowmap[1], rowmap[2], ptr(res), ptr(gate), _stream())
+def gemm(A, lda, W, bias, C, ldc, rows, nout, K, act=(0, 0), rowmap=(1, 1, 0), res=None, gate=None,
+         a_off=0, c_off=0, pre_out=None, pro=(0, 0, 0), a_pre=None, ldp=0, p_off=0, a_gate=None, ldg=0):
+    """C = epi(pro(A) W^T + bias).  ``a_off`` / ``c_off`` / ``p_off``: float offsets of the first column."""
+    call("gn_gemm_ex", A.data_ptr() + 4 * a_off, lda, ptr(W), ptr(bias), C.data_ptr() + 4 * c_off, ldc,
+         rows, nout, K, act[0], act[1], rowmap[0], rowmap[1], rowmap[2], ptr(res), ptr(gate), ptr(pre_out),
+         pro[0], pro[1], pro[2], (a_pre.data_ptr() + 4 * p_off) if a_pre is not None else None, ldp,
+         ptr(a_gate), ldg, _stream())
 
 
 class Graph:
-    """CSR-by-target view of an edge list + per-edge geometry (K1)."""
+    """CSR-by-target view of a target-sorted edge list + per-edge geometry (K1);
+    ``csc()`` adds the by-source view the backward needs."""
 
     def __init__(self, cfg: Config, pw: PackedWeights, n_atoms: int, edge_index: torch.Tensor,
                  edge_diff: torch.Tensor, edge_vec: torch.Tensor):
         dev = edge_index.device
         E = edge_index.shape[1]
         self.N, self.E = n_atoms, E
+        self.edge_diff, self.edge_vec = edge_diff, edge_vec
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         self.src = torch.empty(E, **i32)
@@ -91,51 +108,91 @@ class Graph:
         call("gn_edge_geometry", ptr(edge_vec), ptr(edge_diff), ptr(self.src), ptr(self.dst), E,
              cfg.lmax, cfg.R, ptr(pw.means), ptr(pw.betas), float(cfg.cutoff),
              ptr(self.rl), ptr(self.phi), ptr(self.cut), st)
+        self.perm = self.colptr = None
+
+    def csc(self):
+        """Edges grouped by source (stable): integer index plumbing, no host sync."""
+        if self.perm is None:
+            self.perm = torch.sort(self.src, stable=True).indices.to(torch.int32)
+            cnt = torch.bincount(self.src, minlength=self.N)
+            self.colptr = torch.zeros(self.N + 1, dtype=torch.int32, device=self.src.device)
+            self.colptr[1:] = torch.cumsum(cnt, 0)
+        return self.colptr, self.perm
 
 
-def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph,
-            trace: Optional[list] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(h [N,F], X [N,D,F]) for target-sorted edges.  ``trace`` (tests only) collects
-    per-layer clones of (h, X, t)."""
+@dataclass
+class LayerTape:
+    h_in: torch.Tensor = None; X_in: torch.Tensor = None; t_in: torch.Tensor = None
+    nproj: torch.Tensor = None; xs: torch.Tensor = None; vs: torch.Tensor = None
+    eproj: torch.Tensor = None; attn: torch.Tensor = None
+    EQ: torch.Tensor = None; EK: torch.Tensor = None; w: torch.Tensor = None; pre_t: torch.Tensor = None
+    Xp: torch.Tensor = None; ctx: torch.Tensor = None; pre_g1: torch.Tensor = None; mm: torch.Tensor = None
+
+
+@dataclass
+class Tape:
+    feat: torch.Tensor = None; y_pre: torch.Tensor = None; h0: torch.Tensor = None
+    layers: List[LayerTape] = field(default_factory=list)
+
+
+def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: bool = False,
+            trace: Optional[list] = None):
+    """-> (h [N,F], X [N,D,F], tape or None).  ``save`` keeps what ``backward`` needs;
+    ``trace`` (tests only) collects per-layer clones of (h, X, t)."""
     F_, R, H, D, M, lmax = cfg.F, cfg.R, cfg.H, cfg.D, cfg.M, cfg.lmax
     N, E = g.N, g.E
-    dev = z32.device
-    f32 = dict(dtype=torch.float32, device=dev)
+    f32 = dict(dtype=torch.float32, device=z32.device)
     st = _stream()
     new = lambda *shape: torch.empty(shape, **f32)
+    tape = Tape() if save else None
 
     # ---- init (gotennet.py:973-977) -------------------------------------------------
     feat = new(E, 2 * F_)
     gemm(g.phi, R, pw.Winit, pw.binit, feat, 2 * F_, E, 2 * F_, R)
-    ctx = new(N, 2 * F_)
+    ctx0 = new(N, 2 * F_)
     call("gn_node_init", ptr(z32), ptr(g.rowptr), ptr(g.src), ptr(feat), 2 * F_, ptr(g.cut),
-         ptr(pw.A_na), ptr(pw.A_nbr), N, F_, ptr(ctx), st)
+         ptr(pw.A_na), ptr(pw.A_nbr), N, F_, ptr(ctx0), st)
+    y_pre = new(N, F_)
+    gemm(ctx0, 2 * F_, pw.Wa, pw.ba, y_pre, F_, N, F_, 2 * F_)
     y = new(N, F_)
-    gemm(ctx, 2 * F_, pw.Wa, pw.ba, y, F_, N, F_, 2 * F_)
-    call("gn_layernorm_silu", ptr(y), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, N, F_, ptr(y), st)
+    call("gn_layernorm_silu", ptr(y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, N, F_, ptr(y), st)
     h = new(N, F_)
     gemm(y, F_, pw.Wb, pw.bb, h, F_, N, F_, F_)
     t = new(E, F_)
     call("gn_edge_init", ptr(h), ptr(g.rowptr), ptr(g.src), feat.data_ptr() + 4 * F_, 2 * F_, N, F_, ptr(t), st)
-    del feat
+    if save:
+        tape.feat, tape.y_pre, tape.h0 = feat, y_pre, h
 
     X = torch.zeros((N, D, F_), **f32)            # gotennet.py:992
-    h2, X2, t2 = new(N, F_), new(N, D, F_), new(E, F_)
-    nproj = new(N, 4 * F_)
-    xs, vs = new(N, M * F_), new(N, M * F_)
-    eproj = new(E, (1 + M) * F_)
-    attn = new(E, H)
-    EQ, EK, Xp = new(N, D, F_), new(N, D, F_), new(N, D, F_)
-    w = new(E, F_)
-    g1, mm = new(N, F_), new(N, 2 * F_)
     lde = (1 + M) * F_
+    if not save:                                   # inference: ping-pong work buffers, reused by every layer
+        h2, X2, t2 = new(N, F_), new(N, D, F_), new(E, F_)
+        nproj, xs, vs = new(N, 4 * F_), new(N, M * F_), new(N, M * F_)
+        eproj, attn = new(E, lde), new(E, H)
+        EQ, EK, Xp, w = new(N, D, F_), new(N, D, F_), new(N, D, F_), new(E, F_)
+        ctx, pre_g1, mm = new(N, 2 * F_), new(N, F_), new(N, 2 * F_)
 
     for li, lw in enumerate(pw.layers):
-        # ---- GATA projections (gotennet.py:400-407)
-        gemm(h, F_, lw.Wn1, lw.bn1, nproj, 4 * F_, N, 4 * F_, F_, act=(2 * F_, 4 * F_))
-        gemm(nproj, 4 * F_, lw.Ws2, lw.bs2, xs, M * F_, N, M * F_, F_, a_off=2 * F_)
-        gemm(nproj, 4 * F_, lw.Wv2, lw.bv2, vs, M * F_, N, M * F_, F_, a_off=3 * F_)
-        gemm(t, F_, lw.We, lw.be, eproj, lde, E, lde, F_, act=(0, F_))
+        last = lw.Wt is None
+        if save:                                   # every layer keeps its own activations
+            lt = LayerTape(h_in=h, X_in=X, t_in=t)
+            tape.layers.append(lt)
+            h2, X2 = new(N, F_), new(N, D, F_)
+            t2 = None if last else new(E, F_)
+            nproj, xs, vs = new(N, 4 * F_), new(N, M * F_), new(N, M * F_)
+            eproj, attn = new(E, lde), new(E, H)
+            Xp, ctx, pre_g1, mm = new(N, D, F_), new(N, 2 * F_), new(N, F_), new(N, 2 * F_)
+            if not last:
+                EQ, EK, w = new(N, D, F_), new(N, D, F_), new(E, F_)
+                lt.pre_t = new(E, F_)
+                lt.EQ, lt.EK, lt.w = EQ, EK, w
+            lt.nproj, lt.xs, lt.vs, lt.eproj, lt.attn = nproj, xs, vs, eproj, attn
+            lt.Xp, lt.ctx, lt.pre_g1, lt.mm = Xp, ctx, pre_g1, mm
+        # ---- GATA projections (gotennet.py:400-407); SiLU applied by the consumers
+        gemm(h, F_, lw.Wn1, lw.bn1, nproj, 4 * F_, N, 4 * F_, F_)
+        gemm(nproj, 4 * F_, lw.Ws2, lw.bs2, xs, M * F_, N, M * F_, F_, a_off=2 * F_, pro=(1, 0, F_))
+        gemm(nproj, 4 * F_, lw.Wv2, lw.bv2, vs, M * F_, N, M * F_, F_, a_off=3 * F_, pro=(1, 0, F_))
+        gemm(t, F_, lw.We, lw.be, eproj, lde, E, lde, F_)
         # ---- message / softmax / aggregate / residual (452-559, 613-640, 426-427)
         call("gn_attn_softmax", ptr(nproj), nproj.data_ptr() + 4 * F_, 4 * F_, ptr(eproj), lde,
              ptr(g.rowptr), ptr(g.src), ptr(g.outdeg), N, F_, H, ptr(attn), st)
@@ -145,7 +202,7 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph,
         h, h2 = h2, h
         X, X2 = X2, X
         # ---- HTR (429-445, 561-611)
-        if lw.Wt is not None:
+        if not last:
             gemm(X, F_, lw.Wvq, None, EQ, F_, N * D, F_, F_)
             off = 0
             for l in range(1, lmax + 1):
@@ -153,14 +210,117 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph,
                 gemm(X, F_, lw.Wvk[l - 1], None, EK, F_, N * cnt, F_, F_, rowmap=(cnt, D, off))
                 off += cnt
             call("gn_htr_edge", ptr(EQ), ptr(EK), ptr(g.rl), ptr(g.rowptr), ptr(g.src), N, F_, lmax, ptr(w), st)
-            gemm(t, F_, lw.Wt, lw.bt, t2, F_, E, F_, F_, act=(0, F_), res=t, gate=w)
+            gemm(t, F_, lw.Wt, lw.bt, t2, F_, E, F_, F_, act=(0, F_), res=t, gate=w,
+                 pre_out=lt.pre_t if save else None)
             t, t2 = t2, t
         # ---- EQFF (716-748)
         gemm(X, F_, lw.Wvu, None, Xp, F_, N * D, F_, F_)
         call("gn_eqff_context", ptr(h), ptr(Xp), float(cfg.eps), N, F_, D, ptr(ctx), st)
-        gemm(ctx, 2 * F_, lw.Wm0, lw.bm0, g1, F_, N, F_, 2 * F_, act=(0, F_))
-        gemm(g1, F_, lw.Wm1, lw.bm1, mm, 2 * F_, N, 2 * F_, F_)
+        gemm(ctx, 2 * F_, lw.Wm0, lw.bm0, pre_g1, F_, N, F_, 2 * F_)
+        gemm(pre_g1, F_, lw.Wm1, lw.bm1, mm, 2 * F_, N, 2 * F_, F_, pro=(1, 0, F_))
         call("gn_eqff_update", ptr(mm), ptr(Xp), N, F_, D, ptr(h), ptr(X), st)
         if trace is not None:
             trace.append((h.clone(), X.clone(), t.clone()))
-    return h, X
+    return h, X, tape
+
+
+def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: Tape,
+             gh: torch.Tensor, gX: Optional[torch.Tensor]):
+    """Input-gradients of ``forward``: given dL/dh [N,F] and dL/dX [N,D,F] (or None = 0)
+    returns (g_edge_vec [E,3], g_edge_diff [E]) in the CSR edge order of ``g``."""
+    F_, R, H, D, M, lmax = cfg.F, cfg.R, cfg.H, cfg.D, cfg.M, cfg.lmax
+    N, E = g.N, g.E
+    f32 = dict(dtype=torch.float32, device=z32.device)
+    st = _stream()
+    new = lambda *shape: torch.empty(shape, **f32)
+    colptr, perm = g.csc()
+    lde = (1 + M) * F_
+
+    g_rl = torch.zeros((E, D), **f32)
+    g_cut = torch.zeros(E, **f32)
+    gh = gh.contiguous()
+    gX = torch.zeros((N, D, F_), **f32) if gX is None else gX.contiguous()
+    gt = None                                      # dL/dt of the layer output (None = 0)
+
+    gm, gXp, g_g1, g_ctx = new(N, 2 * F_), new(N, D, F_), new(N, F_), new(N, 2 * F_)
+    gh1, gX1, gX2, gh2 = new(N, F_), new(N, D, F_), new(N, D, F_), new(N, F_)
+    gEQ, gEK = new(N, D, F_), new(N, D, F_)
+    g_eproj, g_s = new(E, lde), new(E, H)
+    g_nproj, g_x, g_v = new(N, 4 * F_), new(N, M * F_), new(N, M * F_)
+    gt_a, gt_b = new(E, F_), new(E, F_)
+
+    for li in reversed(range(len(pw.layers))):
+        lw, lt = pw.layers[li], tape.layers[li]
+        last = lw.Wt is None
+        # ---- EQFF backward
+        call("gn_eqff_backward_a", ptr(gh), ptr(gX), ptr(lt.mm), ptr(lt.Xp), N, F_, D, ptr(gm), ptr(gXp), st)
+        gemm(gm, 2 * F_, _T(lw, "Wm1"), None, g_g1, F_, N, F_, 2 * F_)
+        gemm(g_g1, F_, _T(lw, "Wm0"), None, g_ctx, 2 * F_, N, 2 * F_, F_, pro=(2, 0, F_), a_pre=lt.pre_g1, ldp=F_)
+        call("gn_eqff_backward_b", ptr(g_ctx), ptr(lt.ctx), ptr(lt.Xp), ptr(gh), N, F_, D, ptr(gXp), ptr(gh1), st)
+        gemm(gXp, F_, _T(lw, "Wvu"), None, gX1, F_, N * D, F_, F_, res=gX)
+        # ---- HTR backward
+        if not last:
+            if gt is None:
+                raise RuntimeError("internal: missing edge gradient")
+            call("gn_htr_backward", ptr(gt), ptr(lt.pre_t), ptr(lt.EQ), ptr(lt.EK), ptr(g.rl),
+                 ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm), N, F_, lmax,
+                 ptr(gEQ), ptr(gEK), ptr(g_rl), st)
+            gemm(gEQ, F_, _T(lw, "Wvq"), None, gX1, F_, N * D, F_, F_, res=gX1)
+            off = 0
+            for l in range(1, lmax + 1):
+                cnt = 2 * l + 1
+                wkT = lw.T.get(("Wvk", l))
+                if wkT is None:
+                    wkT = lw.Wvk[l - 1].t().contiguous()
+                    lw.T[("Wvk", l)] = wkT
+                gemm(gEK, F_, wkT, None, gX1, F_, N * cnt, F_, F_, rowmap=(cnt, D, off), res=gX1)
+                off += cnt
+            # gt_a = gt + ((gt * w) * SiLU'(pre_t)) Wt
+            gemm(gt, F_, _T(lw, "Wt"), None, gt_a, F_, E, F_, F_, res=gt,
+                 pro=(2, 0, F_), a_pre=lt.pre_t, ldp=F_, a_gate=lt.w, ldg=F_)
+            gt_in = gt_a
+        else:
+            gt_in = None
+        # ---- message backward
+        call("gn_message_backward", ptr(lt.xs), ptr(lt.vs), M * F_, ptr(lt.eproj), lde, ptr(lt.attn),
+             ptr(lt.nproj), 4 * F_, ptr(lt.X_in), ptr(g.rl), ptr(g.cut), ptr(g.outdeg),
+             ptr(gh1), ptr(gX1), ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm),
+             ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), ptr(gX2), ptr(g_rl), ptr(g_cut),
+             N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), st)
+        gemm(g_x, M * F_, _T(lw, "Ws2"), None, g_nproj, 4 * F_, N, F_, M * F_, c_off=2 * F_)
+        gemm(g_v, M * F_, _T(lw, "Wv2"), None, g_nproj, 4 * F_, N, F_, M * F_, c_off=3 * F_)
+        gemm(g_nproj, 4 * F_, _T(lw, "Wn1"), None, gh2, F_, N, F_, 4 * F_, res=gh1,
+             pro=(2, 2 * F_, 4 * F_), a_pre=lt.nproj, ldp=4 * F_)
+        gemm(g_eproj, lde, _T(lw, "We"), None, gt_b, F_, E, F_, lde, res=gt_in,
+             pro=(2, 0, F_), a_pre=lt.eproj, ldp=lde)
+        gh, gh2 = gh2, gh
+        gX, gX2 = gX2, gX
+        gt, gt_b = gt_b, (gt if gt is not None else new(E, F_))
+
+    # ---- init backward (layers.py:1658-1714) ------------------------------------------
+    g_feat = new(E, 2 * F_)
+    call("gn_edge_init_backward", ptr(gt), ptr(tape.h0), ptr(tape.feat), 2 * F_, ptr(g.rowptr), ptr(g.src),
+         ptr(colptr), ptr(perm), N, F_, ptr(g_feat), ptr(gh), st)
+    gy = new(N, F_)
+    gemm(gh, F_, _T(pw, "Wb"), None, gy, F_, N, F_, F_)
+    gy1 = new(N, F_)
+    call("gn_layernorm_silu_backward", ptr(tape.y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, ptr(gy), N, F_, ptr(gy1), st)
+    gemm(gy1, F_, _T(pw, "Wa"), None, g_ctx, 2 * F_, N, 2 * F_, F_)
+    call("gn_node_init_backward", ptr(g_ctx), ptr(z32), ptr(tape.feat), 2 * F_, ptr(g.cut), ptr(pw.A_nbr),
+         ptr(g.rowptr), ptr(g.src), N, F_, ptr(g_feat), ptr(g_cut), st)
+    g_phi = new(E, R)
+    gemm(g_feat, 2 * F_, _T(pw, "Winit"), None, g_phi, R, E, R, 2 * F_)
+    g_vec, g_diff = new(E, 3), new(E)
+    call("gn_edge_geometry_backward", ptr(g.edge_vec), ptr(g.edge_diff), ptr(g.src), ptr(g.dst), E, lmax, R,
+         ptr(pw.means), ptr(pw.betas), float(cfg.cutoff), ptr(g_rl), ptr(g_cut), ptr(g_phi),
+         ptr(g_vec), ptr(g_diff), st)
+    return g_vec, g_diff
+
+
+def pos_gradient(g: Graph, g_vec: torch.Tensor, g_diff: torch.Tensor, sign: float = 1.0) -> torch.Tensor:
+    """sign * dL/dpos for edge_vec = pos[j] - pos[i], edge_diff = |edge_vec| (Distance, layers.py:1593-1600)."""
+    colptr, perm = g.csc()
+    out = torch.empty((g.N, 3), dtype=torch.float32, device=g_vec.device)
+    call("gn_pos_scatter", ptr(g_vec), ptr(g_diff), ptr(g.edge_vec), ptr(g.rowptr), ptr(colptr), ptr(perm),
+         g.N, float(sign), ptr(out), _stream())
+    return out

@@ -23,6 +23,48 @@ from .layers import (MLP, CosineCutoff, Dense, EdgeInit, NodeInit, get_weight_in
                      resolve_activation, str2basis)
 
 
+class _RepresentationFn(torch.autograd.Function):
+    """(edge_diff, edge_vec) -> (h, X) with the hand-written backward (engine.backward), so a
+    reference-style caller can do torch.autograd.grad(energy, pos) through this module
+    (reference outputs.py:365-375 / goten_model.py:580-588)."""
+
+    @staticmethod
+    def forward(ctx, edge_diff, edge_vec, net, z32, edge_index):
+        cfg, pw = net.config(), net.packed_weights()
+        g = engine.Graph(cfg, pw, z32.shape[0], edge_index, edge_diff.detach(), edge_vec.detach())
+        h, X, tape = engine.forward(cfg, pw, z32, g, save=True)
+        ctx.state = (cfg, pw, z32, g, tape)
+        return h, X
+
+    @staticmethod
+    def backward(ctx, gh, gX):
+        cfg, pw, z32, g, tape = ctx.state
+        g_vec, g_diff = engine.backward(cfg, pw, z32, g, tape, gh, gX)
+        # (an unsorted edge list was sorted with differentiable indexing in GotenNet.forward, so
+        # autograd un-permutes these gradients itself)
+        return g_diff, g_vec, None, None, None
+
+
+class _RepresentationPosFn(torch.autograd.Function):
+    """pos -> (h, X) including the radius graph (GotenNetWrapper.forward, gotennet.py:1043-1045)."""
+
+    @staticmethod
+    def forward(ctx, pos, net, z32, batch):
+        from .graph import distance
+        cfg, pw = net.config(), net.packed_weights()
+        edge_index, edge_diff, edge_vec = distance(pos.detach(), batch, net.cutoff, net.max_num_neighbors)
+        g = engine.Graph(cfg, pw, z32.shape[0], edge_index, edge_diff, edge_vec)
+        h, X, tape = engine.forward(cfg, pw, z32, g, save=True)
+        ctx.state = (cfg, pw, z32, g, tape)
+        return h, X
+
+    @staticmethod
+    def backward(ctx, gh, gX):
+        cfg, pw, z32, g, tape = ctx.state
+        g_vec, g_diff = engine.backward(cfg, pw, z32, g, tape, gh, gX)
+        return engine.pos_gradient(g, g_vec, g_diff, sign=1.0), None, None, None
+
+
 class GATA(nn.Module):
     """Parameter container for one GATA layer (reference gotennet.py:78-317)."""
 
@@ -259,15 +301,19 @@ class GotenNet(nn.Module):
         edge_index = edge_index.contiguous()
         edge_diff = edge_diff.to(torch.float32).contiguous()
         edge_vec = edge_vec.to(torch.float32).contiguous()
+        order = None
         if not self.assume_sorted_edges and edge_index.shape[1] > 1:
             tgt = edge_index[1]
             if not bool((tgt[1:] >= tgt[:-1]).all()):       # one host sync; skipped when assume_sorted_edges
                 order = torch.sort(tgt, stable=True).indices  # keeps the relative order inside a target row
                 edge_index, edge_diff, edge_vec = edge_index[:, order].contiguous(), edge_diff[order], edge_vec[order]
+        z32 = atomic_numbers.to(torch.int32)
+        if torch.is_grad_enabled() and (edge_vec.requires_grad or edge_diff.requires_grad):
+            return _RepresentationFn.apply(edge_diff.contiguous(), edge_vec.contiguous(), self, z32, edge_index)
         with torch.no_grad():
-            z32 = atomic_numbers.to(torch.int32)
             g = engine.Graph(cfg, pw, N, edge_index, edge_diff, edge_vec)
-            return engine.forward(cfg, pw, z32, g, trace=_trace)
+            h, X, _ = engine.forward(cfg, pw, z32, g, trace=_trace)
+            return h, X
 
 
 class GotenNetWrapper(GotenNet):
@@ -280,6 +326,9 @@ class GotenNetWrapper(GotenNet):
     def forward(self, inputs) -> Tuple[Tensor, Tensor]:
         from .graph import distance
         atomic_numbers, pos, batch = inputs.z, inputs.pos, inputs.batch
+        if torch.is_grad_enabled() and pos.requires_grad:
+            self._check_inputs(atomic_numbers, torch.zeros((2, 0), dtype=torch.int64), pos.new_zeros(0), pos.new_zeros((0, 3)))
+            return _RepresentationPosFn.apply(pos, self, atomic_numbers.to(torch.int32), batch)
         edge_index, edge_diff, edge_vec = distance(pos, batch, self.cutoff, self.max_num_neighbors)
         sorted_flag, self.assume_sorted_edges = self.assume_sorted_edges, True   # radius graph is target-major
         try:

@@ -92,11 +92,24 @@ int gn_gemm(const float* A, int lda, const float* W, const float* bias, float* C
             int row_cnt, int row_gstride, int row_goff,
             const float* res, const float* gate, void* stream);
 
+/* Extended form used by the pipeline.  Extra epilogue: pre_out (if non-NULL) receives the value BEFORE
+ * the activation (same addressing as C); `res` alone (gate == NULL) gives C = res + value.  Prologue on A,
+ * applied while staging, on A columns [pro_lo, pro_hi): pro_mode 1: A <- SiLU(A) (activations are stored
+ * pre-activation); pro_mode 2: A <- A * SiLU'(a_pre) (backward through a SiLU; a_pre has A's row addressing
+ * with leading dim ldp); and A <- A * a_gate on every column when a_gate != NULL (leading dim ldg). */
+int gn_gemm_ex(const float* A, int lda, const float* W, const float* bias, float* C, int ldc,
+               int Mrows, int Nout, int K, int act_lo, int act_hi,
+               int row_cnt, int row_gstride, int row_goff,
+               const float* res, const float* gate, float* pre_out,
+               int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
+               const float* a_gate, int ldg, void* stream);
+
 /* ---- K6 GATA message / softmax / aggregate -------------------------------------------- */
 /* Attention weights (gotennet.py:497-511): s[e,h] = sum_{c in head h} q[i,c] k[j,c] t_attn[e,c];
  * a = exp(s - max) / (sum + 1e-16) over the incoming edges of i (PyG softmax), then
  * a *= 1/sqrt(F)  or  sqrt(outdeg[j])/sqrt(F) when outdeg != NULL (scale_edge).  a is [E,H].
- * q,k are rows of ldqk floats, t_attn rows of ldt floats. */
+ * q,k are rows of ldqk floats; t_attn rows of ldt floats hold the PRE-activation W_re t + b
+ * (the kernel applies SiLU while loading). */
 int gn_attn_softmax(const float* q, const float* k, int ldqk, const float* t_attn, int ldt,
                     const int* rowptr, const int* src, const int* outdeg,
                     int N, int F, int H, float* a, void* stream);
@@ -124,6 +137,68 @@ int gn_htr_edge(const float* EQ, const float* EK, const float* rl, const int* ro
 int gn_eqff_context(const float* h, const float* Xp, float eps, int N, int F, int D, float* ctx, void* stream);
 /* h += m[:, 0:F];  X += m[:, F:2F] (broadcast over D) * Xp           (gotennet.py:741-746); m is [N,2F] */
 int gn_eqff_update(const float* m, const float* Xp, int N, int F, int D, float* h, float* X, void* stream);
+
+/* ---- K10 force backward (input gradients only; what torch.autograd.grad does for the reference at
+ *      outputs.py:365-375).  Needs the by-source (CSC) view: perm[colptr[j] .. colptr[j+1]) lists the CSR
+ *      edge ids whose source is j.  F <= 256.  g_rl [E,D] and g_cut [E] are ACCUMULATED (zero them first). */
+
+/* HTR (gotennet.py:561-611) backward: g_t_out = dL/dt' [E,F], pre_t = W_t t + b (saved), w.r.t. EQ, EK and rl. */
+int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* EQ, const float* EK,
+                    const float* rl, const int* rowptr, const int* src, const int* dst,
+                    const int* colptr, const int* perm, int N, int F, int lmax,
+                    float* gEQ, float* gEK, float* g_rl, void* stream);
+
+/* GATA message/softmax/aggregate (gotennet.py:452-559, 613-640) backward.  Inputs: saved x, v [N,MF];
+ * eproj [E,(1+M)F] = (pre-activation of t_attn | t_filter); a [E,H]; qk rows with q at column 0 and k at
+ * column F; X_in [N,D,F]; upstream g_h1 [N,F], g_X1 [N,D,F].  Outputs: g_eproj [E,(1+M)F] (gradient w.r.t.
+ * SiLU(t_attn pre-activation) | t_filter), g_s [E,H] scratch, g_nproj rows (ldn) with g_q at column 0 and g_k
+ * at column F, g_x, g_v [N,MF], g_X_out = g_X1 + (tensor-gate path), g_rl, g_cut accumulated. */
+int gn_message_backward(const float* x, const float* v, int ldxv, const float* eproj, int lde, const float* a,
+                        const float* qk, int ldqk, const float* X_in, const float* rl, const float* cut,
+                        const int* outdeg, const float* g_h1, const float* g_X1,
+                        const int* rowptr, const int* src, const int* dst, const int* colptr, const int* perm,
+                        float* g_eproj, float* g_s, float* g_nproj, int ldn, float* g_x, float* g_v,
+                        float* g_X_out, float* g_rl, float* g_cut,
+                        int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream);
+
+/* EQFF (gotennet.py:716-748) backward, node-local halves around the two gamma_m GEMMs:
+ * a: g_m = [g_h | sum_m g_X Xp], g_Xp = g_X * m2;   b: g_Xp += g_ctx[:,F:] Xp / n, g_h1 = g_h + g_ctx[:, :F]. */
+int gn_eqff_backward_a(const float* g_h, const float* g_X, const float* m, const float* Xp,
+                       int N, int F, int D, float* g_m, float* g_Xp, void* stream);
+int gn_eqff_backward_b(const float* g_ctx, const float* ctx, const float* Xp, const float* g_h,
+                       int N, int F, int D, float* g_Xp, float* g_h1, void* stream);
+
+/* EdgeInit (layers.py:1709-1710) backward: g_feat[e, F:2F] = g_t0 (h_i + h_j); g_h[n] += in- and out-edge sums
+ * of g_t0 * feat[e, F:2F].  feat/g_feat are the [E, 2F] radial projections (W_ndp | W_erp). */
+int gn_edge_init_backward(const float* g_t0, const float* h, const float* feat, int ldf,
+                          const int* rowptr, const int* src, const int* colptr, const int* perm,
+                          int N, int F, float* g_feat, float* g_h, void* stream);
+/* NodeInit aggregate (layers.py:1666-1675) backward: g_feat[e, 0:F] and g_cut[e] += from g_ctx[:, F:2F]. */
+int gn_node_init_backward(const float* g_ctx, const int* z, const float* feat, int ldf, const float* cut,
+                          const float* A_nbr, const int* rowptr, const int* src, int N, int F,
+                          float* g_feat, float* g_cut, void* stream);
+int gn_layernorm_silu_backward(const float* x, const float* gamma, const float* beta, float eps,
+                               const float* g_out, int N, int F, float* g_x, void* stream);
+
+/* Edge geometry (K1) backward: (g_rl, g_cut, g_phi) -> g_vec [E,3] through the unit vector and harmonics,
+ * g_diff [E] through cutoff and radial basis.  Self-loops get zeros. */
+int gn_edge_geometry_backward(const float* edge_vec, const float* edge_diff, const int* src, const int* dst,
+                              int E, int lmax, int R, const float* means, const float* betas, float cutoff,
+                              const float* g_rl, const float* g_cut, const float* g_phi,
+                              float* g_vec, float* g_diff, void* stream);
+/* out[n] = sign * ( sum_{src(e)=n} gv_e - sum_{dst(e)=n} gv_e ), gv = g_vec + g_diff * edge_vec/|edge_vec|
+ * (Distance.forward, layers.py:1593-1600: edge_vec = pos[j]-pos[i], edge_weight = |edge_vec|). sign=-1: forces. */
+int gn_pos_scatter(const float* g_vec, const float* g_diff, const float* edge_vec,
+                   const int* rowptr, const int* colptr, const int* perm, int N, float sign,
+                   float* out, void* stream);
+
+/* ---- K10 energy head (Atomwise, outputs.py:323-376; SchnetMLP layers.py:225-273, 2 layers, SiLU) ------- */
+/* y_n = scale * (sum_k SiLU(pre1[n,k]) W2[k] + b2) + shift (+ atomref[z_n]); energy[b] = sum_{n in molecule b} y_n.
+ * pre1 = W1 h + b1 comes from gn_gemm.  mol_ptr [n_mol+1] int32.  head_grad: g_pre1 = scale W2 SiLU'(pre1). */
+int gn_head_energy(const float* pre1, const float* W2, float b2, float scale, float shift,
+                   const float* atomref, const int* z, const int* mol_ptr, int n_mol, int Hd,
+                   float* y, float* energy, void* stream);
+int gn_head_grad(const float* pre1, const float* W2, float scale, int N, int Hd, float* g_pre1, void* stream);
 
 /* ---- adjacent: radius graph (Distance.forward, layers.py:1588-1604) ----------------------- */
 /* torch_cluster.radius_graph(pos, r, batch, loop=True, max_num_neighbors) semantics: edges j->i with

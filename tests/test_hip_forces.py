@@ -1,0 +1,113 @@
+"""GPU: energy + forces (hand-written backward) against the reference goldens and the oracle's autograd."""
+import types
+
+import pytest
+import torch
+
+from tests.golden_util import case_names, load_case, rel_err
+from tests.test_hip_parity import _net_from_case, _synthetic
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4          # north_star: forces within 1e-4 relative (max-norm)
+FORCE_CASES = [n for n in case_names() if "shuffled" not in n]
+
+
+def _head_from_case(cfg, head_sd):
+    from gotennet_amd.outputs import Atomwise
+    head = Atomwise(n_in=cfg["n_atom_basis"], n_hidden=16, property="property", derivative="forces")
+    head.load_state_dict(head_sd, strict=True)
+    return head.cuda().eval()
+
+
+@pytest.mark.parametrize("name", FORCE_CASES)
+def test_fused_pipeline_matches_golden(name):
+    from gotennet_amd.pipeline import EnergyForces
+    cfg, sd, head_sd, t = load_case(name)
+    net, head = _net_from_case(cfg, sd), _head_from_case(cfg, head_sd)
+    ef = EnergyForces(net, head)
+    e, f = ef(t["z"].cuda(), t["edge_index"].cuda(), t["edge_diff"].cuda(), t["edge_vec"].cuda(),
+              t["batch"].cuda(), cfg["n_mol"])
+    torch.cuda.synchronize()
+    assert rel_err(e.cpu(), t["energy"]) < TOL
+    assert rel_err(f.cpu(), t["forces"]) < TOL
+    # against fp64 truth: not meaningfully worse than the fp32 reference itself
+    assert rel_err(f.cpu(), t["forces_f64"]) < max(10 * rel_err(t["forces"], t["forces_f64"]), 2e-5)
+    e2, f2 = ef(t["z"].cuda(), t["edge_index"].cuda(), t["edge_diff"].cuda(), t["edge_vec"].cuda(),
+                t["batch"].cuda(), cfg["n_mol"])
+    assert torch.equal(f, f2) and torch.equal(e, e2)             # bit-reproducible
+
+
+@pytest.mark.parametrize("name", ["l2_sep_f32", "l1_nosep_scale_f32"])
+def test_reference_style_autograd_call(name):
+    """GotenNetWrapper + Atomwise(derivative) used the way GotenModel uses them (autograd.grad wrt pos)."""
+    import gotennet_amd
+    cfg, sd, head_sd, t = load_case(name)
+    net = gotennet_amd.GotenNetWrapper(
+        n_atom_basis=cfg["n_atom_basis"], n_interactions=cfg["n_interactions"], n_rbf=cfg["n_rbf"],
+        cutoff_fn=gotennet_amd.CosineCutoff(cfg["cutoff"]), max_z=cfg["max_z"], num_heads=cfg["num_heads"],
+        scale_edge=cfg["scale_edge"], lmax=cfg["lmax"], sep_dir=cfg["sep_dir"], sep_tensor=cfg["sep_tensor"])
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    head = _head_from_case(cfg, head_sd)
+    pos = t["pos"].cuda().requires_grad_(True)
+    inp = types.SimpleNamespace(z=t["z"].cuda(), pos=pos, batch=t["batch"].cuda())
+    inp.representation, inp.vector_representation = net(inp)
+    out = head(inp)
+    assert rel_err(out["property"].detach().cpu(), t["energy"]) < TOL
+    assert rel_err(out["forces"].detach().cpu(), t["forces"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["l2_sep_f32", "l2_sep_shuffled_noloop"])
+def test_edge_level_autograd_boundary(name):
+    """GotenNet.forward with edge_vec/edge_diff requiring grad: gradients of a random
+    functional of (h, X) w.r.t. both edge inputs match the oracle's autograd (also for an
+    unsorted edge list)."""
+    from oracle import gotennet_oracle as orc
+    cfg, sd, _, t = load_case(name)
+    net = _net_from_case(cfg, sd)
+    torch.manual_seed(0)
+    wh, wX = torch.randn_like(t["h"]), torch.randn_like(t["X"])
+    ev = t["edge_vec"].clone().requires_grad_(True)
+    ed = t["edge_diff"].clone().requires_grad_(True)
+    h, X = orc.gotennet_forward(sd, cfg, t["z"], t["edge_index"], ed, ev)
+    gv_ref, gd_ref = torch.autograd.grad((h * wh).sum() + (X * wX).sum(), [ev, ed])
+    evc = t["edge_vec"].cuda().requires_grad_(True)
+    edc = t["edge_diff"].cuda().requires_grad_(True)
+    hc, Xc = net(t["z"].cuda(), t["edge_index"].cuda(), edc, evc)
+    gv, gd = torch.autograd.grad((hc * wh.cuda()).sum() + (Xc * wX.cuda()).sum(), [evc, edc])
+    mask = t["edge_index"][0] != t["edge_index"][1]
+    assert rel_err(gv.cpu()[mask], gv_ref[mask]) < TOL
+    assert rel_err(gd.cpu()[mask], gd_ref[mask]) < TOL
+
+
+@pytest.mark.parametrize("F,L,lmax", [(128, 2, 2), (256, 2, 2), (64, 2, 4), (64, 3, 3)])
+def test_forces_match_oracle_wide(F, L, lmax):
+    import gotennet_amd
+    from gotennet_amd.graph import distance
+    from gotennet_amd.outputs import Atomwise
+    from gotennet_amd.pipeline import EnergyForces
+    from oracle import gotennet_oracle as orc
+    torch.manual_seed(F + lmax)
+    net = gotennet_amd.GotenNet(n_atom_basis=F, n_interactions=L, n_rbf=32, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
+                                num_heads=8, scale_edge=False, lmax=lmax, sep_dir=True, sep_tensor=True)
+    head = Atomwise(n_in=F, n_hidden=64, derivative="forces")
+    with torch.no_grad():
+        for m in (net, head):
+            for n, p in m.named_parameters():
+                if p.dim() == 1:
+                    p.uniform_(-0.05, 0.05) if "norm.weight" not in n else p.uniform_(0.9, 1.1)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    hsd = {k: v.clone() for k, v in head.state_dict().items()}
+    cfg = orc.default_config(n_atom_basis=F, n_interactions=L, n_rbf=32, num_heads=8, scale_edge=False, lmax=lmax,
+                             sep_dir=True, sep_tensor=True)
+    pos, batch, z = _synthetic(3, 14, 4.0, seed=F)
+    e_ref, f_ref, _ = orc.energy_and_forces({k: v.double() for k, v in sd.items()}, cfg,
+                                            {k: v.double() for k, v in hsd.items()}, z, pos.double(), batch, 3)
+    net, head = net.cuda().eval(), head.cuda().eval()
+    ei, w, vec = distance(pos.cuda(), batch.cuda(), 5.0, 32)
+    e, f = EnergyForces(net, head)(z.cuda(), ei, w, vec, batch.cuda(), 3)
+    assert rel_err(e.cpu(), e_ref) < TOL
+    assert rel_err(f.cpu(), f_ref) < TOL
+    # conservation: forces of an isolated molecule sum to zero (translation invariance)
+    assert float(f.cpu().reshape(3, 14, 3).sum(1).abs().max()) < 1e-3 * float(f.abs().max())
