@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""bench.py -- energy+force throughput of the GotenNet hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--lmax 2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one energy+force evaluation (representation forward, Atomwise head,
+hand-written backward, force scatter) of one synthetic batch per rank:
+rMD17-aspirin-like molecules (21 atoms, uniform in a 4.6 A cube, 5 A radius graph
+with self-loops; BASELINE.json configs[1]: batch 128, n_atom_basis 256,
+n_interactions 6, reference yaml flags lmax 2 / sep_dir / sep_tensor / 8 heads).
+Inputs (z, edge_index, edge_diff, edge_vec, batch) are resident in HBM before the
+timed region.  N > 1: molecules are sharded by batch index (rank r owns molecules
+[128 r, 128 (r+1))), weights replicated, ONE RCCL all-reduce per step on the
+zero-padded energy vector; forces stay shard-local (weak scaling).
+
+Prints one JSON line (rank 0).  `roofline` is measured live with HIP events around
+every launch of the dominant kernel inside the timed region; `cpu_baseline` times the
+CPU oracle (oracle/, a restatement pinned to the reference's golden vectors) on a
+bounded sample of the same workload on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32, exact fp32
+
+
+class KernelTimer:
+    def __init__(self, wanted=None):
+        self.wanted, self.events = wanted, []
+
+    @staticmethod
+    def tag_of(name, args):
+        if name == "gn_gemm_ex":
+            return f"gn_gemm[{args[6]}x{args[7]}x{args[8]}]"
+        return name
+
+    def want(self, name, args):
+        tag = self.tag_of(name, args)
+        return tag if (self.wanted is None or tag in self.wanted) else None
+
+    def summary(self):
+        tot, cnt = {}, {}
+        for tag, e0, e1 in self.events:
+            tot[tag] = tot.get(tag, 0.0) + e0.elapsed_time(e1)
+            cnt[tag] = cnt.get(tag, 0) + 1
+        return tot, cnt
+
+
+def algorithmic_bytes_message(N, E, F, M, D):
+    """SURVEY.md 8(d) B_msg: every distinct input element read once, every output written once."""
+    return 4 * N * (2 * F + 2 * M * F + D * F) + E * (4 * (F + M * F + D + 2) + 16) + 4 * N * (F + D * F)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="molecules per GPU")
+    ap.add_argument("--lmax", type=int, default=2)
+    ap.add_argument("--workload", default="rmd17_aspirin")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table (stderr)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import gotennet_amd
+    from gotennet_amd import _lib, synthetic
+    from gotennet_amd.graph import distance
+    from gotennet_amd.outputs import Atomwise, molecule_ptr
+    from gotennet_amd.pipeline import EnergyForces
+
+    F, L, R, H, lmax = 256, 6, 32, 8, a.lmax
+    torch.manual_seed(0)                                   # identical replicated weights on every rank
+    rep = gotennet_amd.GotenNet(n_atom_basis=F, n_interactions=L, n_rbf=R, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
+                                num_heads=H, scale_edge=False, lmax=lmax, sep_dir=True, sep_tensor=True).to(dev).eval()
+    head = Atomwise(n_in=F, n_hidden=256, derivative="forces").to(dev).eval()
+    step_fn = EnergyForces(rep, head)
+
+    B = a.batch
+    pos, batch, z = synthetic.make_batch(a.workload, B, seed=0, first_molecule=rank * B)
+    pos, batch, z = pos.to(dev), batch.to(dev), z.to(dev)
+    ei, ed, ev = distance(pos, batch, 5.0, 32)
+    mol_ptr = molecule_ptr(batch, B)
+    N, E = pos.shape[0], ei.shape[1]
+    M, D = rep.config().M, rep.config().D
+    from gotennet_amd.parallel import reduce_energies
+    e_all = torch.zeros(B * world, dtype=torch.float32, device=dev)
+
+    def step():
+        e, f = step_fn(z, ei, ed, ev, batch, B, mol_ptr=mol_ptr)
+        if dist is not None:                               # the one data-path collective (RCCL over xGMI)
+            reduce_energies(e[:, 0], rank * B, B * world, out=e_all)
+        return e, f
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- untimed: warm-up + per-kernel breakdown to pick the dominant kernel ----------
+    for _ in range(max(a.warmup, 1)):
+        step()
+    fence()
+    kt = KernelTimer()
+    _lib.TIMER = kt
+    step()
+    torch.cuda.synchronize()
+    _lib.TIMER = None
+    tot, cnt = kt.summary()
+    dominant = max(tot, key=tot.get)
+    msg_tag = "gn_message_aggregate"
+    if a.breakdown and rank == 0:
+        s = sum(tot.values())
+        for tag in sorted(tot, key=tot.get, reverse=True):
+            print(f"  {tag:42s} {tot[tag]:8.3f} ms/step {cnt[tag]:3d} calls {1e3 * tot[tag] / cnt[tag]:8.1f} us/call "
+                  f"{100 * tot[tag] / s:5.1f}%", file=sys.stderr)
+
+    # ---- timed region: exactly K steps, events only around the dominant + message kernels
+    kt = KernelTimer(wanted={dominant, msg_tag})
+    _lib.TIMER = kt
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        e, f = step()
+    fence()
+    dt = time.perf_counter() - t0
+    _lib.TIMER = None
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(e).all() and torch.isfinite(f).all()
+
+    tot, cnt = kt.summary()
+
+    def roof(tag):
+        us = 1e3 * tot[tag] / cnt[tag]
+        if tag.startswith("gn_gemm["):
+            m_, n_, k_ = (int(v) for v in tag[8:-1].split("x"))
+            flops = 2.0 * m_ * n_ * k_
+            ach = flops / (us * 1e-6) / 1e12
+            return dict(kernel=tag, bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                        frac=round(ach / MFMA_F32_PEAK_TF, 4), traffic=None, us_per_launch=round(us, 2),
+                        launches_per_step=cnt[tag] // a.steps, algorithmic_flops_per_launch=flops)
+        nbytes = algorithmic_bytes_message(N, E, F, M, D)
+        ach = nbytes / (us * 1e-6) / 1e9
+        return dict(kernel=tag, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic(tag, lmax), us_per_launch=round(us, 2),
+                    launches_per_step=cnt[tag] // a.steps, algorithmic_bytes_per_launch=nbytes)
+
+    if rank == 0:
+        out = {
+            "metric": "molecules/sec (energy+force forward), rMD17 aspirin batch=128, 1/2/4/8 MI355X",
+            "value": round(B * world * a.steps / dt, 1), "unit": "molecules/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.workload} batch={B}/GPU (N={N} atoms, E={E} edges incl. self-loops), "
+                                   f"n_atom_basis={F}, n_interactions={L}, lmax={lmax}, n_rbf={R}, heads={H}, "
+                                   "sep_dir/sep_tensor, energy+forces",
+                       "global_batch": B * world, "parallelism": f"dp{world} (molecule shards, 1 all-reduce)"},
+            "roofline": roof(dominant),
+            "roofline_gather_scatter": roof(msg_tag),
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(rep, head, a.workload, lmax)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _pmc_traffic(tag, lmax):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), if present."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return d.get(f"lmax{lmax}", {}).get(tag)
+    except Exception:
+        return None
+
+
+def cpu_baseline(rep, head, workload, lmax, n_mol=8, reps=2):
+    """The CPU oracle (checker) timed on this box's host cores: energy+forces via autograd
+    on a bounded sample (n_mol molecules of the same workload, same hyper-parameters)."""
+    from gotennet_amd import synthetic
+    from oracle import gotennet_oracle as orc
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    sd = {k: v.detach().cpu() for k, v in rep.state_dict().items()}
+    hsd = {k: v.detach().cpu() for k, v in head.state_dict().items()}
+    c = rep.config()
+    cfg = orc.default_config(n_atom_basis=c.F, n_interactions=c.L, n_rbf=c.R, num_heads=c.H, scale_edge=c.scale_edge,
+                             lmax=lmax, sep_dir=c.sep_dir, sep_tensor=c.sep_tensor, cutoff=c.cutoff)
+    pos, batch, z = synthetic.make_batch(workload, n_mol, seed=0)
+    orc.energy_and_forces(sd, cfg, hsd, z, pos, batch, n_mol)           # warm-up
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.energy_and_forces(sd, cfg, hsd, z, pos, batch, n_mol)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(n_mol / dt, 2), "unit": "molecules/s", "cores": threads, "kind": "port",
+            "sample": f"{n_mol} molecules of {workload} (same model), energy+forces by torch autograd on the CPU oracle, "
+                      f"{reps} runs after 1 warm-up, {threads} threads"}
+
+
+if __name__ == "__main__":
+    main()

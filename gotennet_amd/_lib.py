@@ -76,8 +76,23 @@ def load():
     return lib
 
 
+#: optional per-launch timer (bench/profiling only): an object with ``want(name, args) -> tag or None``
+#: and a list ``events``; matching launches are bracketed by HIP events on the current stream.
+TIMER = None
+
+
 def call(name: str, *args) -> None:
-    rc = getattr(load(), name)(*args)
+    t = TIMER
+    tag = t.want(name, args) if t is not None else None
+    if tag is not None:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(load(), name)(*args)
+        e1.record()
+        t.events.append((tag, e0, e1))
+    else:
+        rc = getattr(load(), name)(*args)
     if rc != 0:
         what = "unsupported shape/flag combination" if rc == GN_ERR_BAD_ARG else f"hipError_t {rc}"
         raise GotenNetHipError(f"{name} failed: {what}")
