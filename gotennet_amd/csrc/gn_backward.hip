@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void htr_bwd_target_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F,
     float* __restrict__ gEQ, float* __restrict__ g_rl) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
+    constexpr int KP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));
     constexpr int CH = D < 9 ? D : 9;
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
     const int i = xcd_item(blockIdx.x, N);
@@ -59,6 +60,9 @@ __global__ __launch_bounds__(256) void htr_bwd_target_kernel(
         const float4 gw = ld4(gtp + (size_t)e * F + c0) * silu4(ld4(pre_t + (size_t)e * F + c0));
         const float* kj = EK + (size_t)src[e] * D * F + c0;
         const float* re = rl + (size_t)e * D;
+        float part[KP];
+#pragma unroll
+        for (int m = D; m < KP; ++m) part[m] = 0.f;
         int m0 = 0;
 #pragma unroll
         for (int l = 1; l <= LMAX; ++l) {
@@ -80,10 +84,20 @@ __global__ __launch_bounds__(256) void htr_bwd_target_kernel(
             for (int mm = 0; mm < 2 * l + 1; ++mm) {
                 acc[m0 + mm] = fma4(gw, ek[mm] + pb * (-c * r[mm]), acc[m0 + mm]);
                 const float4 t4 = gw * ((eq[m0 + mm] * pb + pa * ek[mm]) * (-c) + papb * (2.0f * r[mm]));
-                const float s = group_sum(hsum4(t4), lps);
-                if (lp == 0) g_rl[(size_t)e * D + m0 + mm] += s;
+                part[m0 + mm] = hsum4(t4);
             }
             m0 += 2 * l + 1;
+        }
+        if (lps >= KP) {                             // one value-halving butterfly for all D sums
+            multi_group_sum<KP>(part, lps, lp);
+            const int stride = lps / KP;
+            if ((lp & (stride - 1)) == 0 && lp / stride < D) g_rl[(size_t)e * D + lp / stride] += part[0];
+        } else {
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                const float s = group_sum(part[m], lps);
+                if (lp == 0) g_rl[(size_t)e * D + m] += s;
+            }
         }
     }
     reduce_rows<D>(acc, red, slot, c0, F, ns, [&](int row, float4 s) { st4(gEQ + ((size_t)i * D + row) * F + c0, s); });
@@ -178,6 +192,7 @@ template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
 __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p) {
     using S = MsgShape<LMAX, SEP_DIR, SEP_TENSOR>;
     constexpr int D = S::D, M = S::M;
+    constexpr int KP = (D + 8) <= 16 ? 16 : 32;      // D rl sums + 8 head sums, padded to a power of two
     __shared__ __attribute__((aligned(16))) float red[1024];
     const int N = p.N, F = p.F, H = p.H;
     const int i = xcd_item(blockIdx.x, N);
@@ -236,17 +251,39 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
         }
         cutp = group_sum(cutp, lps);
         if (lp == 0) p.g_cut[e] += cutp;
+        if (H <= 8 && lps >= KP) {                   // D rl sums + up to 8 head sums in one butterfly
+            float vals[KP];
 #pragma unroll
-        for (int m = 0; m < D; ++m) {
-            const float s = group_sum(rlp[m], lps);
-            if (lp == 0) p.g_rl[(size_t)e * D + m] += s;
-        }
-        for (int h = 0; h < H; ++h) {
-            float val = 0.f;
+            for (int m = 0; m < D; ++m) vals[m] = rlp[m];
 #pragma unroll
-            for (int b = 0; b < M; ++b) val += (hb[b] == h) ? pa_h[b] : 0.f;
-            val = group_sum(val, lps);
-            if (lp == 0) p.g_s[(size_t)e * H + h] = val;
+            for (int h = 0; h < 8; ++h) {
+                float val = 0.f;
+#pragma unroll
+                for (int b = 0; b < M; ++b) val += (hb[b] == h) ? pa_h[b] : 0.f;
+                vals[D + h] = val;
+            }
+#pragma unroll
+            for (int m = D + 8; m < KP; ++m) vals[m] = 0.f;
+            multi_group_sum<KP>(vals, lps, lp);
+            const int stride = lps / KP;
+            if ((lp & (stride - 1)) == 0) {
+                const int idx = lp / stride;
+                if (idx < D) p.g_rl[(size_t)e * D + idx] += vals[0];
+                else if (idx - D < H) p.g_s[(size_t)e * H + idx - D] = vals[0];
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                const float s = group_sum(rlp[m], lps);
+                if (lp == 0) p.g_rl[(size_t)e * D + m] += s;
+            }
+            for (int h = 0; h < H; ++h) {
+                float val = 0.f;
+#pragma unroll
+                for (int b = 0; b < M; ++b) val += (hb[b] == h) ? pa_h[b] : 0.f;
+                val = group_sum(val, lps);
+                if (lp == 0) p.g_s[(size_t)e * H + h] = val;
+            }
         }
     }
     __syncthreads();

@@ -45,6 +45,33 @@ __device__ __forceinline__ float group_sum(float v, int width) {
     for (int o = 1; o < width; o <<= 1) v += __shfl_xor(v, o, GN_WAVE);
     return v;
 }
+// Sum K values (K a power of two, K <= width) over aligned groups of `width` lanes with a
+// value-halving butterfly: ~K + log2(width) shuffles instead of K log2(width).  On return the lane
+// whose in-group index lp satisfies lp % (width / K) == 0 holds the total of value lp / (width / K) in v[0].
+template <int K>
+__device__ __forceinline__ void multi_group_sum(float (&v)[K], int width, int lp) {
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int off = width >> (s + 1);
+        if (off == 0) break;
+        constexpr int dummy = 0; (void)dummy;
+        const int k = (K >> s) > 1 ? (K >> s) : 1;       // live values before this step (compile-time after unroll)
+        if (k > 1) {
+            const int half = k >> 1;
+            const bool up = (lp & off) != 0;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                if (i >= half) break;
+                const float keep = up ? v[i + half] : v[i];
+                const float send = up ? v[i] : v[i + half];
+                v[i] = keep + __shfl_xor(send, off, GN_WAVE);
+            }
+        } else {
+            v[0] += __shfl_xor(v[0], off, GN_WAVE);
+        }
+    }
+}
+
 __device__ __forceinline__ float wave_max(float v) {
     for (int o = 1; o < GN_WAVE; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, GN_WAVE));
     return v;

@@ -1,0 +1,34 @@
+// gn_gemm.h -- declarations shared by the exact-fp32 (gn_gemm.hip) and the 3xbf16-split
+// (gn_gemm_split.hip) projection kernels.
+#pragma once
+#include "gn_common.h"
+
+namespace gn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const float* A; const float* W; const float* bias; float* C;
+    const float* res; const float* gate; float* pre_out;
+    const float* a_pre; const float* a_gate;
+    int lda, ldc, ldp, ldg, M, N, K;
+    int act_lo, act_hi;
+    int pro_mode, pro_lo, pro_hi;
+    int row_cnt, row_gstride, row_goff;
+    int skew_blocks, skew_mult;
+};
+
+constexpr int BK = 32, PITCH = 36;
+
+__device__ __forceinline__ int phys_row(const GemmArgs& p, int r) {
+    return (r / p.row_cnt) * p.row_gstride + p.row_goff + (r % p.row_cnt);
+}
+
+__device__ __forceinline__ float4 silu4(float4 v) { return make_float4(silu(v.x), silu(v.y), silu(v.z), silu(v.w)); }
+__device__ __forceinline__ float4 dsilu4(float4 v) { return make_float4(dsilu(v.x), dsilu(v.y), dsilu(v.z), dsilu(v.w)); }
+
+
+}  // namespace gn
+
+// split kernel launcher (gn_gemm_split.hip); W3 = [3][N][K] bf16 (hi, mid, lo planes)
+int gn_gemm_split_launch(gn::GemmArgs p, const unsigned short* W3, void* stream);

@@ -22,42 +22,41 @@
 //   1: A <- SiLU(A)                 (activations are stored pre-activation, consumers apply SiLU)
 //   2: A <- A * SiLU'(P)            (backward through an activation; P = stored pre-activation)
 //   and, for every column, A <- A * G when a_gate != NULL.
-#include "gn_common.h"
+#include "gn_gemm.h"
+#include <stdlib.h>
 
 namespace gn {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct GemmArgs {
-    const float* A; const float* W; const float* bias; float* C;
-    const float* res; const float* gate; float* pre_out;
-    const float* a_pre; const float* a_gate;
-    int lda, ldc, ldp, ldg, M, N, K;
-    int act_lo, act_hi;
-    int pro_mode, pro_lo, pro_hi;
-    int row_cnt, row_gstride, row_goff;
-};
-
-constexpr int BK = 32, PITCH = 36;
-
-__device__ __forceinline__ int phys_row(const GemmArgs& p, int r) {
-    return (r / p.row_cnt) * p.row_gstride + p.row_goff + (r % p.row_cnt);
-}
-
-__device__ __forceinline__ float4 silu4(float4 v) { return make_float4(silu(v.x), silu(v.y), silu(v.z), silu(v.w)); }
-__device__ __forceinline__ float4 dsilu4(float4 v) { return make_float4(dsilu(v.x), dsilu(v.y), dsilu(v.z), dsilu(v.w)); }
 
 template <int TM, int TN, bool PRO>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;       // staged float4 rows per thread
-    __shared__ __attribute__((aligned(16))) float As[BM * PITCH];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * PITCH];
+    constexpr int STAGE = (BM + BN) * PITCH;        // floats per K-slab buffer (A rows then W rows)
+    constexpr int CP = BN + 4;                      // epilogue tile pitch
+    constexpr int LDS_FLOATS = (2 * STAGE > BM * CP) ? 2 * STAGE : BM * CP;
+    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
 
+    // XCD-aware tile order (block b runs on XCD b % 8, speed only): every XCD owns a contiguous range
+    // of row tiles and walks all column tiles of a row tile back to back, so an A row tile is pulled
+    // through ONE L2 instead of all eight.  grid = 8 * ceil(tiles_m / 8) * tiles_n; the excess exits.
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile = blockIdx.x;
-    const int m0 = (tile / tiles_n) * BM;           // column tile is the fast index: neighbours share A rows in L2
-    const int n0 = (tile % tiles_n) * BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int xq = tiles_m >> 3, xr = tiles_m & 7, xcd = blockIdx.x & 7;
+    const int idx = blockIdx.x >> 3;
+    const int rows_here = xq + (xcd < xr ? 1 : 0);
+    if (idx / tiles_n >= rows_here) return;
+    const int tm = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + idx / tiles_n;
+    const int m0 = tm * BM;
+    const int n0 = (idx % tiles_n) * BN;
+
+    // De-phase the first wave of workgroups.  Co-resident workgroups that start together stay in
+    // lock-step (same work per tile): their MFMA phases collide and their prologue loads / epilogue
+    // store bursts leave the matrix pipes idle chip-wide.  A one-off pseudo-random start skew of up
+    // to ~one tile time spreads them; later workgroups inherit the skew from the ones they replace.
+    if (p.skew_blocks > 0 && (int)blockIdx.x < p.skew_blocks) {
+        const int n = (int)((blockIdx.x * 2654435761u) >> 28) * p.skew_mult;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(64);
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -110,22 +109,25 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < RB; ++i) pb[i] = (bok[i] && kok) ? ld4(brow[i] + k0) : zero4();
     };
-    auto stash = [&]() {
+    auto stash = [&](float* buf) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) st4(&As[(sr + 32 * i) * PITCH + 4 * c4], pa[i]);
+        for (int i = 0; i < RA; ++i) st4(&buf[(sr + 32 * i) * PITCH + 4 * c4], pa[i]);
 #pragma unroll
-        for (int i = 0; i < RB; ++i) st4(&Bs[(sr + 32 * i) * PITCH + 4 * c4], pb[i]);
+        for (int i = 0; i < RB; ++i) st4(&buf[(BM + sr + 32 * i) * PITCH + 4 * c4], pb[i]);
     };
 
+    // double-buffered K loop: one barrier per slab; slab kt+1 sits in registers while slab kt is multiplied
     const int nk = (p.K + BK - 1) / BK;
     fetch(0);
-    stash();
+    stash(smem);
     __syncthreads();
+    if (nk > 1) fetch(BK);
 
     const int khalf = (lane >> 5) * 16;
     const int frow = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) fetch((kt + 1) * BK);
+        const float* As = smem + (kt & 1) * STAGE;
+        const float* Bs = As + BM * PITCH;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             float a[TM][8], b[TN][8];
@@ -151,35 +153,38 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
         }
+        if (kt + 1 < nk) stash(smem + ((kt + 1) & 1) * STAGE);   // other buffer: last read in iteration kt-1
         __syncthreads();
-        if (kt + 1 < nk) {
-            stash();
-            __syncthreads();
-        }
+        if (kt + 2 < nk) fetch((kt + 2) * BK);
     }
 
-    // epilogue: lane holds column (lane & 31), rows (r&3) + 8 (r>>2) + 4 (lane>>5) of each 32x32 tile
+    // epilogue through LDS: accumulators -> [BM][BN+4] tile -> coalesced float4 rows
+    // (lane holds column (lane & 31), rows (r&3) + 8 (r>>2) + 4 (lane>>5) of each 32x32 tile)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int gn = n0 + wn * 32 * TN + j * 32 + (lane & 31);
-        if (gn >= p.N) continue;
-        const float bv = p.bias ? p.bias[gn] : 0.f;
-        const bool act = gn >= p.act_lo && gn < p.act_hi;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (gm >= p.M) continue;
-                float v = acc[i][j][r] + bv;
-                const size_t off = (size_t)phys_row(p, gm) * p.ldc + gn;
-                if (p.pre_out) p.pre_out[off] = v;
-                if (act) v = silu(v);
-                if (p.gate) v = v * p.gate[off];
-                if (p.res) v = p.res[off] + v;
-                p.C[off] = v;
+                const int row = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                smem[row * CP + wn * 32 * TN + j * 32 + (lane & 31)] = acc[i][j][r];
             }
-        }
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+#pragma unroll 4
+    for (int it = 0; it < (BM * C4) / 256; ++it) {
+        const int e = it * 256 + tid;
+        const int row = e / C4, cc = (e % C4) * 4;
+        const int gm = m0 + row, gn = n0 + cc;
+        if (gm >= p.M || gn >= p.N) continue;
+        float4 v = ld4(&smem[row * CP + cc]);
+        if (p.bias) v = v + ld4(p.bias + gn);
+        const size_t off = (size_t)phys_row(p, gm) * p.ldc + gn;
+        if (p.pre_out) st4(p.pre_out + off, v);
+        if (gn >= p.act_lo && gn < p.act_hi) v = silu4(v);          // act ranges are multiples of 4
+        if (p.gate) v = v * ld4(p.gate + off);
+        if (p.res) v = ld4(p.res + off) + v;
+        st4(p.C + off, v);
     }
 }
 
@@ -191,27 +196,54 @@ extern "C" int gn_gemm_ex(const float* A, int lda, const float* W, const float* 
                           const float* res, const float* gate, float* pre_out,
                           int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
                           const float* a_gate, int ldg, void* stream) {
-    if (Mrows < 0 || Nout <= 0 || K <= 0 || (K & 3) || (lda & 3) || row_cnt <= 0) return GN_ERR_BAD_ARG;
+    if (Mrows < 0 || Nout <= 0 || K <= 0 || (K & 3) || (lda & 3) || (Nout & 3) || (ldc & 3) || (act_lo & 3) ||
+        (act_hi & 3) || row_cnt <= 0)
+        return GN_ERR_BAD_ARG;
     if (gate != nullptr && res == nullptr) return GN_ERR_BAD_ARG;
     if (pro_mode < 0 || pro_mode > 2 || (pro_mode == 2 && (!a_pre || (ldp & 3))) || (a_gate && (ldg & 3)) ||
         (pro_mode && ((pro_lo & 3) || (pro_hi & 3))))
         return GN_ERR_BAD_ARG;
     if (Mrows == 0) return GN_OK;
     gn::GemmArgs p{A, W, bias, C, res, gate, pre_out, a_pre, a_gate, lda, ldc, ldp, ldg, Mrows, Nout, K,
-                   act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff};
+                   act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, 0, 0};
     const long big = (long)((Mrows + 127) / 128) * ((Nout + 127) / 128);
-    const long small = (long)((Mrows + 63) / 64) * ((Nout + 63) / 64);
+    const long grid_big = 8L * (((Mrows + 127) / 128 + 7) / 8) * ((Nout + 127) / 128);
+    const long grid_small = 8L * (((Mrows + 63) / 64 + 7) / 8) * ((Nout + 63) / 64);
+    static const int skew_env = getenv("GN_GEMM_SKEW") ? atoi(getenv("GN_GEMM_SKEW")) : 1;
+    if (skew_env && big >= 1024) {            // many rounds of tiles per CU: worth de-phasing
+        p.skew_blocks = 512;                   // 256 CUs x 2 resident workgroups
+        p.skew_mult = (K + 255) / 256 * skew_env;
+    }
     const bool pro = pro_mode != 0 || a_gate != nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (big >= 384) {
-        if (pro) hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, true>), dim3((unsigned)big), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, false>), dim3((unsigned)big), dim3(256), 0, st, p);
+        if (pro) hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, true>), dim3((unsigned)grid_big), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, false>), dim3((unsigned)grid_big), dim3(256), 0, st, p);
     } else {
-        if (pro) hipLaunchKernelGGL((gn::gemm_f32_mfma<1, 1, true>), dim3((unsigned)small), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gn::gemm_f32_mfma<1, 1, false>), dim3((unsigned)small), dim3(256), 0, st, p);
+        if (pro) hipLaunchKernelGGL((gn::gemm_f32_mfma<1, 1, true>), dim3((unsigned)grid_small), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gn::gemm_f32_mfma<1, 1, false>), dim3((unsigned)grid_small), dim3(256), 0, st, p);
     }
     GN_LAUNCH_CHECK();
     return GN_OK;
+}
+
+extern "C" int gn_gemm_split(const float* A, int lda, const unsigned short* W3, const float* bias, float* C, int ldc,
+                             int Mrows, int Nout, int K, int act_lo, int act_hi,
+                             int row_cnt, int row_gstride, int row_goff,
+                             const float* res, const float* gate, float* pre_out,
+                             int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
+                             const float* a_gate, int ldg, void* stream) {
+    if (Mrows < 0 || Nout <= 0 || K <= 0 || (K & 7) || (lda & 3) || (Nout & 3) || (ldc & 3) || (act_lo & 3) ||
+        (act_hi & 3) || row_cnt <= 0)
+        return GN_ERR_BAD_ARG;
+    if (gate != nullptr && res == nullptr) return GN_ERR_BAD_ARG;
+    if (pro_mode < 0 || pro_mode > 2 || (pro_mode == 2 && (!a_pre || (ldp & 3))) || (a_gate && (ldg & 3)) ||
+        (pro_mode && ((pro_lo & 3) || (pro_hi & 3))))
+        return GN_ERR_BAD_ARG;
+    if (Mrows == 0) return GN_OK;
+    gn::GemmArgs p{A, nullptr, bias, C, res, gate, pre_out, a_pre, a_gate, lda, ldc, ldp, ldg, Mrows, Nout, K,
+                   act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, 0, 0};
+    return gn_gemm_split_launch(p, W3, stream);
 }
 
 extern "C" int gn_gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc,

@@ -14,6 +14,7 @@ Activations are stored PRE-activation; consumers apply SiLU while loading.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
 
@@ -72,10 +73,30 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+#: projection arithmetic: "split" = 3 x bf16 split on the bf16 matrix cores (fp32-class error, 2.67x the
+#: fp32 MFMA rate); "f32" = exact fp32 MFMA.  Env GN_GEMM_MODE overrides.
+GEMM_MODE = os.environ.get("GN_GEMM_MODE", "f32")
+
+
+def split_weight(W: torch.Tensor) -> torch.Tensor:
+    """[3, N, K] bf16 planes of a weight, cached ON the tensor object (the packed weights are
+    long-lived objects; an in-place update bumps ``_version`` and invalidates the planes)."""
+    cached = getattr(W, "_gn_split", None)
+    if cached is not None and cached[0] == W._version and cached[1] == W.data_ptr():
+        return cached[2]
+    w3 = torch.empty((3,) + tuple(W.shape), dtype=torch.bfloat16, device=W.device)
+    call("gn_split_bf16x3", ptr(W), W.numel(), ptr(w3), _stream())
+    W._gn_split = (W._version, W.data_ptr(), w3)
+    return w3
+
+
 def gemm(A, lda, W, bias, C, ldc, rows, nout, K, act=(0, 0), rowmap=(1, 1, 0), res=None, gate=None,
          a_off=0, c_off=0, pre_out=None, pro=(0, 0, 0), a_pre=None, ldp=0, p_off=0, a_gate=None, ldg=0):
     """C = epi(pro(A) W^T + bias).  ``a_off`` / ``c_off`` / ``p_off``: float offsets of the first column."""
-    call("gn_gemm_ex", A.data_ptr() + 4 * a_off, lda, ptr(W), ptr(bias), C.data_ptr() + 4 * c_off, ldc,
+    name = "gn_gemm_ex"
+    if GEMM_MODE == "split" and K % 8 == 0:
+        name, W = "gn_gemm_split", split_weight(W)
+    call(name, A.data_ptr() + 4 * a_off, lda, ptr(W), ptr(bias), C.data_ptr() + 4 * c_off, ldc,
          rows, nout, K, act[0], act[1], rowmap[0], rowmap[1], rowmap[2], ptr(res), ptr(gate), ptr(pre_out),
          pro[0], pro[1], pro[2], (a_pre.data_ptr() + 4 * p_off) if a_pre is not None else None, ldp,
          ptr(a_gate), ldg, _stream())

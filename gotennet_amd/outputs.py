@@ -84,7 +84,11 @@ class Atomwise(nn.Module):
         N, Fd = h.shape
         Hd = d0.out_features
         pre1 = torch.empty((N, Hd), dtype=torch.float32, device=h.device)
-        engine.gemm(h, Fd, d0.weight.detach(), d0.bias.detach(), pre1, Hd, N, Hd, Fd)
+        w1 = getattr(self, "_w1", None)
+        if w1 is None or self._w1_key != (d0.weight._version, d0.weight.data_ptr()):
+            w1 = d0.weight.detach()
+            self._w1, self._w1_key = w1, (d0.weight._version, d0.weight.data_ptr())
+        engine.gemm(h, Fd, w1, d0.bias.detach(), pre1, Hd, N, Hd, Fd)
         y = torch.empty(N, dtype=torch.float32, device=h.device)
         e = torch.empty((n_mol, 1), dtype=torch.float32, device=h.device)
         b2 = self._b2 if getattr(self, "_b2_ver", None) == d1.bias._version else None

@@ -104,6 +104,18 @@ int gn_gemm_ex(const float* A, int lda, const float* W, const float* bias, float
                int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
                const float* a_gate, int ldg, void* stream);
 
+/* 3 x bf16 split variant: same contract as gn_gemm_ex, but the weight is passed as three
+ * bf16 planes W3[3][Nout][K] (hi, mid, lo with W = hi + mid + lo to 2^-25; made once by gn_split_bf16x3) and the
+ * product is accumulated in fp32 from the six plane pairs of order <= 2 on the bf16 matrix cores: fp32-class
+ * error (<= 1e-6 relative) at 16/6 of the exact-fp32 MFMA rate.  K must be a multiple of 8. */
+int gn_split_bf16x3(const float* w, long n, unsigned short* out /* [3][n] */, void* stream);
+int gn_gemm_split(const float* A, int lda, const unsigned short* W3, const float* bias, float* C, int ldc,
+                  int Mrows, int Nout, int K, int act_lo, int act_hi,
+                  int row_cnt, int row_gstride, int row_goff,
+                  const float* res, const float* gate, float* pre_out,
+                  int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
+                  const float* a_gate, int ldg, void* stream);
+
 /* ---- K6 GATA message / softmax / aggregate -------------------------------------------- */
 /* Attention weights (gotennet.py:497-511): s[e,h] = sum_{c in head h} q[i,c] k[j,c] t_attn[e,c];
  * a = exp(s - max) / (sum + 1e-16) over the incoming edges of i (PyG softmax), then

@@ -158,12 +158,13 @@ def test_deterministic_and_empty_rows():
 def test_gemm_row_map_and_epilogues():
     from gotennet_amd import engine
     torch.manual_seed(0)
-    for (M, N, K) in [(1, 32, 32), (130, 200, 64), (257, 96, 8), (1000, 384, 256)]:
+    for (M, N, K) in [(1, 32, 32), (130, 208, 64), (257, 96, 8), (1000, 384, 256)]:
         A = torch.randn(M, K).cuda(); W = torch.randn(N, K).cuda(); b = torch.randn(N).cuda()
         C = torch.empty(M, N).cuda()
-        engine.gemm(A, K, W, b, C, N, M, N, K, act=(N // 4, N // 2))
+        lo, hi = (N // 16) * 4, (N // 8) * 4
+        engine.gemm(A, K, W, b, C, N, M, N, K, act=(lo, hi))
         ref = A.double() @ W.double().T + b.double()
-        ref[:, N // 4:N // 2] = torch.nn.functional.silu(ref[:, N // 4:N // 2])
+        ref[:, lo:hi] = torch.nn.functional.silu(ref[:, lo:hi])
         assert rel_err(C.cpu(), ref.cpu()) < 1e-5
         res = torch.randn(M, N).cuda(); gate = torch.randn(M, N).cuda()
         engine.gemm(A, K, W, b, C, N, M, N, K, act=(0, N), res=res, gate=gate)
