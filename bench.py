@@ -43,7 +43,7 @@ class KernelTimer:
 
     @staticmethod
     def tag_of(name, args):
-        if name == "gn_gemm_ex":
+        if name in ("gn_gemm_ex", "gn_gemm_split"):
             return f"gn_gemm[{args[6]}x{args[7]}x{args[8]}]"
         return name
 

@@ -32,10 +32,10 @@ SIGNATURES = {
     "gn_htr_edge": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "gn_eqff_context": [_P, _P, _F, _I, _I, _I, _P, _P],
     "gn_eqff_update": [_P, _P, _I, _I, _I, _P, _P, _P],
-    "gn_gemm_ex": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P],
-    "gn_gemm_split": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P],
+    "gn_gemm_ex": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],
+    "gn_gemm_split": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],
     "gn_split_bf16x3": [_P, C.c_long, _P, _P],
-    "gn_htr_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "gn_htr_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     "gn_message_backward": [_P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                             _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gn_eqff_backward_a": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],

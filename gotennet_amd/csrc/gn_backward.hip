@@ -19,6 +19,7 @@
 namespace gn {
 
 __device__ __forceinline__ float4 silu4(float4 v) { return make_float4(silu(v.x), silu(v.y), silu(v.z), silu(v.w)); }
+__device__ __forceinline__ float4 dsilu4(float4 v) { return make_float4(dsilu(v.x), dsilu(v.y), dsilu(v.z), dsilu(v.w)); }
 
 // cross-slot fixed-order reduction of ROWS float4 accumulators; `wr(row, sum)` is called by
 // exactly one slot per row.  red: >= min(ROWS, 9) * 1024 floats of LDS.
@@ -40,10 +41,10 @@ __device__ __forceinline__ void reduce_rows(float4 (&acc)[ROWS], float* red, int
 // w = sum_l [ A.B - (2 - r.r)(A.r)(B.r) ],  A = EQ_i block, B = EK_j block, r = rl block
 template <int LMAX>
 __global__ __launch_bounds__(256) void htr_bwd_target_kernel(
-    const float* __restrict__ gtp, const float* __restrict__ pre_t,
+    const float* __restrict__ gtp, const float* __restrict__ pre_t, const float* __restrict__ w,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
     const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F,
-    float* __restrict__ gEQ, float* __restrict__ g_rl) {
+    float* __restrict__ gEQ, float* __restrict__ g_rl, float* __restrict__ g_pre_t) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int KP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));
     constexpr int CH = D < 9 ? D : 9;
@@ -57,7 +58,10 @@ __global__ __launch_bounds__(256) void htr_bwd_target_kernel(
 #pragma unroll
     for (int m = 0; m < D; ++m) { eq[m] = ld4(EQ + ((size_t)i * D + m) * F + c0); acc[m] = zero4(); }
     for (int e = e0 + slot; e < e1; e += ns) {
-        const float4 gw = ld4(gtp + (size_t)e * F + c0) * silu4(ld4(pre_t + (size_t)e * F + c0));
+        const float4 gte = ld4(gtp + (size_t)e * F + c0), pte = ld4(pre_t + (size_t)e * F + c0);
+        const float4 gw = gte * silu4(pte);
+        // t' = t + SiLU(pre_t) * w:  d/d pre_t, ready for the plain W_t^T product that follows
+        st4(g_pre_t + (size_t)e * F + c0, gte * ld4(w + (size_t)e * F + c0) * dsilu4(pte));
         const float* kj = EK + (size_t)src[e] * D * F + c0;
         const float* re = rl + (size_t)e * D;
         float part[KP];
@@ -177,7 +181,7 @@ struct MsgBwdArgs {
     // graph
     const int* rowptr; const int* src; const int* dst; const int* colptr; const int* perm;
     // outputs
-    float* g_eproj;                                    // [E, (1+M) F]: g_ta (before SiLU') | g_tf
+    float* g_eproj;                                    // [E, (1+M) F]: d/d(W_re t + b) | d/d t_filter
     float* g_s;                                        // [E, H] scratch: g_a then g_s
     float* g_nproj; int ldn;                           // [N, 4F]: g_q at col 0, g_k at col F
     float* g_x; float* g_v;                            // [N, M F]
@@ -309,9 +313,9 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
     for (int e = e0 + slot; e < e1; e += ns) {
         const float gs = p.g_s[(size_t)e * H + hq];
         const float4 kj = ld4(p.qk + (size_t)p.src[e] * p.ldqk + F + c0);
-        const float4 ta = silu4(ld4(p.eproj + (size_t)e * p.lde + c0));
-        gq = fma4(gs, kj * ta, gq);
-        st4(p.g_eproj + (size_t)e * p.lde + c0, (qi * kj) * gs);
+        const float4 pta = ld4(p.eproj + (size_t)e * p.lde + c0);
+        gq = fma4(gs, kj * silu4(pta), gq);
+        st4(p.g_eproj + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dsilu4(pta));   // d/d(pre-activation of t_attn)
     }
     st4(&red[slot * F + c0], gq);
     __syncthreads();
@@ -652,15 +656,15 @@ static bool bwd_dim_ok(int F) { return F >= 16 && F <= 256 && gn::is_pow2(F); }
         default: hipLaunchKernelGGL(gn::KERNEL<4>, grid, block, 0, st, __VA_ARGS__); break;            \
     }
 
-extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* EQ, const float* EK,
-                               const float* rl, const int* rowptr, const int* src, const int* dst,
+extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* w, const float* EQ,
+                               const float* EK, const float* rl, const int* rowptr, const int* src, const int* dst,
                                const int* colptr, const int* perm, int N, int F, int lmax,
-                               float* gEQ, float* gEK, float* g_rl, void* stream) {
+                               float* gEQ, float* gEK, float* g_rl, float* g_pre_t, void* stream) {
     if (!bwd_dim_ok(F) || N < 0 || lmax < 1 || lmax > 4) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(gn::xcd_grid(N)), block(256);
-    GN_SWITCH_LMAX(htr_bwd_target_kernel, grid, block, st, g_t_out, pre_t, EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl);
+    GN_SWITCH_LMAX(htr_bwd_target_kernel, grid, block, st, g_t_out, pre_t, w, EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl, g_pre_t);
     GN_LAUNCH_CHECK();
     GN_SWITCH_LMAX(htr_bwd_source_kernel, grid, block, st, g_t_out, pre_t, EQ, EK, rl, colptr, perm, dst, N, F, gEK);
     GN_LAUNCH_CHECK();

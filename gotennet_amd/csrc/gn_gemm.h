@@ -15,6 +15,7 @@ struct GemmArgs {
     int act_lo, act_hi;
     int pro_mode, pro_lo, pro_hi;
     int row_cnt, row_gstride, row_goff;
+    int gate_mode;                  // 0: value * gate; 1: value * SiLU'(gate)
     int skew_blocks, skew_mult;
 };
 

@@ -42,21 +42,13 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int xq = tiles_m >> 3, xr = tiles_m & 7, xcd = blockIdx.x & 7;
-    const int idx = blockIdx.x >> 3;
     const int rows_here = xq + (xcd < xr ? 1 : 0);
-    if (idx / tiles_n >= rows_here) return;
-    const int tm = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + idx / tiles_n;
+    const int row_base = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+  // persistent over tiles: workgroup b walks the tiles b/8, b/8 + gridDim/8, ... of ITS XCD's range
+  for (int idx = blockIdx.x >> 3; idx / tiles_n < rows_here; idx += gridDim.x >> 3) {
+    const int tm = row_base + idx / tiles_n;
     const int m0 = tm * BM;
     const int n0 = (idx % tiles_n) * BN;
-
-    // De-phase the first wave of workgroups.  Co-resident workgroups that start together stay in
-    // lock-step (same work per tile): their MFMA phases collide and their prologue loads / epilogue
-    // store bursts leave the matrix pipes idle chip-wide.  A one-off pseudo-random start skew of up
-    // to ~one tile time spreads them; later workgroups inherit the skew from the ones they replace.
-    if (p.skew_blocks > 0 && (int)blockIdx.x < p.skew_blocks) {
-        const int n = (int)((blockIdx.x * 2654435761u) >> 28) * p.skew_mult;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(64);
-    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -90,9 +82,10 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 pa[RA], pb[RB];
+    const int abl = p.skew_mult;                    // GN_GEMM_ABL (profiling ablations only; 0 in production)
     auto fetch = [&](int k0) {
         const int kc = k0 + 4 * c4;
-        const bool kok = kc < p.K;
+        const bool kok = kc < p.K && !(abl & 2);
         const bool pro = PRO && p.pro_mode && kc >= p.pro_lo && kc < p.pro_hi;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
@@ -182,10 +175,13 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
         const size_t off = (size_t)phys_row(p, gm) * p.ldc + gn;
         if (p.pre_out) st4(p.pre_out + off, v);
         if (gn >= p.act_lo && gn < p.act_hi) v = silu4(v);          // act ranges are multiples of 4
-        if (p.gate) v = v * ld4(p.gate + off);
+        if (p.gate) v = v * (p.gate_mode ? dsilu4(ld4(p.gate + off)) : ld4(p.gate + off));
         if (p.res) v = ld4(p.res + off) + v;
-        st4(p.C + off, v);
+        if (!(abl & 1)) st4(p.C + off, v);
+        else if (v.x == 123.456f) st4(p.C + off, v);
     }
+    __syncthreads();                                // LDS is reused by the next tile's first slab
+  }
 }
 
 }  // namespace gn
@@ -193,29 +189,32 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
 extern "C" int gn_gemm_ex(const float* A, int lda, const float* W, const float* bias, float* C, int ldc,
                           int Mrows, int Nout, int K, int act_lo, int act_hi,
                           int row_cnt, int row_gstride, int row_goff,
-                          const float* res, const float* gate, float* pre_out,
+                          const float* res, const float* gate, int gate_mode, float* pre_out,
                           int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
                           const float* a_gate, int ldg, void* stream) {
     if (Mrows < 0 || Nout <= 0 || K <= 0 || (K & 3) || (lda & 3) || (Nout & 3) || (ldc & 3) || (act_lo & 3) ||
         (act_hi & 3) || row_cnt <= 0)
         return GN_ERR_BAD_ARG;
-    if (gate != nullptr && res == nullptr) return GN_ERR_BAD_ARG;
+    if (gate != nullptr && res == nullptr && gate_mode == 0) return GN_ERR_BAD_ARG;
     if (pro_mode < 0 || pro_mode > 2 || (pro_mode == 2 && (!a_pre || (ldp & 3))) || (a_gate && (ldg & 3)) ||
         (pro_mode && ((pro_lo & 3) || (pro_hi & 3))))
         return GN_ERR_BAD_ARG;
     if (Mrows == 0) return GN_OK;
     gn::GemmArgs p{A, W, bias, C, res, gate, pre_out, a_pre, a_gate, lda, ldc, ldp, ldg, Mrows, Nout, K,
-                   act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, 0, 0};
+                   act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, gate_mode, 0, 0};
     const long big = (long)((Mrows + 127) / 128) * ((Nout + 127) / 128);
-    const long grid_big = 8L * (((Mrows + 127) / 128 + 7) / 8) * ((Nout + 127) / 128);
-    const long grid_small = 8L * (((Mrows + 63) / 64 + 7) / 8) * ((Nout + 63) / 64);
-    static const int skew_env = getenv("GN_GEMM_SKEW") ? atoi(getenv("GN_GEMM_SKEW")) : 1;
-    if (skew_env && big >= 1024) {            // many rounds of tiles per CU: worth de-phasing
-        p.skew_blocks = 512;                   // 256 CUs x 2 resident workgroups
-        p.skew_mult = (K + 255) / 256 * skew_env;
-    }
+    long grid_big = 8L * (((Mrows + 127) / 128 + 7) / 8) * ((Nout + 127) / 128);
+    long grid_small = 8L * (((Mrows + 63) / 64 + 7) / 8) * ((Nout + 63) / 64);
+    static const int abl_env = getenv("GN_GEMM_ABL") ? atoi(getenv("GN_GEMM_ABL")) : 0;
+    p.skew_mult = abl_env;
     const bool pro = pro_mode != 0 || a_gate != nullptr;
     hipStream_t st = (hipStream_t)stream;
+    static const int pers_env = getenv("GN_GEMM_PERSIST") ? atoi(getenv("GN_GEMM_PERSIST")) : 512;
+    const long grid_cap = pers_env > 0 ? pers_env : (1L << 30);
+    const long grid_big_full = grid_big, grid_small_full = grid_small;
+    (void)grid_big_full; (void)grid_small_full;
+    if (grid_big > grid_cap) grid_big = grid_cap;
+    if (grid_small > 2 * grid_cap) grid_small = 2 * grid_cap;
     if (big >= 384) {
         if (pro) hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, true>), dim3((unsigned)grid_big), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, false>), dim3((unsigned)grid_big), dim3(256), 0, st, p);
@@ -230,19 +229,19 @@ extern "C" int gn_gemm_ex(const float* A, int lda, const float* W, const float* 
 extern "C" int gn_gemm_split(const float* A, int lda, const unsigned short* W3, const float* bias, float* C, int ldc,
                              int Mrows, int Nout, int K, int act_lo, int act_hi,
                              int row_cnt, int row_gstride, int row_goff,
-                             const float* res, const float* gate, float* pre_out,
+                             const float* res, const float* gate, int gate_mode, float* pre_out,
                              int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
                              const float* a_gate, int ldg, void* stream) {
     if (Mrows < 0 || Nout <= 0 || K <= 0 || (K & 7) || (lda & 3) || (Nout & 3) || (ldc & 3) || (act_lo & 3) ||
         (act_hi & 3) || row_cnt <= 0)
         return GN_ERR_BAD_ARG;
-    if (gate != nullptr && res == nullptr) return GN_ERR_BAD_ARG;
+    if (gate != nullptr && res == nullptr && gate_mode == 0) return GN_ERR_BAD_ARG;
     if (pro_mode < 0 || pro_mode > 2 || (pro_mode == 2 && (!a_pre || (ldp & 3))) || (a_gate && (ldg & 3)) ||
         (pro_mode && ((pro_lo & 3) || (pro_hi & 3))))
         return GN_ERR_BAD_ARG;
     if (Mrows == 0) return GN_OK;
     gn::GemmArgs p{A, nullptr, bias, C, res, gate, pre_out, a_pre, a_gate, lda, ldc, ldp, ldg, Mrows, Nout, K,
-                   act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, 0, 0};
+                   act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, gate_mode, 0, 0};
     return gn_gemm_split_launch(p, W3, stream);
 }
 
@@ -251,5 +250,5 @@ extern "C" int gn_gemm(const float* A, int lda, const float* W, const float* bia
                        int row_cnt, int row_gstride, int row_goff,
                        const float* res, const float* gate, void* stream) {
     return gn_gemm_ex(A, lda, W, bias, C, ldc, Mrows, Nout, K, act_lo, act_hi, row_cnt, row_gstride, row_goff,
-                      res, gate, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, stream);
+                      res, gate, 0, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, stream);
 }

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_mfma(const GemmArgs p, const 
         const size_t off = (size_t)phys_row(p, gm) * p.ldc + gn;
         if (p.pre_out) st4(p.pre_out + off, v);
         if (gn >= p.act_lo && gn < p.act_hi) v = silu4(v);
-        if (p.gate) v = v * ld4(p.gate + off);
+        if (p.gate) v = v * (p.gate_mode ? dsilu4(ld4(p.gate + off)) : ld4(p.gate + off));
         if (p.res) v = ld4(p.res + off) + v;
         st4(p.C + off, v);
     }

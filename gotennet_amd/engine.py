@@ -91,13 +91,16 @@ def split_weight(W: torch.Tensor) -> torch.Tensor:
 
 
 def gemm(A, lda, W, bias, C, ldc, rows, nout, K, act=(0, 0), rowmap=(1, 1, 0), res=None, gate=None,
-         a_off=0, c_off=0, pre_out=None, pro=(0, 0, 0), a_pre=None, ldp=0, p_off=0, a_gate=None, ldg=0):
-    """C = epi(pro(A) W^T + bias).  ``a_off`` / ``c_off`` / ``p_off``: float offsets of the first column."""
+         a_off=0, c_off=0, pre_out=None, pro=(0, 0, 0), a_pre=None, ldp=0, p_off=0, a_gate=None, ldg=0,
+         dgate=None, g_off=0):
+    """C = epi(pro(A) W^T + bias).  ``a_off`` / ``c_off`` / ``p_off`` / ``g_off``: float offsets of the first
+    column.  ``dgate``: multiply the output by SiLU'(dgate) (same addressing as C)."""
     name = "gn_gemm_ex"
     if GEMM_MODE == "split" and K % 8 == 0:
         name, W = "gn_gemm_split", split_weight(W)
     call(name, A.data_ptr() + 4 * a_off, lda, ptr(W), ptr(bias), C.data_ptr() + 4 * c_off, ldc,
-         rows, nout, K, act[0], act[1], rowmap[0], rowmap[1], rowmap[2], ptr(res), ptr(gate), ptr(pre_out),
+         rows, nout, K, act[0], act[1], rowmap[0], rowmap[1], rowmap[2], ptr(res),
+         (dgate.data_ptr() + 4 * g_off) if dgate is not None else ptr(gate), 1 if dgate is not None else 0, ptr(pre_out),
          pro[0], pro[1], pro[2], (a_pre.data_ptr() + 4 * p_off) if a_pre is not None else None, ldp,
          ptr(a_gate), ldg, _stream())
 
@@ -268,24 +271,24 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
     gEQ, gEK = new(N, D, F_), new(N, D, F_)
     g_eproj, g_s = new(E, lde), new(E, H)
     g_nproj, g_x, g_v = new(N, 4 * F_), new(N, M * F_), new(N, M * F_)
-    gt_a, gt_b = new(E, F_), new(E, F_)
+    gt_a, gt_b, g_pre_t = new(E, F_), new(E, F_), new(E, F_)
 
     for li in reversed(range(len(pw.layers))):
         lw, lt = pw.layers[li], tape.layers[li]
         last = lw.Wt is None
         # ---- EQFF backward
         call("gn_eqff_backward_a", ptr(gh), ptr(gX), ptr(lt.mm), ptr(lt.Xp), N, F_, D, ptr(gm), ptr(gXp), st)
-        gemm(gm, 2 * F_, _T(lw, "Wm1"), None, g_g1, F_, N, F_, 2 * F_)
-        gemm(g_g1, F_, _T(lw, "Wm0"), None, g_ctx, 2 * F_, N, 2 * F_, F_, pro=(2, 0, F_), a_pre=lt.pre_g1, ldp=F_)
+        gemm(gm, 2 * F_, _T(lw, "Wm1"), None, g_g1, F_, N, F_, 2 * F_, dgate=lt.pre_g1)   # * SiLU'(pre) in the epilogue
+        gemm(g_g1, F_, _T(lw, "Wm0"), None, g_ctx, 2 * F_, N, 2 * F_, F_)
         call("gn_eqff_backward_b", ptr(g_ctx), ptr(lt.ctx), ptr(lt.Xp), ptr(gh), N, F_, D, ptr(gXp), ptr(gh1), st)
         gemm(gXp, F_, _T(lw, "Wvu"), None, gX1, F_, N * D, F_, F_, res=gX)
         # ---- HTR backward
         if not last:
             if gt is None:
                 raise RuntimeError("internal: missing edge gradient")
-            call("gn_htr_backward", ptr(gt), ptr(lt.pre_t), ptr(lt.EQ), ptr(lt.EK), ptr(g.rl),
+            call("gn_htr_backward", ptr(gt), ptr(lt.pre_t), ptr(lt.w), ptr(lt.EQ), ptr(lt.EK), ptr(g.rl),
                  ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm), N, F_, lmax,
-                 ptr(gEQ), ptr(gEK), ptr(g_rl), st)
+                 ptr(gEQ), ptr(gEK), ptr(g_rl), ptr(g_pre_t), st)
             gemm(gEQ, F_, _T(lw, "Wvq"), None, gX1, F_, N * D, F_, F_, res=gX1)
             off = 0
             for l in range(1, lmax + 1):
@@ -297,8 +300,7 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
                 gemm(gEK, F_, wkT, None, gX1, F_, N * cnt, F_, F_, rowmap=(cnt, D, off), res=gX1)
                 off += cnt
             # gt_a = gt + ((gt * w) * SiLU'(pre_t)) Wt
-            gemm(gt, F_, _T(lw, "Wt"), None, gt_a, F_, E, F_, F_, res=gt,
-                 pro=(2, 0, F_), a_pre=lt.pre_t, ldp=F_, a_gate=lt.w, ldg=F_)
+            gemm(g_pre_t, F_, _T(lw, "Wt"), None, gt_a, F_, E, F_, F_, res=gt)
             gt_in = gt_a
         else:
             gt_in = None
@@ -308,12 +310,12 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
              ptr(gh1), ptr(gX1), ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm),
              ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), ptr(gX2), ptr(g_rl), ptr(g_cut),
              N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), st)
-        gemm(g_x, M * F_, _T(lw, "Ws2"), None, g_nproj, 4 * F_, N, F_, M * F_, c_off=2 * F_)
-        gemm(g_v, M * F_, _T(lw, "Wv2"), None, g_nproj, 4 * F_, N, F_, M * F_, c_off=3 * F_)
-        gemm(g_nproj, 4 * F_, _T(lw, "Wn1"), None, gh2, F_, N, F_, 4 * F_, res=gh1,
-             pro=(2, 2 * F_, 4 * F_), a_pre=lt.nproj, ldp=4 * F_)
-        gemm(g_eproj, lde, _T(lw, "We"), None, gt_b, F_, E, F_, lde, res=gt_in,
-             pro=(2, 0, F_), a_pre=lt.eproj, ldp=lde)
+        gemm(g_x, M * F_, _T(lw, "Ws2"), None, g_nproj, 4 * F_, N, F_, M * F_, c_off=2 * F_,
+             dgate=lt.nproj, g_off=2 * F_)
+        gemm(g_v, M * F_, _T(lw, "Wv2"), None, g_nproj, 4 * F_, N, F_, M * F_, c_off=3 * F_,
+             dgate=lt.nproj, g_off=3 * F_)
+        gemm(g_nproj, 4 * F_, _T(lw, "Wn1"), None, gh2, F_, N, F_, 4 * F_, res=gh1)
+        gemm(g_eproj, lde, _T(lw, "We"), None, gt_b, F_, E, F_, lde, res=gt_in)
         gh, gh2 = gh2, gh
         gX, gX2 = gX2, gX
         gt, gt_b = gt_b, (gt if gt is not None else new(E, F_))

@@ -93,14 +93,16 @@ int gn_gemm(const float* A, int lda, const float* W, const float* bias, float* C
             const float* res, const float* gate, void* stream);
 
 /* Extended form used by the pipeline.  Extra epilogue: pre_out (if non-NULL) receives the value BEFORE
- * the activation (same addressing as C); `res` alone (gate == NULL) gives C = res + value.  Prologue on A,
+ * the activation (same addressing as C); `res` alone (gate == NULL) gives C = res + value; gate_mode 1
+ * multiplies by SiLU'(gate) instead of gate (backward through an activation, applied once per output
+ * element in the PRODUCER's epilogue; res may then be NULL).  Prologue on A,
  * applied while staging, on A columns [pro_lo, pro_hi): pro_mode 1: A <- SiLU(A) (activations are stored
  * pre-activation); pro_mode 2: A <- A * SiLU'(a_pre) (backward through a SiLU; a_pre has A's row addressing
  * with leading dim ldp); and A <- A * a_gate on every column when a_gate != NULL (leading dim ldg). */
 int gn_gemm_ex(const float* A, int lda, const float* W, const float* bias, float* C, int ldc,
                int Mrows, int Nout, int K, int act_lo, int act_hi,
                int row_cnt, int row_gstride, int row_goff,
-               const float* res, const float* gate, float* pre_out,
+               const float* res, const float* gate, int gate_mode, float* pre_out,
                int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
                const float* a_gate, int ldg, void* stream);
 
@@ -112,7 +114,7 @@ int gn_split_bf16x3(const float* w, long n, unsigned short* out /* [3][n] */, vo
 int gn_gemm_split(const float* A, int lda, const unsigned short* W3, const float* bias, float* C, int ldc,
                   int Mrows, int Nout, int K, int act_lo, int act_hi,
                   int row_cnt, int row_gstride, int row_goff,
-                  const float* res, const float* gate, float* pre_out,
+                  const float* res, const float* gate, int gate_mode, float* pre_out,
                   int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
                   const float* a_gate, int ldg, void* stream);
 
@@ -154,16 +156,17 @@ int gn_eqff_update(const float* m, const float* Xp, int N, int F, int D, float* 
  *      outputs.py:365-375).  Needs the by-source (CSC) view: perm[colptr[j] .. colptr[j+1]) lists the CSR
  *      edge ids whose source is j.  F <= 256.  g_rl [E,D] and g_cut [E] are ACCUMULATED (zero them first). */
 
-/* HTR (gotennet.py:561-611) backward: g_t_out = dL/dt' [E,F], pre_t = W_t t + b (saved), w.r.t. EQ, EK and rl. */
-int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* EQ, const float* EK,
+/* HTR (gotennet.py:561-611) backward: g_t_out = dL/dt' [E,F], pre_t = W_t t + b and w (saved), w.r.t. EQ, EK,
+ * rl, and g_pre_t = g_t_out * w * SiLU'(pre_t) [E,F] (the operand of the W_t^T product). */
+int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* w, const float* EQ, const float* EK,
                     const float* rl, const int* rowptr, const int* src, const int* dst,
                     const int* colptr, const int* perm, int N, int F, int lmax,
-                    float* gEQ, float* gEK, float* g_rl, void* stream);
+                    float* gEQ, float* gEK, float* g_rl, float* g_pre_t, void* stream);
 
 /* GATA message/softmax/aggregate (gotennet.py:452-559, 613-640) backward.  Inputs: saved x, v [N,MF];
  * eproj [E,(1+M)F] = (pre-activation of t_attn | t_filter); a [E,H]; qk rows with q at column 0 and k at
  * column F; X_in [N,D,F]; upstream g_h1 [N,F], g_X1 [N,D,F].  Outputs: g_eproj [E,(1+M)F] (gradient w.r.t.
- * SiLU(t_attn pre-activation) | t_filter), g_s [E,H] scratch, g_nproj rows (ldn) with g_q at column 0 and g_k
+ * the t_attn pre-activation | t_filter), g_s [E,H] scratch, g_nproj rows (ldn) with g_q at column 0 and g_k
  * at column F, g_x, g_v [N,MF], g_X_out = g_X1 + (tensor-gate path), g_rl, g_cut accumulated. */
 int gn_message_backward(const float* x, const float* v, int ldxv, const float* eproj, int lde, const float* a,
                         const float* qk, int ldqk, const float* X_in, const float* rl, const float* cut,
