@@ -58,8 +58,13 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(
 
 // ------------------------------------------------------------------ K6 message + aggregate
 // M F-wide blocks of the value vector: 0 = scalar; direction gate of degree l: block
-// (SEP_DIR ? l : 1); tensor gate: block TB0 + (SEP_TENSOR ? l-1 : 0), TB0 = 1 + (SEP_DIR ? LMAX : 1).
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
+// (SEP_DIR ? l : 1); tensor gate: block 1 + ND + (SEP_TENSOR ? l-1 : 0), ND = SEP_DIR ? LMAX : 1.
+//
+// One launch covers the degrees LLO..LHI (and the scalar row when SCALAR): for lmax >= 3 the
+// (1 + D) accumulator rows are cut into degree groups {scalar,1,2}, {3}, {4} so that every launch
+// keeps <= 9 float4 accumulators per lane (3+ waves/SIMD instead of 2 at 246 VGPRs).  Gates are
+// per degree, so the groups re-read nothing but the per-edge scalars.
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR>
 __global__ __launch_bounds__(256) void message_aggregate_kernel(
     const float* __restrict__ x, const float* __restrict__ v, int ldxv,
     const float* __restrict__ tf, int ldt, const float* __restrict__ a,
@@ -71,8 +76,10 @@ __global__ __launch_bounds__(256) void message_aggregate_kernel(
     constexpr int ND = SEP_DIR ? LMAX : 1;
     constexpr int NT = SEP_TENSOR ? LMAX : 1;
     constexpr int M = 1 + ND + NT;
-    constexpr int ROWS = 1 + D;
-    constexpr int CH = ROWS < 9 ? ROWS : 9;         // rows reduced per LDS pass (<= 36 KiB)
+    constexpr int XROWS = (LHI + 1) * (LHI + 1) - LLO * LLO;     // rows of degrees LLO..LHI
+    constexpr int ROWS = (SCALAR ? 1 : 0) + XROWS;
+    constexpr int M0 = LLO * LLO - 1;                             // first X row of the group
+    constexpr int CH = ROWS < 9 ? ROWS : 9;                       // rows reduced per LDS pass (<= 36 KiB)
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
 
     const int i = xcd_item(blockIdx.x, N);
@@ -81,10 +88,6 @@ __global__ __launch_bounds__(256) void message_aggregate_kernel(
     const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
     const int per_head = (M * F) / H;
-
-    int hb[M];
-#pragma unroll
-    for (int b = 0; b < M; ++b) hb[b] = (b * F + c0) / per_head;
 
     float4 acc[ROWS];
 #pragma unroll
@@ -99,23 +102,24 @@ __global__ __launch_bounds__(256) void message_aggregate_kernel(
         const float* ar = a + (size_t)e * H;
         const float* Xj = X_in + (size_t)j * D * F + c0;
         const float* re = rl + (size_t)e * D;
-        float4 o[M];
-#pragma unroll
-        for (int b = 0; b < M; ++b) {
-            // gotennet.py:516-529: (t_filter * x_j) * cutoff + attn * v_j
+        // gotennet.py:516-529: (t_filter * x_j) * cutoff + attn * v_j, block b of the value vector
+        auto gate = [&](int b) {
             const float4 sp = (ld4(tr + b * F) * ld4(xr + b * F)) * ce;
-            o[b] = fma4(ar[hb[b]], ld4(vr + b * F), sp);
-        }
-        acc[0] = acc[0] + o[0];
-        int m = 0;
+            return fma4(ar[(b * F + c0) / per_head], ld4(vr + b * F), sp);
+        };
+        if (SCALAR) acc[0] = acc[0] + gate(0);
+        float4 od = zero4(), ot = zero4();
+        if (!SEP_DIR) od = gate(1);
+        if (!SEP_TENSOR) ot = gate(1 + ND);
 #pragma unroll
-        for (int l = 1; l <= LMAX; ++l) {
-            const float4 od = o[SEP_DIR ? l : 1];
-            const float4 ot = o[1 + ND + (SEP_TENSOR ? l - 1 : 0)];
+        for (int l = LLO; l <= LHI; ++l) {
+            if (SEP_DIR) od = gate(l);
+            if (SEP_TENSOR) ot = gate(1 + ND + l - 1);
 #pragma unroll
-            for (int mm = 0; mm < 2 * l + 1; ++mm, ++m) {
+            for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                const int m = l * l - 1 + mm;
                 // gotennet.py:538-558: rl * o_d + X_j * o_t
-                acc[1 + m] = acc[1 + m] + fma4(ld4(Xj + (size_t)m * F), ot, od * re[m]);
+                acc[(SCALAR ? 1 : 0) + m - M0] = acc[(SCALAR ? 1 : 0) + m - M0] + fma4(ld4(Xj + (size_t)m * F), ot, od * re[m]);
             }
         }
     }
@@ -131,10 +135,10 @@ __global__ __launch_bounds__(256) void message_aggregate_kernel(
         for (int r = slot; r < CH && base + r < ROWS; r += ns) {
             const float4 s = red4(red + r * 1024, c0, F, ns);
             const int row = base + r;
-            if (row == 0) {
+            if (SCALAR && row == 0) {
                 st4(h_out + (size_t)i * F + c0, ld4(h_in + (size_t)i * F + c0) + s);
             } else {
-                const size_t off = ((size_t)i * D + (row - 1)) * F + c0;
+                const size_t off = ((size_t)i * D + (M0 + row - (SCALAR ? 1 : 0))) * F + c0;
                 st4(X_out + off, ld4(X_in + off) + s);
             }
         }
@@ -205,10 +209,18 @@ extern "C" int gn_attn_softmax(const float* q, const float* k, int ldqk, const f
     return GN_OK;
 }
 
-#define GN_MSG_LAUNCH(L, SD, ST)                                                                          \
-    hipLaunchKernelGGL((gn::message_aggregate_kernel<L, SD, ST>), dim3(gn::xcd_grid(N)), dim3(256), 0,    \
-                       (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in,     \
-                       X_in, h_out, X_out, N, F, H)
+#define GN_MSG_ONE(L, SD, ST, LLO, LHI, SC)                                                                 \
+    hipLaunchKernelGGL((gn::message_aggregate_kernel<L, SD, ST, LLO, LHI, SC>), dim3(gn::xcd_grid(N)), dim3(256), \
+                       0, (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in,  \
+                       h_out, X_out, N, F, H)
+// degree groups per lmax: {scalar,1..min(lmax,2)}, {3}, {4}
+#define GN_MSG_LAUNCH(L, SD, ST)                                      \
+    do {                                                              \
+        if (L == 1) { GN_MSG_ONE(L, SD, ST, 1, 1, true); }            \
+        else { GN_MSG_ONE(L, SD, ST, 1, 2, true); }                   \
+        if (L >= 3) { GN_MSG_ONE(L, SD, ST, 3, 3, false); }           \
+        if (L >= 4) { GN_MSG_ONE(L, SD, ST, 4, 4, false); }           \
+    } while (0)
 
 extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, const float* t_filter, int ldt,
                                     const float* a, const float* rl, const float* cut,
