@@ -43,7 +43,7 @@ SIGNATURES = {
     "gn_edge_init_backward": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "gn_node_init_backward": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "gn_layernorm_silu_backward": [_P, _P, _P, _F, _P, _I, _I, _P, _P],
-    "gn_edge_geometry_backward": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P],
+    "gn_edge_geometry_backward": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _F, _P, _I, _P, _I, _P, _P, _P, _P],
     "gn_pos_scatter": [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P],
     "gn_head_energy": [_P, _P, _F, _F, _F, _P, _P, _P, _I, _I, _P, _P, _P],
     "gn_head_grad": [_P, _P, _F, _I, _I, _P, _P],

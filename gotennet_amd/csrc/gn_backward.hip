@@ -15,6 +15,7 @@
 // layers.py:133-152, 744-746, 805-902 (cutoff, RBF, harmonics).
 #include "gn_common.h"
 #include "gn_sh.h"
+#include <stdlib.h>
 
 namespace gn {
 
@@ -95,12 +96,12 @@ __global__ __launch_bounds__(256) void htr_bwd_target_kernel(
         if (lps >= KP) {                             // one value-halving butterfly for all D sums
             multi_group_sum<KP>(part, lps, lp);
             const int stride = lps / KP;
-            if ((lp & (stride - 1)) == 0 && lp / stride < D) g_rl[(size_t)e * D + lp / stride] += part[0];
+            if ((lp & (stride - 1)) == 0 && lp / stride < D) g_rl[(size_t)e * D + lp / stride] = part[0];
         } else {
 #pragma unroll
             for (int m = 0; m < D; ++m) {
                 const float s = group_sum(part[m], lps);
-                if (lp == 0) g_rl[(size_t)e * D + m] += s;
+                if (lp == 0) g_rl[(size_t)e * D + m] = s;
             }
         }
     }
@@ -186,9 +187,10 @@ struct MsgBwdArgs {
     float* g_nproj; int ldn;                           // [N, 4F]: g_q at col 0, g_k at col F
     float* g_x; float* g_v;                            // [N, M F]
     float* g_X_out;                                    // [N, D, F] = g_X1 + source part
-    float* g_rl; float* g_cut;                         // accumulated
+    float* g_rl; float* g_cut;                         // this call's slice (written, not accumulated)
     int N, F, H;
     float inv_sqrt_f;
+    int abl;                                           // profiling ablations only (0 in production)
 };
 
 // by-target pass: g_tf, g_cut, g_rl, attention backward (g_a -> g_s), g_ta, g_q
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
                         go = S::is_dir(b) ? fma4(re[m], gdX[m], go) : fma4(gdX[m], ld4(Xj + (size_t)m * F), go);
             }
             const float4 tfb = ld4(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
-            st4(gtr + b * F, (go * xb) * ce);
+            if (!(p.abl & 1)) st4(gtr + b * F, (go * xb) * ce);
             cutp += hsum4(go * tfb * xb);
             pa_h[b] = hsum4(go * vb);
             if (S::is_dir(b)) {
@@ -253,8 +255,9 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
                     for (int m = S::first_row(l); m < S::first_row(l) + 2 * l + 1; ++m) rlp[m] = hsum4(gdX[m] * od);
             }
         }
+        if (p.abl & 8) continue;
         cutp = group_sum(cutp, lps);
-        if (lp == 0) p.g_cut[e] += cutp;
+        if (lp == 0) p.g_cut[e] = cutp;
         if (H <= 8 && lps >= KP) {                   // D rl sums + up to 8 head sums in one butterfly
             float vals[KP];
 #pragma unroll
@@ -272,14 +275,14 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
             const int stride = lps / KP;
             if ((lp & (stride - 1)) == 0) {
                 const int idx = lp / stride;
-                if (idx < D) p.g_rl[(size_t)e * D + idx] += vals[0];
+                if (idx < D) p.g_rl[(size_t)e * D + idx] = vals[0];
                 else if (idx - D < H) p.g_s[(size_t)e * H + idx - D] = vals[0];
             }
         } else {
 #pragma unroll
             for (int m = 0; m < D; ++m) {
                 const float s = group_sum(rlp[m], lps);
-                if (lp == 0) p.g_rl[(size_t)e * D + m] += s;
+                if (lp == 0) p.g_rl[(size_t)e * D + m] = s;
             }
             for (int h = 0; h < H; ++h) {
                 float val = 0.f;
@@ -290,6 +293,7 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
             }
         }
     }
+    if (p.abl & 2) return;
     __syncthreads();
     // ---- phase 2: softmax backward per head:  g_s = a g_a - (a / nrm) sum_e' a g_a
     {
@@ -306,6 +310,7 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
         }
     }
     __syncthreads();
+    if (p.abl & 4) return;
     // ---- phase 3: scores backward: g_ta (pre-SiLU' factor), g_q
     const int hq = c0 / (F / H);
     const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(256) void node_init_bwd_kernel(
         }
         st4(g_feat + (size_t)e * ldf + c0, gfn);
         gc = group_sum(gc, lps);
-        if (lp == 0) g_cut[e] += gc;
+        if (lp == 0) g_cut[e] = gc;
     }
 }
 
@@ -546,8 +551,8 @@ template <int LMAX>
 __global__ void edge_geometry_bwd_kernel(
     const float* __restrict__ vec, const float* __restrict__ dist, const int* __restrict__ src, const int* __restrict__ dst,
     int E, int R, const float* __restrict__ means, const float* __restrict__ betas, float cutoff, float alpha,
-    const float* __restrict__ g_rl, const float* __restrict__ g_cut, const float* __restrict__ g_phi,
-    float* __restrict__ g_vec, float* __restrict__ g_diff) {
+    const float* __restrict__ g_rl, int n_rl, const float* __restrict__ g_cut, int n_cut,
+    const float* __restrict__ g_phi, float* __restrict__ g_vec, float* __restrict__ g_diff) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
@@ -571,7 +576,9 @@ __global__ void edge_geometry_bwd_kernel(
             // d/dd [ c G ] = dc G + c G (-2 beta w) (-alpha u)
             s += g_phi[(size_t)e * R + r] * G * (dc + c * (2.0f * betas[r] * w * alpha * u));
         }
-        gd = s + g_cut[e] * dc;
+        float gc = 0.f;                              // fixed-order sum of the per-kernel slices
+        for (int q = 0; q < n_cut; ++q) gc += g_cut[(size_t)q * E + e];
+        gd = s + gc * dc;
     }
     g_diff[e] = gd;
     const float x = vec[3 * e], y = vec[3 * e + 1], z = vec[3 * e + 2];
@@ -582,7 +589,8 @@ __global__ void edge_geometry_bwd_kernel(
     float gu0 = 0.f, gu1 = 0.f, gu2 = 0.f;
 #pragma unroll
     for (int m = 0; m < D; ++m) {
-        const float g = g_rl[(size_t)e * D + m];
+        float g = 0.f;
+        for (int q = 0; q < n_rl; ++q) g += g_rl[((size_t)q * E + e) * D + m];
         gu0 += g * o[m].d[0]; gu1 += g * o[m].d[1]; gu2 += g * o[m].d[2];
     }
     const float dotp = gu0 * ux + gu1 * uy + gu2 * uz;      // u = v / |v|:  g_v = (g_u - (g_u . u) u) / |v|
@@ -674,7 +682,7 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
 #define GN_MSGB_LAUNCH(L, SD, ST)                                                                        \
     do {                                                                                                  \
         hipLaunchKernelGGL((gn::msg_bwd_target_kernel<L, SD, ST>), grid, block, 0, st, p);                \
-        hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST>), grid, block, 0, st, p);                \
+        if (!(p.abl & 16)) hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST>), grid, block, 0, st, p); \
     } while (0)
 
 extern "C" int gn_message_backward(
@@ -691,7 +699,7 @@ extern "C" int gn_message_backward(
     if (N == 0) return GN_OK;
     gn::MsgBwdArgs p{x, v, ldxv, eproj, lde, a, qk, ldqk, X_in, rl, cut, outdeg, g_h1, g_X1,
                      rowptr, src, dst, colptr, perm, g_eproj, g_s, g_nproj, ldn, g_x, g_v, g_X_out, g_rl, g_cut,
-                     N, F, H, (float)(1.0 / sqrt((double)F))};
+                     N, F, H, (float)(1.0 / sqrt((double)F)), getenv("GN_MSGB_ABL") ? atoi(getenv("GN_MSGB_ABL")) : 0};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(gn::xcd_grid(N)), block(256);
     const int key = lmax * 4 + (sep_dir ? 2 : 0) + (sep_tensor ? 1 : 0);
@@ -770,14 +778,14 @@ extern "C" int gn_layernorm_silu_backward(const float* x, const float* gamma, co
 
 extern "C" int gn_edge_geometry_backward(const float* edge_vec, const float* edge_diff, const int* src, const int* dst,
                                          int E, int lmax, int R, const float* means, const float* betas, float cutoff,
-                                         const float* g_rl, const float* g_cut, const float* g_phi,
-                                         float* g_vec, float* g_diff, void* stream) {
-    if (E < 0 || lmax < 1 || lmax > 4 || R <= 0) return GN_ERR_BAD_ARG;
+                                         const float* g_rl, int n_rl, const float* g_cut, int n_cut,
+                                         const float* g_phi, float* g_vec, float* g_diff, void* stream) {
+    if (E < 0 || lmax < 1 || lmax > 4 || R <= 0 || n_rl < 0 || n_cut < 0) return GN_ERR_BAD_ARG;
     if (E == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((E + 127) / 128), block(128);
     GN_SWITCH_LMAX(edge_geometry_bwd_kernel, grid, block, st, edge_vec, edge_diff, src, dst, E, R, means, betas,
-                   cutoff, 5.0f / cutoff, g_rl, g_cut, g_phi, g_vec, g_diff);
+                   cutoff, 5.0f / cutoff, g_rl, n_rl, g_cut, n_cut, g_phi, g_vec, g_diff);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }

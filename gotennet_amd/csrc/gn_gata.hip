@@ -56,7 +56,92 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(
     }
 }
 
-// ------------------------------------------------------------------ K6 message + aggregate
+// ------------------------------------------------------------------ K6 message + aggregate (lmax <= 2: one launch)
+// M F-wide blocks of the value vector: 0 = scalar; direction gate of degree l: block
+// (SEP_DIR ? l : 1); tensor gate: block TB0 + (SEP_TENSOR ? l-1 : 0), TB0 = 1 + (SEP_DIR ? LMAX : 1).
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
+__global__ __launch_bounds__(256) void message_aggregate_kernel(
+    const float* __restrict__ x, const float* __restrict__ v, int ldxv,
+    const float* __restrict__ tf, int ldt, const float* __restrict__ a,
+    const float* __restrict__ rl, const float* __restrict__ cut,
+    const int* __restrict__ rowptr, const int* __restrict__ src,
+    const float* __restrict__ h_in, const float* __restrict__ X_in,
+    float* __restrict__ h_out, float* __restrict__ X_out, int N, int F, int H) {
+    constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
+    constexpr int ND = SEP_DIR ? LMAX : 1;
+    constexpr int NT = SEP_TENSOR ? LMAX : 1;
+    constexpr int M = 1 + ND + NT;
+    constexpr int ROWS = 1 + D;
+    constexpr int CH = ROWS < 9 ? ROWS : 9;         // rows reduced per LDS pass (<= 36 KiB)
+    __shared__ __attribute__((aligned(16))) float red[CH * 1024];
+
+    const int i = xcd_item(blockIdx.x, N);
+    if (i < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    const int per_head = (M * F) / H;
+
+    int hb[M];
+#pragma unroll
+    for (int b = 0; b < M; ++b) hb[b] = (b * F + c0) / per_head;
+
+    float4 acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = zero4();
+
+    for (int e = e0 + slot; e < e1; e += ns) {
+        const int j = src[e];
+        const float ce = cut[e];
+        const float* xr = x + (size_t)j * ldxv + c0;
+        const float* vr = v + (size_t)j * ldxv + c0;
+        const float* tr = tf + (size_t)e * ldt + c0;
+        const float* ar = a + (size_t)e * H;
+        const float* Xj = X_in + (size_t)j * D * F + c0;
+        const float* re = rl + (size_t)e * D;
+        float4 o[M];
+#pragma unroll
+        for (int b = 0; b < M; ++b) {
+            // gotennet.py:516-529: (t_filter * x_j) * cutoff + attn * v_j
+            const float4 sp = (ld4(tr + b * F) * ld4(xr + b * F)) * ce;
+            o[b] = fma4(ar[hb[b]], ld4(vr + b * F), sp);
+        }
+        acc[0] = acc[0] + o[0];
+        int m = 0;
+#pragma unroll
+        for (int l = 1; l <= LMAX; ++l) {
+            const float4 od = o[SEP_DIR ? l : 1];
+            const float4 ot = o[1 + ND + (SEP_TENSOR ? l - 1 : 0)];
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm, ++m) {
+                // gotennet.py:538-558: rl * o_d + X_j * o_t
+                acc[1 + m] = acc[1 + m] + fma4(ld4(Xj + (size_t)m * F), ot, od * re[m]);
+            }
+        }
+    }
+
+    // fixed-order reduction over slots, CH rows per pass; slot s finishes rows s, s+ns, ...
+#pragma unroll
+    for (int base = 0; base < ROWS; base += CH) {
+        if (base) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CH; ++r)
+            if (base + r < ROWS) st4(&red[r * 1024 + slot * F + c0], acc[base + r]);
+        __syncthreads();
+        for (int r = slot; r < CH && base + r < ROWS; r += ns) {
+            const float4 s = red4(red + r * 1024, c0, F, ns);
+            const int row = base + r;
+            if (row == 0) {
+                st4(h_out + (size_t)i * F + c0, ld4(h_in + (size_t)i * F + c0) + s);
+            } else {
+                const size_t off = ((size_t)i * D + (row - 1)) * F + c0;
+                st4(X_out + off, ld4(X_in + off) + s);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K6 message + aggregate (lmax >= 3: degree groups)
 // M F-wide blocks of the value vector: 0 = scalar; direction gate of degree l: block
 // (SEP_DIR ? l : 1); tensor gate: block 1 + ND + (SEP_TENSOR ? l-1 : 0), ND = SEP_DIR ? LMAX : 1.
 //
@@ -65,7 +150,7 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(
 // keeps <= 9 float4 accumulators per lane (3+ waves/SIMD instead of 2 at 246 VGPRs).  Gates are
 // per degree, so the groups re-read nothing but the per-edge scalars.
 template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR>
-__global__ __launch_bounds__(256) void message_aggregate_kernel(
+__global__ __launch_bounds__(256) void message_aggregate_group_kernel(
     const float* __restrict__ x, const float* __restrict__ v, int ldxv,
     const float* __restrict__ tf, int ldt, const float* __restrict__ a,
     const float* __restrict__ rl, const float* __restrict__ cut,
@@ -89,6 +174,10 @@ __global__ __launch_bounds__(256) void message_aggregate_kernel(
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
     const int per_head = (M * F) / H;
 
+    int hb[M];                                      // attention head of this lane's channels in block b
+#pragma unroll
+    for (int b = 0; b < M; ++b) hb[b] = (b * F + c0) / per_head;
+
     float4 acc[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) acc[r] = zero4();
@@ -105,21 +194,25 @@ __global__ __launch_bounds__(256) void message_aggregate_kernel(
         // gotennet.py:516-529: (t_filter * x_j) * cutoff + attn * v_j, block b of the value vector
         auto gate = [&](int b) {
             const float4 sp = (ld4(tr + b * F) * ld4(xr + b * F)) * ce;
-            return fma4(ar[(b * F + c0) / per_head], ld4(vr + b * F), sp);
+            return fma4(ar[hb[b]], ld4(vr + b * F), sp);
         };
-        if (SCALAR) acc[0] = acc[0] + gate(0);
-        float4 od = zero4(), ot = zero4();
-        if (!SEP_DIR) od = gate(1);
-        if (!SEP_TENSOR) ot = gate(1 + ND);
+        // all gate loads first (independent, issued back to back), then the X_j rows
+        constexpr int NL = LHI - LLO + 1;
+        float4 gd[NL], gt[NL];
 #pragma unroll
         for (int l = LLO; l <= LHI; ++l) {
-            if (SEP_DIR) od = gate(l);
-            if (SEP_TENSOR) ot = gate(1 + ND + l - 1);
+            gd[l - LLO] = (SEP_DIR || l == LLO) ? gate(SEP_DIR ? l : 1) : gd[0];
+            gt[l - LLO] = (SEP_TENSOR || l == LLO) ? gate(1 + ND + (SEP_TENSOR ? l - 1 : 0)) : gt[0];
+        }
+        if (SCALAR) acc[0] = acc[0] + gate(0);
+#pragma unroll
+        for (int l = LLO; l <= LHI; ++l) {
 #pragma unroll
             for (int mm = 0; mm < 2 * l + 1; ++mm) {
                 const int m = l * l - 1 + mm;
                 // gotennet.py:538-558: rl * o_d + X_j * o_t
-                acc[(SCALAR ? 1 : 0) + m - M0] = acc[(SCALAR ? 1 : 0) + m - M0] + fma4(ld4(Xj + (size_t)m * F), ot, od * re[m]);
+                acc[(SCALAR ? 1 : 0) + m - M0] = acc[(SCALAR ? 1 : 0) + m - M0] +
+                                                 fma4(ld4(Xj + (size_t)m * F), gt[l - LLO], gd[l - LLO] * re[m]);
             }
         }
     }
@@ -210,16 +303,22 @@ extern "C" int gn_attn_softmax(const float* q, const float* k, int ldqk, const f
 }
 
 #define GN_MSG_ONE(L, SD, ST, LLO, LHI, SC)                                                                 \
-    hipLaunchKernelGGL((gn::message_aggregate_kernel<L, SD, ST, LLO, LHI, SC>), dim3(gn::xcd_grid(N)), dim3(256), \
+    hipLaunchKernelGGL((gn::message_aggregate_group_kernel<L, SD, ST, LLO, LHI, SC>), dim3(gn::xcd_grid(N)), dim3(256), \
                        0, (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in,  \
                        h_out, X_out, N, F, H)
 // degree groups per lmax: {scalar,1..min(lmax,2)}, {3}, {4}
+#define GN_MSG_MONO(L, SD, ST)                                                                              \
+    hipLaunchKernelGGL((gn::message_aggregate_kernel<L, SD, ST>), dim3(gn::xcd_grid(N)), dim3(256), 0,         \
+                       (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in,    \
+                       h_out, X_out, N, F, H)
 #define GN_MSG_LAUNCH(L, SD, ST)                                      \
     do {                                                              \
-        if (L == 1) { GN_MSG_ONE(L, SD, ST, 1, 1, true); }            \
-        else { GN_MSG_ONE(L, SD, ST, 1, 2, true); }                   \
-        if (L >= 3) { GN_MSG_ONE(L, SD, ST, 3, 3, false); }           \
-        if (L >= 4) { GN_MSG_ONE(L, SD, ST, 4, 4, false); }           \
+        if constexpr (L <= 2) { GN_MSG_MONO(L, SD, ST); }             \
+        else {                                                        \
+            GN_MSG_ONE(L, SD, ST, 1, 2, true);                        \
+            GN_MSG_ONE(L, SD, ST, 3, 3, false);                       \
+            if constexpr (L >= 4) { GN_MSG_ONE(L, SD, ST, 4, 4, false); } \
+        }                                                             \
     } while (0)
 
 extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, const float* t_filter, int ldt,

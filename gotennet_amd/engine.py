@@ -260,8 +260,12 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
     colptr, perm = g.csc()
     lde = (1 + M) * F_
 
-    g_rl = torch.zeros((E, D), **f32)
-    g_cut = torch.zeros(E, **f32)
+    # every contributing kernel writes its own slice; the geometry backward sums them in a fixed order
+    L = len(pw.layers)
+    n_rl, n_cut = 2 * L - 1, L + 1
+    g_rl_parts, g_cut_parts = new(n_rl, E, D), new(n_cut, E)
+    rl_slice = lambda q: g_rl_parts.data_ptr() + 4 * q * E * D
+    cut_slice = lambda q: g_cut_parts.data_ptr() + 4 * q * E
     gh = gh.contiguous()
     gX = torch.zeros((N, D, F_), **f32) if gX is None else gX.contiguous()
     gt = None                                      # dL/dt of the layer output (None = 0)
@@ -288,7 +292,7 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
                 raise RuntimeError("internal: missing edge gradient")
             call("gn_htr_backward", ptr(gt), ptr(lt.pre_t), ptr(lt.w), ptr(lt.EQ), ptr(lt.EK), ptr(g.rl),
                  ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm), N, F_, lmax,
-                 ptr(gEQ), ptr(gEK), ptr(g_rl), ptr(g_pre_t), st)
+                 ptr(gEQ), ptr(gEK), rl_slice(L + li), ptr(g_pre_t), st)
             gemm(gEQ, F_, _T(lw, "Wvq"), None, gX1, F_, N * D, F_, F_, res=gX1)
             off = 0
             for l in range(1, lmax + 1):
@@ -308,7 +312,7 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
         call("gn_message_backward", ptr(lt.xs), ptr(lt.vs), M * F_, ptr(lt.eproj), lde, ptr(lt.attn),
              ptr(lt.nproj), 4 * F_, ptr(lt.X_in), ptr(g.rl), ptr(g.cut), ptr(g.outdeg),
              ptr(gh1), ptr(gX1), ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm),
-             ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), ptr(gX2), ptr(g_rl), ptr(g_cut),
+             ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), ptr(gX2), rl_slice(li), cut_slice(li),
              N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), st)
         gemm(g_x, M * F_, _T(lw, "Ws2"), None, g_nproj, 4 * F_, N, F_, M * F_, c_off=2 * F_,
              dgate=lt.nproj, g_off=2 * F_)
@@ -330,13 +334,13 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
     call("gn_layernorm_silu_backward", ptr(tape.y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, ptr(gy), N, F_, ptr(gy1), st)
     gemm(gy1, F_, _T(pw, "Wa"), None, g_ctx, 2 * F_, N, 2 * F_, F_)
     call("gn_node_init_backward", ptr(g_ctx), ptr(z32), ptr(tape.feat), 2 * F_, ptr(g.cut), ptr(pw.A_nbr),
-         ptr(g.rowptr), ptr(g.src), N, F_, ptr(g_feat), ptr(g_cut), st)
+         ptr(g.rowptr), ptr(g.src), N, F_, ptr(g_feat), cut_slice(L), st)
     g_phi = new(E, R)
     gemm(g_feat, 2 * F_, _T(pw, "Winit"), None, g_phi, R, E, R, 2 * F_)
     g_vec, g_diff = new(E, 3), new(E)
     call("gn_edge_geometry_backward", ptr(g.edge_vec), ptr(g.edge_diff), ptr(g.src), ptr(g.dst), E, lmax, R,
-         ptr(pw.means), ptr(pw.betas), float(cfg.cutoff), ptr(g_rl), ptr(g_cut), ptr(g_phi),
-         ptr(g_vec), ptr(g_diff), st)
+         ptr(pw.means), ptr(pw.betas), float(cfg.cutoff), ptr(g_rl_parts), n_rl, ptr(g_cut_parts), n_cut,
+         ptr(g_phi), ptr(g_vec), ptr(g_diff), st)
     return g_vec, g_diff
 
 

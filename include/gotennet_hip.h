@@ -154,7 +154,8 @@ int gn_eqff_update(const float* m, const float* Xp, int N, int F, int D, float* 
 
 /* ---- K10 force backward (input gradients only; what torch.autograd.grad does for the reference at
  *      outputs.py:365-375).  Needs the by-source (CSC) view: perm[colptr[j] .. colptr[j+1]) lists the CSR
- *      edge ids whose source is j.  F <= 256.  g_rl [E,D] and g_cut [E] are ACCUMULATED (zero them first). */
+ *      edge ids whose source is j.  F <= 256.  Every kernel WRITES its g_rl [E,D] / g_cut [E] contribution to
+ *      the slice it is given (plain stores, no read-modify-write); gn_edge_geometry_backward sums the slices. */
 
 /* HTR (gotennet.py:561-611) backward: g_t_out = dL/dt' [E,F], pre_t = W_t t + b and w (saved), w.r.t. EQ, EK,
  * rl, and g_pre_t = g_t_out * w * SiLU'(pre_t) [E,F] (the operand of the W_t^T product). */
@@ -167,7 +168,7 @@ int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* w, co
  * eproj [E,(1+M)F] = (pre-activation of t_attn | t_filter); a [E,H]; qk rows with q at column 0 and k at
  * column F; X_in [N,D,F]; upstream g_h1 [N,F], g_X1 [N,D,F].  Outputs: g_eproj [E,(1+M)F] (gradient w.r.t.
  * the t_attn pre-activation | t_filter), g_s [E,H] scratch, g_nproj rows (ldn) with g_q at column 0 and g_k
- * at column F, g_x, g_v [N,MF], g_X_out = g_X1 + (tensor-gate path), g_rl, g_cut accumulated. */
+ * at column F, g_x, g_v [N,MF], g_X_out = g_X1 + (tensor-gate path), g_rl [E,D] and g_cut [E] slices. */
 int gn_message_backward(const float* x, const float* v, int ldxv, const float* eproj, int lde, const float* a,
                         const float* qk, int ldqk, const float* X_in, const float* rl, const float* cut,
                         const int* outdeg, const float* g_h1, const float* g_X1,
@@ -188,18 +189,19 @@ int gn_eqff_backward_b(const float* g_ctx, const float* ctx, const float* Xp, co
 int gn_edge_init_backward(const float* g_t0, const float* h, const float* feat, int ldf,
                           const int* rowptr, const int* src, const int* colptr, const int* perm,
                           int N, int F, float* g_feat, float* g_h, void* stream);
-/* NodeInit aggregate (layers.py:1666-1675) backward: g_feat[e, 0:F] and g_cut[e] += from g_ctx[:, F:2F]. */
+/* NodeInit aggregate (layers.py:1666-1675) backward: g_feat[e, 0:F] and the g_cut [E] slice from g_ctx[:, F:2F]. */
 int gn_node_init_backward(const float* g_ctx, const int* z, const float* feat, int ldf, const float* cut,
                           const float* A_nbr, const int* rowptr, const int* src, int N, int F,
                           float* g_feat, float* g_cut, void* stream);
 int gn_layernorm_silu_backward(const float* x, const float* gamma, const float* beta, float eps,
                                const float* g_out, int N, int F, float* g_x, void* stream);
 
-/* Edge geometry (K1) backward: (g_rl, g_cut, g_phi) -> g_vec [E,3] through the unit vector and harmonics,
- * g_diff [E] through cutoff and radial basis.  Self-loops get zeros. */
+/* Edge geometry (K1) backward: (sum of the n_rl slices g_rl [n_rl,E,D], sum of the n_cut slices g_cut [n_cut,E],
+ * g_phi [E,R]) -> g_vec [E,3] through the unit vector and harmonics, g_diff [E] through cutoff and radial
+ * basis.  Self-loops get zeros. */
 int gn_edge_geometry_backward(const float* edge_vec, const float* edge_diff, const int* src, const int* dst,
                               int E, int lmax, int R, const float* means, const float* betas, float cutoff,
-                              const float* g_rl, const float* g_cut, const float* g_phi,
+                              const float* g_rl, int n_rl, const float* g_cut, int n_cut, const float* g_phi,
                               float* g_vec, float* g_diff, void* stream);
 /* out[n] = sign * ( sum_{src(e)=n} gv_e - sum_{dst(e)=n} gv_e ), gv = g_vec + g_diff * edge_vec/|edge_vec|
  * (Distance.forward, layers.py:1593-1600: edge_vec = pos[j]-pos[i], edge_weight = |edge_vec|). sign=-1: forces. */

@@ -1,1 +1,2 @@
-for pz in 0 512 768; do echo "== GN_GEMM_PERSIST=$pz"; GN_GEMM_PERSIST=$pz GN_GEMM_MODE=f32 python tools/gemm_bench.py 2>&1 | grep -v amdgpu | head -7; done
+python bench.py --breakdown --no-cpu-baseline --steps 10 2>&1 >/dev/null | grep -E "message_aggregate|message_backward"
+python bench.py --lmax 4 --breakdown --no-cpu-baseline --steps 5 2>&1 >/dev/null | grep -E "message_aggregate"
