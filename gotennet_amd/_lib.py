@@ -37,7 +37,8 @@ SIGNATURES = {
     "gn_split_bf16x3": [_P, C.c_long, _P, _P],
     "gn_htr_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     "gn_message_backward": [_P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                            _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+                            _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.c_long, _I, _I, _I, _I, _I, _I, _P],
+    "gn_message_backward_groups": [_I, _I, _I],
     "gn_eqff_backward_a": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "gn_eqff_backward_b": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "gn_edge_init_backward": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P],

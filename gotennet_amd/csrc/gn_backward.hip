@@ -407,6 +407,329 @@ __global__ __launch_bounds__(256) void msg_bwd_source_kernel(const MsgBwdArgs p)
     });
 }
 
+// =========================================================================== degree-grouped backward (lmax >= 3)
+// For lmax >= 3 with sep_dir and sep_tensor the monolithic kernels above need 250+ VGPRs.  Gates are
+// per degree, so the work is cut into degree groups {scalar,1,2}, {3}, {4}: one target-pass and one
+// source-pass launch per group, plus one attention-backward launch (softmax backward needs the head
+// sums of ALL groups).  Value blocks: 0 scalar, l direction gate, LMAX + l tensor gate.
+template <int LMAX, int LLO, int LHI, bool SCALAR>
+__global__ __launch_bounds__(256) void msg_bwd_target_group_kernel(const MsgBwdArgs p, float* __restrict__ ga_slice,
+                                                                  float* __restrict__ cut_slice) {
+    constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
+    constexpr int M = 1 + 2 * LMAX;
+    constexpr int XR = (LHI + 1) * (LHI + 1) - LLO * LLO, M0 = LLO * LLO - 1;
+    constexpr int KP = (XR + 8) <= 16 ? 16 : 32;
+    const int N = p.N, F = p.F, H = p.H;
+    const int i = xcd_item(blockIdx.x, N);
+    if (i < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
+    const int e0 = p.rowptr[i], e1 = p.rowptr[i + 1];
+    const int per_head = (M * F) / H;
+    const float4 gdh = SCALAR ? ld4(p.g_h1 + (size_t)i * F + c0) : zero4();
+    float4 gdX[XR];
+#pragma unroll
+    for (int m = 0; m < XR; ++m) gdX[m] = ld4(p.g_X1 + ((size_t)i * D + M0 + m) * F + c0);
+
+    for (int e = e0 + slot; e < e1; e += ns) {
+        const int j = p.src[e];
+        const float ce = p.cut[e];
+        const float* xr = p.x + (size_t)j * p.ldxv + c0;
+        const float* vr = p.v + (size_t)j * p.ldxv + c0;
+        const float* tr = p.eproj + (size_t)e * p.lde + F + c0;
+        float* gtr = p.g_eproj + (size_t)e * p.lde + F + c0;
+        const float* ar = p.a + (size_t)e * H;
+        const float* Xj = p.X_in + (size_t)j * D * F + c0;
+        const float* re = p.rl + (size_t)e * D;
+        float cutp = 0.f;
+        float vals[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) vals[k] = 0.f;
+        // one value block: gradient `go` of its gate -> g_tf, cut partial, head partial; returns tf*x*cut + a*v
+        auto block = [&](int b, float4 go, bool need_fwd) {
+            const float4 tfb = ld4(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
+            st4(gtr + b * F, (go * xb) * ce);
+            cutp += hsum4(go * tfb * xb);
+            const int hb = (b * F + c0) / per_head;
+            const float pa = hsum4(go * vb);
+#pragma unroll
+            for (int h = 0; h < 8; ++h) vals[XR + h] += (hb == h) ? pa : 0.f;
+            return need_fwd ? fma4(ar[hb], vb, (tfb * xb) * ce) : zero4();
+        };
+        if (SCALAR) block(0, gdh, false);
+#pragma unroll
+        for (int l = LLO; l <= LHI; ++l) {
+            float4 god = zero4(), got = zero4();
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                const int m = l * l - 1 + mm;
+                god = fma4(re[m], gdX[m - M0], god);
+                got = fma4(gdX[m - M0], ld4(Xj + (size_t)m * F), got);
+            }
+            const float4 od = block(l, god, true);
+            block(LMAX + l, got, false);
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                const int m = l * l - 1 + mm;
+                vals[m - M0] = hsum4(gdX[m - M0] * od);
+            }
+        }
+        cutp = group_sum(cutp, lps);
+        if (lp == 0) cut_slice[e] = cutp;
+        if (H <= 8 && lps >= KP) {
+            multi_group_sum<KP>(vals, lps, lp);
+            const int stride = lps / KP;
+            if ((lp & (stride - 1)) == 0) {
+                const int idx = lp / stride;
+                if (idx < XR) p.g_rl[(size_t)e * D + M0 + idx] = vals[0];
+                else if (idx - XR < H) ga_slice[(size_t)e * H + idx - XR] = vals[0];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < XR + 8; ++k) {
+                const float sv = group_sum(vals[k], lps);
+                if (lp == 0) {
+                    if (k < XR) p.g_rl[(size_t)e * D + M0 + k] = sv;
+                    else if (k - XR < H) ga_slice[(size_t)e * H + k - XR] = sv;
+                }
+            }
+        }
+    }
+}
+
+// softmax backward over the summed head gradients of all groups, then scores backward (g_ta, g_q)
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const MsgBwdArgs p, const float* __restrict__ ga_parts, int G, size_t gstride) {
+    __shared__ __attribute__((aligned(16))) float red[1024];
+    const int N = p.N, F = p.F, H = p.H;
+    const int i = xcd_item(blockIdx.x, N);
+    if (i < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    const int e0 = p.rowptr[i], e1 = p.rowptr[i + 1];
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int h = wave; h < H; h += 4) {
+            float dot = 0.f;
+            for (int e = e0 + lane; e < e1; e += 64) {
+                float ga = 0.f;
+                for (int q = 0; q < G; ++q) ga += ga_parts[q * gstride + (size_t)e * H + h];
+                p.g_s[(size_t)e * H + h] = ga;
+                dot += p.a[(size_t)e * H + h] * ga;
+            }
+            dot = wave_sum(dot);
+            for (int e = e0 + lane; e < e1; e += 64) {
+                const float nrm = p.outdeg ? sqrtf((float)p.outdeg[p.src[e]]) * p.inv_sqrt_f : p.inv_sqrt_f;
+                const float av = p.a[(size_t)e * H + h];
+                p.g_s[(size_t)e * H + h] = av * p.g_s[(size_t)e * H + h] - (av / nrm) * dot;
+            }
+        }
+    }
+    __syncthreads();
+    const int hq = c0 / (F / H);
+    const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
+    float4 gq = zero4();
+    for (int e = e0 + slot; e < e1; e += ns) {
+        const float gs = p.g_s[(size_t)e * H + hq];
+        const float4 kj = ld4(p.qk + (size_t)p.src[e] * p.ldqk + F + c0);
+        const float4 pta = ld4(p.eproj + (size_t)e * p.lde + c0);
+        gq = fma4(gs, kj * silu4(pta), gq);
+        st4(p.g_eproj + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dsilu4(pta));
+    }
+    st4(&red[slot * F + c0], gq);
+    __syncthreads();
+    if (slot == 0) st4(p.g_nproj + (size_t)i * p.ldn + c0, red4(red, c0, F, ns));
+}
+
+template <int LMAX, int LLO, int LHI, bool SCALAR>
+__global__ __launch_bounds__(256) void msg_bwd_source_group_kernel(const MsgBwdArgs p) {
+    constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
+    constexpr int M = 1 + 2 * LMAX;
+    constexpr int NL = LHI - LLO + 1;
+    constexpr int XR = (LHI + 1) * (LHI + 1) - LLO * LLO, M0 = LLO * LLO - 1;
+    constexpr int NB = (SCALAR ? 1 : 0) + 2 * NL;            // value blocks of this group
+    constexpr int ROWS = 2 * NB + XR + (SCALAR ? 1 : 0);     // g_x, g_v per block, g_X rows, g_k
+    constexpr int CH = ROWS < 9 ? ROWS : 9;
+    __shared__ __attribute__((aligned(16))) float red[CH * 1024];
+    const int N = p.N, F = p.F, H = p.H;
+    const int j = xcd_item(blockIdx.x, N);
+    if (j < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    const int p0 = p.colptr[j], p1 = p.colptr[j + 1];
+    const int per_head = (M * F) / H;
+    const int hq = c0 / (F / H);
+    // local block k -> value block: [scalar], dir LLO..LHI, tensor LLO..LHI
+    auto vblock = [&](int k) { return SCALAR ? (k == 0 ? 0 : (k <= NL ? LLO + k - 1 : LMAX + LLO + k - 1 - NL))
+                                             : (k < NL ? LLO + k : LMAX + LLO + k - NL); };
+    float4 acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = zero4();
+
+    for (int pp = p0 + slot; pp < p1; pp += ns) {
+        const int e = p.perm[pp];
+        const int i = p.dst[e];
+        const float ce = p.cut[e];
+        const float* xr = p.x + (size_t)j * p.ldxv + c0;
+        const float* vr = p.v + (size_t)j * p.ldxv + c0;
+        const float* Xj = p.X_in + (size_t)j * D * F + c0;
+        asm volatile("" : "+v"(xr), "+v"(vr), "+v"(Xj));      // own rows: re-read per edge, not pinned in registers
+        const float* tr = p.eproj + (size_t)e * p.lde + F + c0;
+        const float* ar = p.a + (size_t)e * H;
+        const float* re = p.rl + (size_t)e * D;
+        const float* gXi = p.g_X1 + (size_t)i * D * F + c0;
+        if (SCALAR) {
+            const float4 go = ld4(p.g_h1 + (size_t)i * F + c0);
+            acc[0] = fma4(go, ld4(tr) * ce, acc[0]);
+            acc[NB] = fma4(ar[c0 / per_head], go, acc[NB]);
+        }
+#pragma unroll
+        for (int l = LLO; l <= LHI; ++l) {
+            const int kd = (SCALAR ? 1 : 0) + (l - LLO), kt = kd + NL;
+            const int bd = l, bt = LMAX + l;
+            const float4 tfd = ld4(tr + bd * F), tft = ld4(tr + bt * F);
+            const float ad = ar[(bd * F + c0) / per_head], at = ar[(bt * F + c0) / per_head];
+            const float4 ot = fma4(at, ld4(vr + bt * F), (tft * ld4(xr + bt * F)) * ce);   // forward tensor gate
+            float4 god = zero4(), got = zero4();
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                const int m = l * l - 1 + mm;
+                const float4 gx = ld4(gXi + (size_t)m * F);
+                god = fma4(re[m], gx, god);
+                got = fma4(gx, ld4(Xj + (size_t)m * F), got);
+                acc[2 * NB + m - M0] = fma4(gx, ot, acc[2 * NB + m - M0]);
+            }
+            acc[kd] = fma4(god, tfd * ce, acc[kd]);
+            acc[NB + kd] = fma4(ad, god, acc[NB + kd]);
+            acc[kt] = fma4(got, tft * ce, acc[kt]);
+            acc[NB + kt] = fma4(at, got, acc[NB + kt]);
+        }
+        if (SCALAR) {
+            const float gs = p.g_s[(size_t)e * H + hq];
+            const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
+            const float4 ta = silu4(ld4(p.eproj + (size_t)e * p.lde + c0));
+            acc[2 * NB + XR] = fma4(gs, qi * ta, acc[2 * NB + XR]);
+        }
+    }
+    reduce_rows<ROWS>(acc, red, slot, c0, F, ns, [&](int row, float4 sv) {
+        if (row < NB) st4(p.g_x + (size_t)j * p.ldxv + vblock(row) * F + c0, sv);
+        else if (row < 2 * NB) st4(p.g_v + (size_t)j * p.ldxv + vblock(row - NB) * F + c0, sv);
+        else if (row < 2 * NB + XR) {
+            const size_t off = ((size_t)j * D + M0 + (row - 2 * NB)) * F + c0;
+            st4(p.g_X_out + off, ld4(p.g_X1 + off) + sv);
+        } else st4(p.g_nproj + (size_t)j * p.ldn + F + c0, sv);
+    });
+}
+
+// HTR backward per degree group (w = sum_l w_l: the degrees are independent)
+template <int LMAX, int LLO, int LHI, bool FIRST>
+__global__ __launch_bounds__(256) void htr_bwd_target_group_kernel(
+    const float* __restrict__ gtp, const float* __restrict__ pre_t, const float* __restrict__ w,
+    const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
+    const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F,
+    float* __restrict__ gEQ, float* __restrict__ g_rl, float* __restrict__ g_pre_t) {
+    constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
+    constexpr int XR = (LHI + 1) * (LHI + 1) - LLO * LLO, M0 = LLO * LLO - 1;
+    constexpr int KP = XR <= 4 ? 4 : (XR <= 8 ? 8 : 16);
+    constexpr int CH = XR < 9 ? XR : 9;
+    __shared__ __attribute__((aligned(16))) float red[CH * 1024];
+    const int i = xcd_item(blockIdx.x, N);
+    if (i < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
+    float4 eq[XR], acc[XR];
+#pragma unroll
+    for (int m = 0; m < XR; ++m) { eq[m] = ld4(EQ + ((size_t)i * D + M0 + m) * F + c0); acc[m] = zero4(); }
+    for (int e = rowptr[i] + slot; e < rowptr[i + 1]; e += ns) {
+        const float4 gte = ld4(gtp + (size_t)e * F + c0), pte = ld4(pre_t + (size_t)e * F + c0);
+        const float4 gw = gte * silu4(pte);
+        if (FIRST) st4(g_pre_t + (size_t)e * F + c0, gte * ld4(w + (size_t)e * F + c0) * dsilu4(pte));
+        const float* kj = EK + (size_t)src[e] * D * F + c0;
+        const float* re = rl + (size_t)e * D;
+        float part[KP];
+#pragma unroll
+        for (int m = 0; m < KP; ++m) part[m] = 0.f;
+#pragma unroll
+        for (int l = LLO; l <= LHI; ++l) {
+            const int b0 = l * l - 1 - M0;
+            float4 ek[2 * LMAX + 1];
+            float r[2 * LMAX + 1];
+            float4 pa = zero4(), pb = zero4();
+            float rr = 0.f;
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                ek[mm] = ld4(kj + (size_t)(M0 + b0 + mm) * F);
+                r[mm] = re[M0 + b0 + mm];
+                pa = fma4(r[mm], eq[b0 + mm], pa);
+                pb = fma4(r[mm], ek[mm], pb);
+                rr = fmaf(r[mm], r[mm], rr);
+            }
+            const float c = 2.0f - rr;
+            const float4 papb = pa * pb;
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                acc[b0 + mm] = fma4(gw, ek[mm] + pb * (-c * r[mm]), acc[b0 + mm]);
+                part[b0 + mm] = hsum4(gw * ((eq[b0 + mm] * pb + pa * ek[mm]) * (-c) + papb * (2.0f * r[mm])));
+            }
+        }
+        if (lps >= KP) {
+            multi_group_sum<KP>(part, lps, lp);
+            const int stride = lps / KP;
+            if ((lp & (stride - 1)) == 0 && lp / stride < XR) g_rl[(size_t)e * D + M0 + lp / stride] = part[0];
+        } else {
+#pragma unroll
+            for (int m = 0; m < XR; ++m) {
+                const float sv = group_sum(part[m], lps);
+                if (lp == 0) g_rl[(size_t)e * D + M0 + m] = sv;
+            }
+        }
+    }
+    reduce_rows<XR>(acc, red, slot, c0, F, ns, [&](int row, float4 sv) { st4(gEQ + ((size_t)i * D + M0 + row) * F + c0, sv); });
+}
+
+template <int LMAX, int LLO, int LHI>
+__global__ __launch_bounds__(256) void htr_bwd_source_group_kernel(
+    const float* __restrict__ gtp, const float* __restrict__ pre_t,
+    const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
+    const int* __restrict__ colptr, const int* __restrict__ perm, const int* __restrict__ dst, int N, int F,
+    float* __restrict__ gEK) {
+    constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
+    constexpr int XR = (LHI + 1) * (LHI + 1) - LLO * LLO, M0 = LLO * LLO - 1;
+    constexpr int CH = XR < 9 ? XR : 9;
+    __shared__ __attribute__((aligned(16))) float red[CH * 1024];
+    const int j = xcd_item(blockIdx.x, N);
+    if (j < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    float4 acc[XR];
+#pragma unroll
+    for (int m = 0; m < XR; ++m) acc[m] = zero4();
+    for (int pp = colptr[j] + slot; pp < colptr[j + 1]; pp += ns) {
+        const int e = perm[pp];
+        const float4 gw = ld4(gtp + (size_t)e * F + c0) * silu4(ld4(pre_t + (size_t)e * F + c0));
+        const float* qi = EQ + (size_t)dst[e] * D * F + c0;
+        const float* re = rl + (size_t)e * D;
+#pragma unroll
+        for (int l = LLO; l <= LHI; ++l) {
+            const int b0 = l * l - 1 - M0;
+            float4 eq[2 * LMAX + 1];
+            float r[2 * LMAX + 1];
+            float4 pa = zero4();
+            float rr = 0.f;
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                eq[mm] = ld4(qi + (size_t)(M0 + b0 + mm) * F);
+                r[mm] = re[M0 + b0 + mm];
+                pa = fma4(r[mm], eq[mm], pa);
+                rr = fmaf(r[mm], r[mm], rr);
+            }
+            const float c = 2.0f - rr;
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm) acc[b0 + mm] = fma4(gw, eq[mm] + pa * (-c * r[mm]), acc[b0 + mm]);
+        }
+    }
+    reduce_rows<XR>(acc, red, slot, c0, F, ns, [&](int row, float4 sv) { st4(gEK + ((size_t)j * D + M0 + row) * F + c0, sv); });
+}
+
 // =========================================================================== EQFF backward
 // part a: gm = [gh' | sum_m gX' Xp],  gXp = gX' * m2
 __global__ void eqff_bwd_a_kernel(const float* __restrict__ gh, const float* __restrict__ gX,
@@ -672,9 +995,20 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
     if (N == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(gn::xcd_grid(N)), block(256);
-    GN_SWITCH_LMAX(htr_bwd_target_kernel, grid, block, st, g_t_out, pre_t, w, EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl, g_pre_t);
-    GN_LAUNCH_CHECK();
-    GN_SWITCH_LMAX(htr_bwd_source_kernel, grid, block, st, g_t_out, pre_t, EQ, EK, rl, colptr, perm, dst, N, F, gEK);
+#define GN_HTRB(L, LLO, LHI, FIRST)                                                                              \
+    hipLaunchKernelGGL((gn::htr_bwd_target_group_kernel<L, LLO, LHI, FIRST>), grid, block, 0, st, g_t_out, pre_t, w, \
+                       EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl, g_pre_t);                                        \
+    hipLaunchKernelGGL((gn::htr_bwd_source_group_kernel<L, LLO, LHI>), grid, block, 0, st, g_t_out, pre_t, EQ, EK, \
+                       rl, colptr, perm, dst, N, F, gEK)
+    if (lmax <= 2) {
+        GN_SWITCH_LMAX(htr_bwd_target_kernel, grid, block, st, g_t_out, pre_t, w, EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl, g_pre_t);
+        GN_LAUNCH_CHECK();
+        GN_SWITCH_LMAX(htr_bwd_source_kernel, grid, block, st, g_t_out, pre_t, EQ, EK, rl, colptr, perm, dst, N, F, gEK);
+    } else if (lmax == 3) {
+        GN_HTRB(3, 1, 2, true); GN_HTRB(3, 3, 3, false);
+    } else {
+        GN_HTRB(4, 1, 2, true); GN_HTRB(4, 3, 3, false); GN_HTRB(4, 4, 4, false);
+    }
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
@@ -685,13 +1019,17 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
         if (!(p.abl & 16)) hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST>), grid, block, 0, st, p); \
     } while (0)
 
+extern "C" int gn_message_backward_groups(int lmax, int sep_dir, int sep_tensor) {
+    return (lmax >= 3 && sep_dir && sep_tensor) ? lmax - 1 : 1;
+}
+
 extern "C" int gn_message_backward(
     const float* x, const float* v, int ldxv, const float* eproj, int lde, const float* a,
     const float* qk, int ldqk, const float* X_in, const float* rl, const float* cut, const int* outdeg,
     const float* g_h1, const float* g_X1,
     const int* rowptr, const int* src, const int* dst, const int* colptr, const int* perm,
     float* g_eproj, float* g_s, float* g_nproj, int ldn, float* g_x, float* g_v, float* g_X_out,
-    float* g_rl, float* g_cut,
+    float* g_rl, float* g_cut, float* ga_parts, long E,
     int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream) {
     if (!bwd_dim_ok(F) || N < 0 || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || lmax < 1 || lmax > 4 ||
         (ldxv & 3) || (lde & 3) || (ldqk & 3) || (ldn & 3) || g_X_out == g_X1)
@@ -702,6 +1040,27 @@ extern "C" int gn_message_backward(
                      N, F, H, (float)(1.0 / sqrt((double)F)), getenv("GN_MSGB_ABL") ? atoi(getenv("GN_MSGB_ABL")) : 0};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(gn::xcd_grid(N)), block(256);
+    if (gn_message_backward_groups(lmax, sep_dir, sep_tensor) > 1) {
+        // degree groups: target passes (head sums and cut slices per group) -> attention backward -> source passes
+        if (ga_parts == nullptr || E <= 0) return GN_ERR_BAD_ARG;
+        const size_t gs = (size_t)E * H;
+#define GN_MSGB_T(L, LLO, LHI, SC, G)                                                                        \
+    hipLaunchKernelGGL((gn::msg_bwd_target_group_kernel<L, LLO, LHI, SC>), grid, block, 0, st, p,            \
+                       ga_parts + (size_t)(G) * gs, g_cut + (size_t)(G) * E)
+#define GN_MSGB_S(L, LLO, LHI, SC) \
+    hipLaunchKernelGGL((gn::msg_bwd_source_group_kernel<L, LLO, LHI, SC>), grid, block, 0, st, p)
+        if (lmax == 3) {
+            GN_MSGB_T(3, 1, 2, true, 0); GN_MSGB_T(3, 3, 3, false, 1);
+            hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, 2, gs);
+            GN_MSGB_S(3, 1, 2, true); GN_MSGB_S(3, 3, 3, false);
+        } else {
+            GN_MSGB_T(4, 1, 2, true, 0); GN_MSGB_T(4, 3, 3, false, 1); GN_MSGB_T(4, 4, 4, false, 2);
+            hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, 3, gs);
+            GN_MSGB_S(4, 1, 2, true); GN_MSGB_S(4, 3, 3, false); GN_MSGB_S(4, 4, 4, false);
+        }
+        GN_LAUNCH_CHECK();
+        return GN_OK;
+    }
     const int key = lmax * 4 + (sep_dir ? 2 : 0) + (sep_tensor ? 1 : 0);
     switch (key) {
         case 4: case 5: case 6: case 7: GN_MSGB_LAUNCH(1, false, false); break;

@@ -20,6 +20,7 @@ from typing import List, Optional, Tuple
 
 import torch
 
+from . import _lib
 from ._lib import call, ptr
 
 
@@ -262,8 +263,10 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
 
     # every contributing kernel writes its own slice; the geometry backward sums them in a fixed order
     L = len(pw.layers)
-    n_rl, n_cut = 2 * L - 1, L + 1
+    G = _lib.load().gn_message_backward_groups(lmax, int(cfg.sep_dir), int(cfg.sep_tensor))
+    n_rl, n_cut = 2 * L - 1, G * L + 1
     g_rl_parts, g_cut_parts = new(n_rl, E, D), new(n_cut, E)
+    ga_parts = new(G, E, H) if G > 1 else None
     rl_slice = lambda q: g_rl_parts.data_ptr() + 4 * q * E * D
     cut_slice = lambda q: g_cut_parts.data_ptr() + 4 * q * E
     gh = gh.contiguous()
@@ -312,7 +315,8 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
         call("gn_message_backward", ptr(lt.xs), ptr(lt.vs), M * F_, ptr(lt.eproj), lde, ptr(lt.attn),
              ptr(lt.nproj), 4 * F_, ptr(lt.X_in), ptr(g.rl), ptr(g.cut), ptr(g.outdeg),
              ptr(gh1), ptr(gX1), ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm),
-             ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), ptr(gX2), rl_slice(li), cut_slice(li),
+             ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), ptr(gX2), rl_slice(li), cut_slice(G * li),
+             ptr(ga_parts), E,
              N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), st)
         gemm(g_x, M * F_, _T(lw, "Ws2"), None, g_nproj, 4 * F_, N, F_, M * F_, c_off=2 * F_,
              dgate=lt.nproj, g_off=2 * F_)
@@ -334,7 +338,7 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
     call("gn_layernorm_silu_backward", ptr(tape.y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, ptr(gy), N, F_, ptr(gy1), st)
     gemm(gy1, F_, _T(pw, "Wa"), None, g_ctx, 2 * F_, N, 2 * F_, F_)
     call("gn_node_init_backward", ptr(g_ctx), ptr(z32), ptr(tape.feat), 2 * F_, ptr(g.cut), ptr(pw.A_nbr),
-         ptr(g.rowptr), ptr(g.src), N, F_, ptr(g_feat), cut_slice(L), st)
+         ptr(g.rowptr), ptr(g.src), N, F_, ptr(g_feat), cut_slice(G * L), st)
     g_phi = new(E, R)
     gemm(g_feat, 2 * F_, _T(pw, "Winit"), None, g_phi, R, E, R, 2 * F_)
     g_vec, g_diff = new(E, 3), new(E)

@@ -174,8 +174,12 @@ int gn_message_backward(const float* x, const float* v, int ldxv, const float* e
                         const int* outdeg, const float* g_h1, const float* g_X1,
                         const int* rowptr, const int* src, const int* dst, const int* colptr, const int* perm,
                         float* g_eproj, float* g_s, float* g_nproj, int ldn, float* g_x, float* g_v,
-                        float* g_X_out, float* g_rl, float* g_cut,
+                        float* g_X_out, float* g_rl, float* g_cut, float* ga_parts, long E,
                         int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream);
+/* Number of degree groups G the message backward uses for these flags (1 = monolithic kernels; lmax >= 3 with
+ * sep_dir and sep_tensor: {scalar,1,2}, {3}, {4}).  g_cut must then hold G consecutive [E] slices and ga_parts
+ * G x [E,H] floats of workspace. */
+int gn_message_backward_groups(int lmax, int sep_dir, int sep_tensor);
 
 /* EQFF (gotennet.py:716-748) backward, node-local halves around the two gamma_m GEMMs:
  * a: g_m = [g_h | sum_m g_X Xp], g_Xp = g_X * m2;   b: g_Xp += g_ctx[:,F:] Xp / n, g_h1 = g_h + g_ctx[:, :F]. */
