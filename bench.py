@@ -29,6 +29,7 @@ import time
 
 import torch
 
+JSON_FD = 1
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -59,6 +60,11 @@ class KernelTimer:
         return tot, cnt
 
 
+def family(tag):
+    """Kernel family of a launch tag: every projection launch is the same MFMA kernel template."""
+    return "gn_gemm" if tag.startswith("gn_gemm[") else tag
+
+
 def algorithmic_bytes_message(N, E, F, M, D):
     """SURVEY.md 8(d) B_msg: every distinct input element read once, every output written once."""
     return 4 * N * (2 * F + 2 * M * F + D * F) + E * (4 * (F + M * F + D + 2) + 16) + 4 * N * (F + D * F)
@@ -74,11 +80,13 @@ def main():
     ap.add_argument("--workload", default="rmd17_aspirin")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table (stderr)")
+    ap.add_argument("--no-lmax4", action="store_true", help="skip the short lmax=4 side measurement")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (path check)")
     a = ap.parse_args()
 
     # keep stdout clean for the ONE JSON line: RCCL prints a version banner to C stdout at exit
-    json_fd = os.dup(1)
+    global JSON_FD
+    JSON_FD = os.dup(1)
     os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,13 +105,33 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
+    res = measure(a, a.lmax, a.steps, a.warmup, rank, world, dev, dist)
+    side = None
+    if a.lmax != 4 and not a.no_lmax4:
+        # the north-star's "L=4" target shape (lmax = 4), reported alongside (short run)
+        side = measure(a, 4, max(3, a.steps // 4), 2, rank, world, dev, dist)
+    if rank == 0:
+        out = res["out"]
+        if side is not None:
+            so = side["out"]
+            out["also"] = {"lmax4": {k: so[k] for k in ("value", "unit", "ms_per_step", "steps", "roofline",
+                                                        "roofline_gather_scatter")}}
+            out["also"]["lmax4"]["config"] = so["config"]["workload"]
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(res["rep"], res["head"], a.workload, a.lmax)
+        os.write(JSON_FD, (json.dumps(out) + "\n").encode())
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def measure(a, lmax, steps, warmup, rank, world, dev, dist):
     import gotennet_amd
     from gotennet_amd import _lib, synthetic
     from gotennet_amd.graph import distance
     from gotennet_amd.outputs import Atomwise, molecule_ptr
     from gotennet_amd.pipeline import EnergyForces
 
-    F, L, R, H, lmax = 256, 6, 32, 8, a.lmax
+    F, L, R, H = 256, 6, 32, 8
     torch.manual_seed(0)                                   # identical replicated weights on every rank
     rep = gotennet_amd.GotenNet(n_atom_basis=F, n_interactions=L, n_rbf=R, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
                                 num_heads=H, scale_edge=False, lmax=lmax, sep_dir=True, sep_tensor=True).to(dev).eval()
@@ -133,7 +161,7 @@ def main():
         torch.cuda.synchronize()
 
     # ---- untimed: warm-up + per-kernel breakdown to pick the dominant kernel ----------
-    for _ in range(max(a.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         step()
     fence()
     kt = KernelTimer()
@@ -142,20 +170,29 @@ def main():
     torch.cuda.synchronize()
     _lib.TIMER = None
     tot, cnt = kt.summary()
-    dominant = max(tot, key=tot.get)
+    fam = {}
+    for tag, t in tot.items():
+        fam[family(tag)] = fam.get(family(tag), 0.0) + t
+    dominant = max(fam, key=fam.get)               # kernel family with the largest share of the step
     msg_tag = "gn_message_aggregate"
     if a.breakdown and rank == 0:
-        s = sum(tot.values())
+        ssum = sum(tot.values())
+        print(f"# lmax={lmax}: per-kernel HIP-event breakdown of one step ({ssum:.3f} ms of events)", file=sys.stderr)
         for tag in sorted(tot, key=tot.get, reverse=True):
             print(f"  {tag:42s} {tot[tag]:8.3f} ms/step {cnt[tag]:3d} calls {1e3 * tot[tag] / cnt[tag]:8.1f} us/call "
-                  f"{100 * tot[tag] / s:5.1f}%", file=sys.stderr)
+                  f"{100 * tot[tag] / ssum:5.1f}%", file=sys.stderr)
 
     # ---- timed region: exactly K steps, events only around the dominant + message kernels
-    kt = KernelTimer(wanted={dominant, msg_tag})
+    # (the ~130 projection launches of a step are bracketed on the LAST timed step only, so that the
+    # event records do not perturb `value`; the 6 message launches are bracketed on every step)
+    dom_tags = {t for t in tot if family(t) == dominant}
+    kt = KernelTimer(wanted={msg_tag} if len(dom_tags) > 8 else dom_tags | {msg_tag})
     _lib.TIMER = kt
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for it in range(steps):
+        if it == steps - 1:
+            kt.wanted = dom_tags | {msg_tag}
         e, f = step()
     fence()
     dt = time.perf_counter() - t0
@@ -168,39 +205,64 @@ def main():
 
     tot, cnt = kt.summary()
 
-    def roof(tag):
-        us = 1e3 * tot[tag] / cnt[tag]
-        if tag.startswith("gn_gemm["):
+    dom_steps = 1 if len(dom_tags) > 8 else steps
+
+    def roof_gemm_family():
+        """All projection launches of the timed region: algorithmic flops / summed launch time."""
+        flops = t_ms = 0.0
+        n = 0
+        big = None
+        for tag in tot:
+            if family(tag) != "gn_gemm":
+                continue
             m_, n_, k_ = (int(v) for v in tag[8:-1].split("x"))
-            flops = 2.0 * m_ * n_ * k_
-            ach = flops / (us * 1e-6) / 1e12
-            return dict(kernel=tag, bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                        frac=round(ach / MFMA_F32_PEAK_TF, 4), traffic=None, us_per_launch=round(us, 2),
-                        launches_per_step=cnt[tag] // a.steps, algorithmic_flops_per_launch=flops)
+            flops += 2.0 * m_ * n_ * k_ * cnt[tag]
+            t_ms += tot[tag]
+            n += cnt[tag]
+            us = 1e3 * tot[tag] / cnt[tag]
+            if big is None or tot[tag] > big[1]:
+                big = (tag, tot[tag], us, 2.0 * m_ * n_ * k_ / (us * 1e-6) / 1e12)
+        ach = flops / (t_ms * 1e-3) / 1e12
+        exact = os.environ.get("GN_GEMM_MODE", "f32") == "f32"
+        return dict(kernel="gn::gemm_f32_mfma (all projection launches, exact fp32 MFMA)" if exact else
+                    "gn::gemm_bf16x3_mfma (all projection launches, 3xbf16-split MFMA)",
+                    bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                    frac=round(ach / MFMA_F32_PEAK_TF, 4), traffic=_pmc_traffic("gn_gemm_family_avg", lmax),
+                    us_per_launch=round(1e3 * t_ms / n, 2), launches_per_step=n // dom_steps,
+                    algorithmic_flops_per_step=flops / dom_steps,
+                    largest_launch=dict(shape_MxNxK=big[0][8:-1], us=round(big[2], 2), tflops=round(big[3], 2),
+                                        frac=round(big[3] / MFMA_F32_PEAK_TF, 4)))
+
+    def roof_message():
+        us = 1e3 * tot[msg_tag] / cnt[msg_tag]
         nbytes = algorithmic_bytes_message(N, E, F, M, D)
         ach = nbytes / (us * 1e-6) / 1e9
-        return dict(kernel=tag, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic(tag, lmax), us_per_launch=round(us, 2),
-                    launches_per_step=cnt[tag] // a.steps, algorithmic_bytes_per_launch=nbytes)
+        return dict(kernel=msg_tag, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic(msg_tag, lmax), us_per_launch=round(us, 2),
+                    launches_per_step=cnt[msg_tag] // steps, algorithmic_bytes_per_launch=nbytes)
 
+    def roof_other(name):
+        t_ms = sum(tot[t] for t in tot if family(t) == name)
+        n = sum(cnt[t] for t in tot if family(t) == name)
+        return dict(kernel=name, bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
+                    us_per_launch=round(1e3 * t_ms / n, 2), launches_per_step=n // dom_steps)
+
+    out = None
     if rank == 0:
         out = {
             "metric": "molecules/sec (energy+force forward), rMD17 aspirin batch=128, 1/2/4/8 MI355X",
-            "value": round(B * world * a.steps / dt, 1), "unit": "molecules/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value": round(B * world * steps / dt, 1), "unit": "molecules/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if os.environ.get("GN_GEMM_MODE", "f32") == "f32" else "f32 (3xbf16-split MFMA, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"{a.workload} batch={B}/GPU (N={N} atoms, E={E} edges incl. self-loops), "
                                    f"n_atom_basis={F}, n_interactions={L}, lmax={lmax}, n_rbf={R}, heads={H}, "
                                    "sep_dir/sep_tensor, energy+forces",
                        "global_batch": B * world, "parallelism": f"dp{world} (molecule shards, 1 all-reduce)"},
-            "roofline": roof(dominant),
-            "roofline_gather_scatter": roof(msg_tag),
+            "roofline": roof_gemm_family() if dominant == "gn_gemm" else
+            (roof_message() if dominant == msg_tag else roof_other(dominant)),
+            "roofline_gather_scatter": roof_message(),
         }
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(rep, head, a.workload, lmax)
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if dist is not None:
-        dist.destroy_process_group()
+    return {"out": out, "rep": rep, "head": head}
 
 
 def _pmc_traffic(tag, lmax):

@@ -15,7 +15,6 @@
 // layers.py:133-152, 744-746, 805-902 (cutoff, RBF, harmonics).
 #include "gn_common.h"
 #include "gn_sh.h"
-#include <stdlib.h>
 
 namespace gn {
 
@@ -190,7 +189,6 @@ struct MsgBwdArgs {
     float* g_rl; float* g_cut;                         // this call's slice (written, not accumulated)
     int N, F, H;
     float inv_sqrt_f;
-    int abl;                                           // profiling ablations only (0 in production)
 };
 
 // by-target pass: g_tf, g_cut, g_rl, attention backward (g_a -> g_s), g_ta, g_q
@@ -244,7 +242,7 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
                         go = S::is_dir(b) ? fma4(re[m], gdX[m], go) : fma4(gdX[m], ld4(Xj + (size_t)m * F), go);
             }
             const float4 tfb = ld4(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
-            if (!(p.abl & 1)) st4(gtr + b * F, (go * xb) * ce);
+            st4(gtr + b * F, (go * xb) * ce);
             cutp += hsum4(go * tfb * xb);
             pa_h[b] = hsum4(go * vb);
             if (S::is_dir(b)) {
@@ -255,7 +253,6 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
                     for (int m = S::first_row(l); m < S::first_row(l) + 2 * l + 1; ++m) rlp[m] = hsum4(gdX[m] * od);
             }
         }
-        if (p.abl & 8) continue;
         cutp = group_sum(cutp, lps);
         if (lp == 0) p.g_cut[e] = cutp;
         if (H <= 8 && lps >= KP) {                   // D rl sums + up to 8 head sums in one butterfly
@@ -293,7 +290,6 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
             }
         }
     }
-    if (p.abl & 2) return;
     __syncthreads();
     // ---- phase 2: softmax backward per head:  g_s = a g_a - (a / nrm) sum_e' a g_a
     {
@@ -310,7 +306,6 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
         }
     }
     __syncthreads();
-    if (p.abl & 4) return;
     // ---- phase 3: scores backward: g_ta (pre-SiLU' factor), g_q
     const int hq = c0 / (F / H);
     const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
@@ -1016,7 +1011,7 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
 #define GN_MSGB_LAUNCH(L, SD, ST)                                                                        \
     do {                                                                                                  \
         hipLaunchKernelGGL((gn::msg_bwd_target_kernel<L, SD, ST>), grid, block, 0, st, p);                \
-        if (!(p.abl & 16)) hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST>), grid, block, 0, st, p); \
+        hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST>), grid, block, 0, st, p);                \
     } while (0)
 
 extern "C" int gn_message_backward_groups(int lmax, int sep_dir, int sep_tensor) {
@@ -1037,7 +1032,7 @@ extern "C" int gn_message_backward(
     if (N == 0) return GN_OK;
     gn::MsgBwdArgs p{x, v, ldxv, eproj, lde, a, qk, ldqk, X_in, rl, cut, outdeg, g_h1, g_X1,
                      rowptr, src, dst, colptr, perm, g_eproj, g_s, g_nproj, ldn, g_x, g_v, g_X_out, g_rl, g_cut,
-                     N, F, H, (float)(1.0 / sqrt((double)F)), getenv("GN_MSGB_ABL") ? atoi(getenv("GN_MSGB_ABL")) : 0};
+                     N, F, H, (float)(1.0 / sqrt((double)F))};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(gn::xcd_grid(N)), block(256);
     if (gn_message_backward_groups(lmax, sep_dir, sep_tensor) > 1) {

@@ -16,7 +16,6 @@ struct GemmArgs {
     int pro_mode, pro_lo, pro_hi;
     int row_cnt, row_gstride, row_goff;
     int gate_mode;                  // 0: value * gate; 1: value * SiLU'(gate)
-    int skew_blocks, skew_mult;
 };
 
 constexpr int BK = 32, PITCH = 36;

@@ -23,7 +23,6 @@
 //   2: A <- A * SiLU'(P)            (backward through an activation; P = stored pre-activation)
 //   and, for every column, A <- A * G when a_gate != NULL.
 #include "gn_gemm.h"
-#include <stdlib.h>
 
 namespace gn {
 
@@ -82,10 +81,9 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 pa[RA], pb[RB];
-    const int abl = p.skew_mult;                    // GN_GEMM_ABL (profiling ablations only; 0 in production)
     auto fetch = [&](int k0) {
         const int kc = k0 + 4 * c4;
-        const bool kok = kc < p.K && !(abl & 2);
+        const bool kok = kc < p.K;
         const bool pro = PRO && p.pro_mode && kc >= p.pro_lo && kc < p.pro_hi;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
@@ -177,8 +175,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
         if (gn >= p.act_lo && gn < p.act_hi) v = silu4(v);          // act ranges are multiples of 4
         if (p.gate) v = v * (p.gate_mode ? dsilu4(ld4(p.gate + off)) : ld4(p.gate + off));
         if (p.res) v = ld4(p.res + off) + v;
-        if (!(abl & 1)) st4(p.C + off, v);
-        else if (v.x == 123.456f) st4(p.C + off, v);
+        st4(p.C + off, v);
     }
     __syncthreads();                                // LDS is reused by the next tile's first slab
   }
@@ -201,20 +198,15 @@ extern "C" int gn_gemm_ex(const float* A, int lda, const float* W, const float* 
         return GN_ERR_BAD_ARG;
     if (Mrows == 0) return GN_OK;
     gn::GemmArgs p{A, W, bias, C, res, gate, pre_out, a_pre, a_gate, lda, ldc, ldp, ldg, Mrows, Nout, K,
-                   act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, gate_mode, 0, 0};
+                   act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, gate_mode};
     const long big = (long)((Mrows + 127) / 128) * ((Nout + 127) / 128);
     long grid_big = 8L * (((Mrows + 127) / 128 + 7) / 8) * ((Nout + 127) / 128);
     long grid_small = 8L * (((Mrows + 63) / 64 + 7) / 8) * ((Nout + 63) / 64);
-    static const int abl_env = getenv("GN_GEMM_ABL") ? atoi(getenv("GN_GEMM_ABL")) : 0;
-    p.skew_mult = abl_env;
     const bool pro = pro_mode != 0 || a_gate != nullptr;
     hipStream_t st = (hipStream_t)stream;
-    static const int pers_env = getenv("GN_GEMM_PERSIST") ? atoi(getenv("GN_GEMM_PERSIST")) : 512;
-    const long grid_cap = pers_env > 0 ? pers_env : (1L << 30);
-    const long grid_big_full = grid_big, grid_small_full = grid_small;
-    (void)grid_big_full; (void)grid_small_full;
-    if (grid_big > grid_cap) grid_big = grid_cap;
-    if (grid_small > 2 * grid_cap) grid_small = 2 * grid_cap;
+    // persistent launch: at most 2 (big tiles) / 4 (small tiles) workgroups per CU walk the tile list
+    if (grid_big > 512) grid_big = 512;
+    if (grid_small > 1024) grid_small = 1024;
     if (big >= 384) {
         if (pro) hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, true>), dim3((unsigned)grid_big), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, false>), dim3((unsigned)grid_big), dim3(256), 0, st, p);
@@ -241,7 +233,7 @@ extern "C" int gn_gemm_split(const float* A, int lda, const unsigned short* W3, 
         return GN_ERR_BAD_ARG;
     if (Mrows == 0) return GN_OK;
     gn::GemmArgs p{A, nullptr, bias, C, res, gate, pre_out, a_pre, a_gate, lda, ldc, ldp, ldg, Mrows, Nout, K,
-                   act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, gate_mode, 0, 0};
+                   act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, gate_mode};
     return gn_gemm_split_launch(p, W3, stream);
 }
 
