@@ -204,7 +204,7 @@ extern "C" int gn_gemm_ex(const float* A, int lda, const float* W, const float* 
     long grid_small = 8L * (((Mrows + 63) / 64 + 7) / 8) * ((Nout + 63) / 64);
     const bool pro = pro_mode != 0 || a_gate != nullptr;
     hipStream_t st = (hipStream_t)stream;
-    // persistent launch: at most 2 (big tiles) / 4 (small tiles) workgroups per CU walk the tile list
+    // persistent launch: at most 2 (big tiles) / 4 (small tiles) workgroups per CU walk the tile list (+2 %)
     if (grid_big > 512) grid_big = 512;
     if (grid_small > 1024) grid_small = 1024;
     if (big >= 384) {

@@ -74,6 +74,50 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+#: GN_OVERLAP=1 runs the atom-sized (node-level) kernel chains of a layer on a second HIP stream, concurrently
+#: with the edge-sized GEMMs they do not depend on.  Measured on MI355X (round 1): 14.89 -> 14.77 ms/step only --
+#: the edge GEMM's two 73.7 KB-LDS workgroups per CU leave no LDS for a co-resident kernel -- so it is OFF by default.
+OVERLAP = os.environ.get("GN_OVERLAP", "0") != "0"
+_SIDE: dict = {}
+
+
+class _Side:
+    """``with _Side(dev) as s:`` forks a side stream off the current one; ``s.join()`` makes the
+    current stream wait for it.  No-op (same stream) when OVERLAP is off."""
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        if OVERLAP:
+            key = (device.index if device.index is not None else torch.cuda.current_device())
+            if key not in _SIDE:
+                _SIDE[key] = torch.cuda.Stream(device=device)
+            self.side = _SIDE[key]
+        else:
+            self.side = self.main
+        self.ctx = None
+
+    def __enter__(self):
+        if self.side is not self.main:
+            self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def wait_main(self):
+        """inside the block: make the side stream wait for what the main stream has queued so far."""
+        if self.side is not self.main:
+            self.side.wait_stream(self.main)
+
+    def join(self):
+        if self.side is not self.main:
+            self.main.wait_stream(self.side)
+
+
 #: projection arithmetic: "split" = 3 x bf16 split on the bf16 matrix cores (fp32-class error, 2.67x the
 #: fp32 MFMA rate); "f32" = exact fp32 MFMA.  Env GN_GEMM_MODE overrides.
 GEMM_MODE = os.environ.get("GN_GEMM_MODE", "f32")
@@ -121,18 +165,17 @@ class Graph:
         self.src = torch.empty(E, **i32)
         self.dst = torch.empty(E, **i32)
         self.rowptr = torch.empty(n_atoms + 1, **i32)
-        st = _stream()
-        call("gn_build_csr", ptr(edge_index), E, n_atoms, ptr(self.src), ptr(self.dst), ptr(self.rowptr), st)
+        call("gn_build_csr", ptr(edge_index), E, n_atoms, ptr(self.src), ptr(self.dst), ptr(self.rowptr), _stream())
         self.outdeg = None
         if cfg.scale_edge:
             self.outdeg = torch.zeros(n_atoms, **i32)
-            call("gn_out_degree", ptr(self.src), E, ptr(self.outdeg), st)
+            call("gn_out_degree", ptr(self.src), E, ptr(self.outdeg), _stream())
         self.rl = torch.empty((E, cfg.D), **f32)
         self.phi = torch.empty((E, cfg.R), **f32)
         self.cut = torch.empty(E, **f32)
         call("gn_edge_geometry", ptr(edge_vec), ptr(edge_diff), ptr(self.src), ptr(self.dst), E,
              cfg.lmax, cfg.R, ptr(pw.means), ptr(pw.betas), float(cfg.cutoff),
-             ptr(self.rl), ptr(self.phi), ptr(self.cut), st)
+             ptr(self.rl), ptr(self.phi), ptr(self.cut), _stream())
         self.perm = self.colptr = None
 
     def csc(self):
@@ -166,8 +209,8 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
     ``trace`` (tests only) collects per-layer clones of (h, X, t)."""
     F_, R, H, D, M, lmax = cfg.F, cfg.R, cfg.H, cfg.D, cfg.M, cfg.lmax
     N, E = g.N, g.E
-    f32 = dict(dtype=torch.float32, device=z32.device)
-    st = _stream()
+    dev = z32.device
+    f32 = dict(dtype=torch.float32, device=dev)
     new = lambda *shape: torch.empty(shape, **f32)
     tape = Tape() if save else None
 
@@ -176,15 +219,15 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
     gemm(g.phi, R, pw.Winit, pw.binit, feat, 2 * F_, E, 2 * F_, R)
     ctx0 = new(N, 2 * F_)
     call("gn_node_init", ptr(z32), ptr(g.rowptr), ptr(g.src), ptr(feat), 2 * F_, ptr(g.cut),
-         ptr(pw.A_na), ptr(pw.A_nbr), N, F_, ptr(ctx0), st)
+         ptr(pw.A_na), ptr(pw.A_nbr), N, F_, ptr(ctx0), _stream())
     y_pre = new(N, F_)
     gemm(ctx0, 2 * F_, pw.Wa, pw.ba, y_pre, F_, N, F_, 2 * F_)
     y = new(N, F_)
-    call("gn_layernorm_silu", ptr(y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, N, F_, ptr(y), st)
+    call("gn_layernorm_silu", ptr(y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, N, F_, ptr(y), _stream())
     h = new(N, F_)
     gemm(y, F_, pw.Wb, pw.bb, h, F_, N, F_, F_)
     t = new(E, F_)
-    call("gn_edge_init", ptr(h), ptr(g.rowptr), ptr(g.src), feat.data_ptr() + 4 * F_, 2 * F_, N, F_, ptr(t), st)
+    call("gn_edge_init", ptr(h), ptr(g.rowptr), ptr(g.src), feat.data_ptr() + 4 * F_, 2 * F_, N, F_, ptr(t), _stream())
     if save:
         tape.feat, tape.y_pre, tape.h0 = feat, y_pre, h
 
@@ -214,18 +257,26 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
             lt.nproj, lt.xs, lt.vs, lt.eproj, lt.attn = nproj, xs, vs, eproj, attn
             lt.Xp, lt.ctx, lt.pre_g1, lt.mm = Xp, ctx, pre_g1, mm
         # ---- GATA projections (gotennet.py:400-407); SiLU applied by the consumers
-        gemm(h, F_, lw.Wn1, lw.bn1, nproj, 4 * F_, N, 4 * F_, F_)
-        gemm(nproj, 4 * F_, lw.Ws2, lw.bs2, xs, M * F_, N, M * F_, F_, a_off=2 * F_, pro=(1, 0, F_))
-        gemm(nproj, 4 * F_, lw.Wv2, lw.bv2, vs, M * F_, N, M * F_, F_, a_off=3 * F_, pro=(1, 0, F_))
+        with _Side(dev) as fork:                   # atom-sized projections || edge projection
+            gemm(h, F_, lw.Wn1, lw.bn1, nproj, 4 * F_, N, 4 * F_, F_)
+            gemm(nproj, 4 * F_, lw.Ws2, lw.bs2, xs, M * F_, N, M * F_, F_, a_off=2 * F_, pro=(1, 0, F_))
+            gemm(nproj, 4 * F_, lw.Wv2, lw.bv2, vs, M * F_, N, M * F_, F_, a_off=3 * F_, pro=(1, 0, F_))
         gemm(t, F_, lw.We, lw.be, eproj, lde, E, lde, F_)
+        fork.join()
         # ---- message / softmax / aggregate / residual (452-559, 613-640, 426-427)
         call("gn_attn_softmax", ptr(nproj), nproj.data_ptr() + 4 * F_, 4 * F_, ptr(eproj), lde,
-             ptr(g.rowptr), ptr(g.src), ptr(g.outdeg), N, F_, H, ptr(attn), st)
+             ptr(g.rowptr), ptr(g.src), ptr(g.outdeg), N, F_, H, ptr(attn), _stream())
         call("gn_message_aggregate", ptr(xs), ptr(vs), M * F_, eproj.data_ptr() + 4 * F_, lde,
              ptr(attn), ptr(g.rl), ptr(g.cut), ptr(g.rowptr), ptr(g.src),
-             ptr(h), ptr(X), ptr(h2), ptr(X2), N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), st)
+             ptr(h), ptr(X), ptr(h2), ptr(X2), N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
         h, h2 = h2, h
         X, X2 = X2, X
+        # ---- EQFF (716-748): node-local chain on the side stream while HTR walks the edges
+        with _Side(dev) as fork:
+            gemm(X, F_, lw.Wvu, None, Xp, F_, N * D, F_, F_)
+            call("gn_eqff_context", ptr(h), ptr(Xp), float(cfg.eps), N, F_, D, ptr(ctx), _stream())
+            gemm(ctx, 2 * F_, lw.Wm0, lw.bm0, pre_g1, F_, N, F_, 2 * F_)
+            gemm(pre_g1, F_, lw.Wm1, lw.bm1, mm, 2 * F_, N, 2 * F_, F_, pro=(1, 0, F_))
         # ---- HTR (429-445, 561-611)
         if not last:
             gemm(X, F_, lw.Wvq, None, EQ, F_, N * D, F_, F_)
@@ -234,16 +285,12 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
                 cnt = 2 * l + 1
                 gemm(X, F_, lw.Wvk[l - 1], None, EK, F_, N * cnt, F_, F_, rowmap=(cnt, D, off))
                 off += cnt
-            call("gn_htr_edge", ptr(EQ), ptr(EK), ptr(g.rl), ptr(g.rowptr), ptr(g.src), N, F_, lmax, ptr(w), st)
+            call("gn_htr_edge", ptr(EQ), ptr(EK), ptr(g.rl), ptr(g.rowptr), ptr(g.src), N, F_, lmax, ptr(w), _stream())
             gemm(t, F_, lw.Wt, lw.bt, t2, F_, E, F_, F_, act=(0, F_), res=t, gate=w,
                  pre_out=lt.pre_t if save else None)
             t, t2 = t2, t
-        # ---- EQFF (716-748)
-        gemm(X, F_, lw.Wvu, None, Xp, F_, N * D, F_, F_)
-        call("gn_eqff_context", ptr(h), ptr(Xp), float(cfg.eps), N, F_, D, ptr(ctx), st)
-        gemm(ctx, 2 * F_, lw.Wm0, lw.bm0, pre_g1, F_, N, F_, 2 * F_)
-        gemm(pre_g1, F_, lw.Wm1, lw.bm1, mm, 2 * F_, N, 2 * F_, F_, pro=(1, 0, F_))
-        call("gn_eqff_update", ptr(mm), ptr(Xp), N, F_, D, ptr(h), ptr(X), st)
+        fork.join()                                # X is updated in place only after HTR has read it
+        call("gn_eqff_update", ptr(mm), ptr(Xp), N, F_, D, ptr(h), ptr(X), _stream())
         if trace is not None:
             trace.append((h.clone(), X.clone(), t.clone()))
     return h, X, tape
@@ -256,7 +303,6 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
     F_, R, H, D, M, lmax = cfg.F, cfg.R, cfg.H, cfg.D, cfg.M, cfg.lmax
     N, E = g.N, g.E
     f32 = dict(dtype=torch.float32, device=z32.device)
-    st = _stream()
     new = lambda *shape: torch.empty(shape, **f32)
     colptr, perm = g.csc()
     lde = (1 + M) * F_
@@ -284,10 +330,10 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
         lw, lt = pw.layers[li], tape.layers[li]
         last = lw.Wt is None
         # ---- EQFF backward
-        call("gn_eqff_backward_a", ptr(gh), ptr(gX), ptr(lt.mm), ptr(lt.Xp), N, F_, D, ptr(gm), ptr(gXp), st)
+        call("gn_eqff_backward_a", ptr(gh), ptr(gX), ptr(lt.mm), ptr(lt.Xp), N, F_, D, ptr(gm), ptr(gXp), _stream())
         gemm(gm, 2 * F_, _T(lw, "Wm1"), None, g_g1, F_, N, F_, 2 * F_, dgate=lt.pre_g1)   # * SiLU'(pre) in the epilogue
         gemm(g_g1, F_, _T(lw, "Wm0"), None, g_ctx, 2 * F_, N, 2 * F_, F_)
-        call("gn_eqff_backward_b", ptr(g_ctx), ptr(lt.ctx), ptr(lt.Xp), ptr(gh), N, F_, D, ptr(gXp), ptr(gh1), st)
+        call("gn_eqff_backward_b", ptr(g_ctx), ptr(lt.ctx), ptr(lt.Xp), ptr(gh), N, F_, D, ptr(gXp), ptr(gh1), _stream())
         gemm(gXp, F_, _T(lw, "Wvu"), None, gX1, F_, N * D, F_, F_, res=gX)
         # ---- HTR backward
         if not last:
@@ -295,7 +341,7 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
                 raise RuntimeError("internal: missing edge gradient")
             call("gn_htr_backward", ptr(gt), ptr(lt.pre_t), ptr(lt.w), ptr(lt.EQ), ptr(lt.EK), ptr(g.rl),
                  ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm), N, F_, lmax,
-                 ptr(gEQ), ptr(gEK), rl_slice(L + li), ptr(g_pre_t), st)
+                 ptr(gEQ), ptr(gEK), rl_slice(L + li), ptr(g_pre_t), _stream())
             gemm(gEQ, F_, _T(lw, "Wvq"), None, gX1, F_, N * D, F_, F_, res=gX1)
             off = 0
             for l in range(1, lmax + 1):
@@ -317,7 +363,7 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
              ptr(gh1), ptr(gX1), ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm),
              ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), ptr(gX2), rl_slice(li), cut_slice(G * li),
              ptr(ga_parts), E,
-             N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), st)
+             N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
         gemm(g_x, M * F_, _T(lw, "Ws2"), None, g_nproj, 4 * F_, N, F_, M * F_, c_off=2 * F_,
              dgate=lt.nproj, g_off=2 * F_)
         gemm(g_v, M * F_, _T(lw, "Wv2"), None, g_nproj, 4 * F_, N, F_, M * F_, c_off=3 * F_,
@@ -331,20 +377,20 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
     # ---- init backward (layers.py:1658-1714) ------------------------------------------
     g_feat = new(E, 2 * F_)
     call("gn_edge_init_backward", ptr(gt), ptr(tape.h0), ptr(tape.feat), 2 * F_, ptr(g.rowptr), ptr(g.src),
-         ptr(colptr), ptr(perm), N, F_, ptr(g_feat), ptr(gh), st)
+         ptr(colptr), ptr(perm), N, F_, ptr(g_feat), ptr(gh), _stream())
     gy = new(N, F_)
     gemm(gh, F_, _T(pw, "Wb"), None, gy, F_, N, F_, F_)
     gy1 = new(N, F_)
-    call("gn_layernorm_silu_backward", ptr(tape.y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, ptr(gy), N, F_, ptr(gy1), st)
+    call("gn_layernorm_silu_backward", ptr(tape.y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, ptr(gy), N, F_, ptr(gy1), _stream())
     gemm(gy1, F_, _T(pw, "Wa"), None, g_ctx, 2 * F_, N, 2 * F_, F_)
     call("gn_node_init_backward", ptr(g_ctx), ptr(z32), ptr(tape.feat), 2 * F_, ptr(g.cut), ptr(pw.A_nbr),
-         ptr(g.rowptr), ptr(g.src), N, F_, ptr(g_feat), cut_slice(G * L), st)
+         ptr(g.rowptr), ptr(g.src), N, F_, ptr(g_feat), cut_slice(G * L), _stream())
     g_phi = new(E, R)
     gemm(g_feat, 2 * F_, _T(pw, "Winit"), None, g_phi, R, E, R, 2 * F_)
     g_vec, g_diff = new(E, 3), new(E)
     call("gn_edge_geometry_backward", ptr(g.edge_vec), ptr(g.edge_diff), ptr(g.src), ptr(g.dst), E, lmax, R,
          ptr(pw.means), ptr(pw.betas), float(cfg.cutoff), ptr(g_rl_parts), n_rl, ptr(g_cut_parts), n_cut,
-         ptr(g_phi), ptr(g_vec), ptr(g_diff), st)
+         ptr(g_phi), ptr(g_vec), ptr(g_diff), _stream())
     return g_vec, g_diff
 
 
