@@ -111,3 +111,40 @@ def test_forces_match_oracle_wide(F, L, lmax):
     assert rel_err(f.cpu(), f_ref) < TOL
     # conservation: forces of an isolated molecule sum to zero (translation invariance)
     assert float(f.cpu().reshape(3, 14, 3).sum(1).abs().max()) < 1e-3 * float(f.abs().max())
+
+
+def test_forces_asymmetric_graph_neighbor_cap():
+    """A dense molecule with max_num_neighbors far below the neighbour count: the capped radius graph is NOT
+    symmetric (j->i present, i->j absent), so the by-source (CSC) backward pass sees different rows than the
+    by-target pass.  Same first-k rule as the oracle; forces vs the oracle's fp64 autograd."""
+    import gotennet_amd
+    from gotennet_amd.graph import distance
+    from gotennet_amd.outputs import Atomwise
+    from gotennet_amd.pipeline import EnergyForces
+    from oracle import gotennet_oracle as orc
+    torch.manual_seed(11)
+    F, L, lmax, cap = 64, 2, 2, 8
+    net = gotennet_amd.GotenNet(n_atom_basis=F, n_interactions=L, n_rbf=16, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
+                                num_heads=8, scale_edge=True, lmax=lmax, sep_dir=True, sep_tensor=True)
+    head = Atomwise(n_in=F, n_hidden=32, derivative="forces")
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    hsd = {k: v.clone() for k, v in head.state_dict().items()}
+    cfg = orc.default_config(n_atom_basis=F, n_interactions=L, n_rbf=16, num_heads=8, scale_edge=True, lmax=lmax,
+                             sep_dir=True, sep_tensor=True)
+    g = torch.Generator().manual_seed(5)
+    pos = torch.rand((60, 3), generator=g) * 6.0
+    batch = torch.zeros(60, dtype=torch.long)
+    z = torch.randint(1, 9, (60,), generator=g)
+    ei_ref = orc.radius_graph(pos, batch, 5.0, cap, loop=True)
+    src, dst = ei_ref
+    pairs = set(zip(src.tolist(), dst.tolist()))
+    assert any((d, s_) not in pairs for s_, d in pairs)          # really asymmetric
+    e_ref, f_ref, _ = orc.energy_and_forces({k: v.double() for k, v in sd.items()}, cfg,
+                                            {k: v.double() for k, v in hsd.items()}, z, pos.double(), batch, 1,
+                                            max_num_neighbors=cap)
+    net, head = net.cuda().eval(), head.cuda().eval()
+    ei, w, vec = distance(pos.cuda(), batch.cuda(), 5.0, cap)
+    assert torch.equal(ei.cpu(), ei_ref)
+    e, f = EnergyForces(net, head)(z.cuda(), ei, w, vec, batch.cuda(), 1)
+    assert rel_err(e.cpu(), e_ref) < TOL
+    assert rel_err(f.cpu(), f_ref) < TOL

@@ -179,3 +179,50 @@ def test_gemm_row_map_and_epilogues():
     ref[:, 3:8] = X[:, 3:8].double().cpu() @ W.double().cpu().T
     assert rel_err(out.cpu(), ref) < 1e-5
     assert float(out[:, :3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("F,H", [(512, 8), (1024, 16), (16, 4)])
+def test_forward_feature_width_extremes(F, H):
+    """Slot layout corner cases: F = 512/1024 (a slot spans 2/4 waves), F = 16 (64 slots per workgroup)."""
+    import gotennet_amd
+    from oracle import gotennet_oracle as orc
+    torch.manual_seed(F)
+    net = gotennet_amd.GotenNet(n_atom_basis=F, n_interactions=2, n_rbf=16, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
+                                num_heads=H, scale_edge=True, lmax=2, sep_dir=True, sep_tensor=True)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    cfg = orc.default_config(n_atom_basis=F, n_interactions=2, n_rbf=16, num_heads=H, scale_edge=True, lmax=2,
+                             sep_dir=True, sep_tensor=True)
+    pos, batch, z = _synthetic(2, 12, 3.5, seed=F)
+    ei, w, vec = orc.distance(pos, batch, 5.0)
+    h_ref, X_ref = orc.gotennet_forward(sd, cfg, z, ei, w, vec)
+    net = net.cuda().eval()
+    h, X = net(z.cuda(), ei.cuda(), w.cuda(), vec.cuda())
+    assert rel_err(h.cpu(), h_ref) < TOL
+    assert rel_err(X.cpu(), X_ref) < TOL
+
+
+def test_softmax_high_degree():
+    """One target with 150 incoming edges (> 64 lanes, > one wave pass) and many single-edge targets."""
+    import gotennet_amd
+    from oracle import gotennet_oracle as orc
+    torch.manual_seed(3)
+    F = 64
+    net = gotennet_amd.GotenNet(n_atom_basis=F, n_interactions=2, n_rbf=16, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
+                                num_heads=8, scale_edge=True, lmax=1)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    cfg = orc.default_config(n_atom_basis=F, n_interactions=2, n_rbf=16, num_heads=8, scale_edge=True, lmax=1)
+    n = 151
+    g = torch.Generator().manual_seed(2)
+    pos = torch.rand((n, 3), generator=g) * 2.5
+    z = torch.randint(1, 9, (n,), generator=g)
+    # star: everyone -> atom 0, plus self-loops; target-sorted
+    src = torch.cat([torch.arange(0, n), torch.arange(1, n)])
+    dst = torch.cat([torch.zeros(n, dtype=torch.long), torch.arange(1, n)])
+    ei = torch.stack([src, dst])
+    vec = pos[src] - pos[dst]
+    w = torch.where(src != dst, vec.norm(dim=1), torch.zeros(src.numel()))
+    h_ref, X_ref = orc.gotennet_forward(sd, cfg, z, ei, w, vec)
+    net = net.cuda().eval()
+    h, X = net(z.cuda(), ei.cuda(), w.cuda(), vec.cuda())
+    assert rel_err(h.cpu(), h_ref) < TOL
+    assert rel_err(X.cpu(), X_ref) < TOL
