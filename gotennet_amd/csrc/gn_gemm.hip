@@ -26,7 +26,7 @@
 
 namespace gn {
 
-template <int TM, int TN, bool PRO>
+template <int TM, int TN, bool PRO, int PF>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;       // staged float4 rows per thread
@@ -80,8 +80,10 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 pa[RA], pb[RB];
-    auto fetch = [&](int k0) {
+    // PF register sets of prefetched slabs: a fetched slab stays in flight for PF compute phases (PF = 1 is
+    // what ships: PF = 2/3 measured no gain on MI355X and costs a wave of occupancy)
+    float4 pa[PF][RA], pb[PF][RB];
+    auto fetch = [&](int k0, float4 (&qa)[RA], float4 (&qb)[RB]) {
         const int kc = k0 + 4 * c4;
         const bool kok = kc < p.K;
         const bool pro = PRO && p.pro_mode && kc >= p.pro_lo && kc < p.pro_hi;
@@ -95,28 +97,35 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
                     if (p.a_gate) v = v * ld4(p.a_gate + (size_t)prow[i] * p.ldg + kc);
                 }
             }
-            pa[i] = v;
+            qa[i] = v;
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) pb[i] = (bok[i] && kok) ? ld4(brow[i] + k0) : zero4();
+        for (int i = 0; i < RB; ++i) qb[i] = (bok[i] && kok) ? ld4(brow[i] + k0) : zero4();
     };
-    auto stash = [&](float* buf) {
+    auto stash = [&](float* buf, const float4 (&qa)[RA], const float4 (&qb)[RB]) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) st4(&buf[(sr + 32 * i) * PITCH + 4 * c4], pa[i]);
+        for (int i = 0; i < RA; ++i) st4(&buf[(sr + 32 * i) * PITCH + 4 * c4], qa[i]);
 #pragma unroll
-        for (int i = 0; i < RB; ++i) st4(&buf[(BM + sr + 32 * i) * PITCH + 4 * c4], pb[i]);
+        for (int i = 0; i < RB; ++i) st4(&buf[(BM + sr + 32 * i) * PITCH + 4 * c4], qb[i]);
     };
 
-    // double-buffered K loop: one barrier per slab; slab kt+1 sits in registers while slab kt is multiplied
+    // double-buffered LDS K loop, one barrier per slab; register set s holds slab kt+1 when slab kt is
+    // multiplied and is refilled with slab kt+1+PF right after it has been written to LDS
     const int nk = (p.K + BK - 1) / BK;
-    fetch(0);
-    stash(smem);
+    fetch(0, pa[0], pb[0]);
+    stash(smem, pa[0], pb[0]);
     __syncthreads();
-    if (nk > 1) fetch(BK);
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+        if (1 + s < nk) fetch((1 + s) * BK, pa[s], pb[s]);
 
     const int khalf = (lane >> 5) * 16;
     const int frow = lane & 31;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+      for (int s = 0; s < PF; ++s) {
+        const int kt = kt0 + s;
+        if (kt >= nk) break;
         const float* As = smem + (kt & 1) * STAGE;
         const float* Bs = As + BM * PITCH;
 #pragma unroll
@@ -137,16 +146,17 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
                 b[j][4] = b1.x; b[j][5] = b1.y; b[j][6] = b1.z; b[j][7] = b1.w;
             }
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
+            for (int q = 0; q < 8; ++q)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) stash(smem + ((kt + 1) & 1) * STAGE);   // other buffer: last read in iteration kt-1
+        if (kt + 1 < nk) stash(smem + ((kt + 1) & 1) * STAGE, pa[s], pb[s]);   // other buffer: last read in iteration kt-1
         __syncthreads();
-        if (kt + 2 < nk) fetch((kt + 2) * BK);
+        if (kt + 1 + PF < nk) fetch((kt + 1 + PF) * BK, pa[s], pb[s]);
+      }
     }
 
     // epilogue through LDS: accumulators -> [BM][BN+4] tile -> coalesced float4 rows
@@ -207,12 +217,12 @@ extern "C" int gn_gemm_ex(const float* A, int lda, const float* W, const float* 
     // persistent launch: at most 2 (big tiles) / 4 (small tiles) workgroups per CU walk the tile list (+2 %)
     if (grid_big > 512) grid_big = 512;
     if (grid_small > 1024) grid_small = 1024;
-    if (big >= 384) {
-        if (pro) hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, true>), dim3((unsigned)grid_big), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, false>), dim3((unsigned)grid_big), dim3(256), 0, st, p);
+    if (big >= 384) {                          // measured best switch-over (tools/gemm_bench.py sweep)
+        if (pro) hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, true, 1>), dim3((unsigned)grid_big), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, false, 1>), dim3((unsigned)grid_big), dim3(256), 0, st, p);
     } else {
-        if (pro) hipLaunchKernelGGL((gn::gemm_f32_mfma<1, 1, true>), dim3((unsigned)grid_small), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gn::gemm_f32_mfma<1, 1, false>), dim3((unsigned)grid_small), dim3(256), 0, st, p);
+        if (pro) hipLaunchKernelGGL((gn::gemm_f32_mfma<1, 1, true, 1>), dim3((unsigned)grid_small), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gn::gemm_f32_mfma<1, 1, false, 1>), dim3((unsigned)grid_small), dim3(256), 0, st, p);
     }
     GN_LAUNCH_CHECK();
     return GN_OK;
