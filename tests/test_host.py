@@ -72,3 +72,44 @@ def test_no_oracle_import_in_product():
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
             assert "/root/reference" not in src, fn
+
+
+def test_packed_weights_layout():
+    """Projections that share an input are concatenated in the order the kernels index them."""
+    import gotennet_amd
+    torch.manual_seed(0)
+    F, M = 32, 5
+    net = gotennet_amd.GotenNet(n_atom_basis=F, n_interactions=2, n_rbf=8, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
+                                lmax=2, sep_dir=True, sep_tensor=True)
+    pw = net.packed_weights()
+    g0 = net.gata_list[0]
+    assert net.config().M == M and net.config().D == 8
+    assert torch.equal(pw.layers[0].Wn1[:F], g0.W_q.weight) and torch.equal(pw.layers[0].Wn1[F:2 * F], g0.W_k.weight)
+    assert torch.equal(pw.layers[0].Wn1[2 * F:3 * F], g0.gamma_s[0].weight)
+    assert torch.equal(pw.layers[0].Wn1[3 * F:], g0.gamma_v[0].weight)
+    assert torch.equal(pw.layers[0].We[:F], g0.W_re.weight) and torch.equal(pw.layers[0].We[F:], g0.W_rs.weight)
+    assert pw.layers[0].We.shape == ((1 + M) * F, F)
+    assert pw.layers[0].Wt is not None and pw.layers[1].Wt is None          # last layer has no HTR
+    assert torch.equal(pw.Winit[:F], net.node_init.W_ndp.dense_layers[0].weight)
+    assert torch.equal(pw.Winit[F:], net.edge_init.W_erp.weight)
+    assert net.packed_weights() is pw                                       # cached ...
+    with torch.no_grad():
+        g0.W_q.weight.add_(1.0)
+    pw2 = net.packed_weights()                                              # ... until a parameter changes
+    assert pw2 is not pw and torch.equal(pw2.layers[0].Wn1[:F], g0.W_q.weight)
+
+
+def test_synthetic_shards_are_consistent():
+    """Rank r's shard is the same set of molecules whatever the world size (bench.py sharding)."""
+    from gotennet_amd import synthetic
+    from gotennet_amd.parallel import shard_range
+    pos, batch, z = synthetic.make_batch("rmd17_aspirin", 8, seed=0)
+    for world in (2, 4):
+        parts = []
+        for r in range(world):
+            first, cnt = shard_range(r, world, 8)
+            p, b, zz = synthetic.make_batch("rmd17_aspirin", cnt, seed=0, first_molecule=first)
+            parts.append((p, zz))
+        assert torch.equal(torch.cat([p for p, _ in parts]), pos)
+        assert torch.equal(torch.cat([q for _, q in parts]), z)
+    assert pos.shape == (8 * 21, 3) and int(batch.max()) == 7
