@@ -43,42 +43,36 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
     const int xq = tiles_m >> 3, xr = tiles_m & 7, xcd = blockIdx.x & 7;
     const int rows_here = xq + (xcd < xr ? 1 : 0);
     const int row_base = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
-  // persistent over tiles: workgroup b walks the tiles b/8, b/8 + gridDim/8, ... of ITS XCD's range
-  for (int idx = blockIdx.x >> 3; idx / tiles_n < rows_here; idx += gridDim.x >> 3) {
-    const int tm = row_base + idx / tiles_n;
-    const int m0 = tm * BM;
-    const int n0 = (idx % tiles_n) * BN;
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int c4 = tid & 7;                         // staging map: thread -> (row sr + 32 i, float4 column c4)
     const int sr = tid >> 3;
+    const int stride = gridDim.x >> 3;
 
+    // fetch-side context of a tile (set one tile AHEAD at the end of the K loop: the first slab of the next
+    // tile is already in flight while the current tile's epilogue runs)
     int prow[RA];
     const float* brow[RB];
     bool aok[RA], bok[RB];
+    auto set_tile = [&](int t_idx) {
+        const int m0f = (row_base + t_idx / tiles_n) * BM, n0f = (t_idx % tiles_n) * BN;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        const int gm = m0 + sr + 32 * i;
-        aok[i] = gm < p.M;
-        prow[i] = phys_row(p, aok[i] ? gm : 0);
-    }
+        for (int i = 0; i < RA; ++i) {
+            const int gm = m0f + sr + 32 * i;
+            aok[i] = gm < p.M;
+            prow[i] = phys_row(p, aok[i] ? gm : 0);
+        }
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int gn = n0 + sr + 32 * i;
-        bok[i] = gn < p.N;
-        brow[i] = p.W + (size_t)(bok[i] ? gn : 0) * p.K + 4 * c4;
-    }
+        for (int i = 0; i < RB; ++i) {
+            const int gn = n0f + sr + 32 * i;
+            bok[i] = gn < p.N;
+            brow[i] = p.W + (size_t)(bok[i] ? gn : 0) * p.K + 4 * c4;
+        }
+    };
 
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // PF register sets of prefetched slabs: a fetched slab stays in flight for PF compute phases (PF = 1 is
     // what ships: PF = 2/3 measured no gain on MI355X and costs a wave of occupancy)
@@ -112,7 +106,20 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
     // double-buffered LDS K loop, one barrier per slab; register set s holds slab kt+1 when slab kt is
     // multiplied and is refilled with slab kt+1+PF right after it has been written to LDS
     const int nk = (p.K + BK - 1) / BK;
+    int idx = blockIdx.x >> 3;
+    if (idx / tiles_n >= rows_here) return;
+    set_tile(idx);
     fetch(0, pa[0], pb[0]);
+  // persistent over tiles: workgroup b walks the tiles b/8, b/8 + gridDim/8, ... of ITS XCD's range
+  for (;;) {
+    const int m0 = (row_base + idx / tiles_n) * BM;
+    const int n0 = (idx % tiles_n) * BN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     stash(smem, pa[0], pb[0]);
     __syncthreads();
 #pragma unroll
@@ -159,6 +166,14 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
       }
     }
 
+    // next tile's first slab goes in flight now and lands during the epilogue
+    const int next = idx + stride;
+    const bool has_next = next / tiles_n < rows_here;
+    if (has_next) {
+        set_tile(next);
+        fetch(0, pa[0], pb[0]);
+    }
+
     // epilogue through LDS: accumulators -> [BM][BN+4] tile -> coalesced float4 rows
     // (lane holds column (lane & 31), rows (r&3) + 8 (r>>2) + 4 (lane>>5) of each 32x32 tile)
 #pragma unroll
@@ -171,23 +186,30 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
                 smem[row * CP + wn * 32 * TN + j * 32 + (lane & 31)] = acc[i][j][r];
             }
     __syncthreads();
-    constexpr int C4 = BN / 4;
+    {
+        constexpr int C4 = BN / 4;                  // 256 % C4 == 0: a thread keeps ONE column group
+        const int cc = (tid % C4) * 4, gn = n0 + cc;
+        if (gn < p.N) {
+            const float4 bias4 = p.bias ? ld4(p.bias + gn) : zero4();
+            const bool act = gn >= p.act_lo && gn < p.act_hi;          // act ranges are multiples of 4
 #pragma unroll 4
-    for (int it = 0; it < (BM * C4) / 256; ++it) {
-        const int e = it * 256 + tid;
-        const int row = e / C4, cc = (e % C4) * 4;
-        const int gm = m0 + row, gn = n0 + cc;
-        if (gm >= p.M || gn >= p.N) continue;
-        float4 v = ld4(&smem[row * CP + cc]);
-        if (p.bias) v = v + ld4(p.bias + gn);
-        const size_t off = (size_t)phys_row(p, gm) * p.ldc + gn;
-        if (p.pre_out) st4(p.pre_out + off, v);
-        if (gn >= p.act_lo && gn < p.act_hi) v = silu4(v);          // act ranges are multiples of 4
-        if (p.gate) v = v * (p.gate_mode ? dsilu4(ld4(p.gate + off)) : ld4(p.gate + off));
-        if (p.res) v = ld4(p.res + off) + v;
-        st4(p.C + off, v);
+            for (int it = 0; it < (BM * C4) / 256; ++it) {
+                const int row = it * (256 / C4) + tid / C4;
+                const int gm = m0 + row;
+                if (gm >= p.M) continue;
+                float4 v = ld4(&smem[row * CP + cc]) + bias4;
+                const size_t off = (size_t)phys_row(p, gm) * p.ldc + gn;
+                if (p.pre_out) st4(p.pre_out + off, v);
+                if (act) v = silu4(v);
+                if (p.gate) v = v * (p.gate_mode ? dsilu4(ld4(p.gate + off)) : ld4(p.gate + off));
+                if (p.res) v = ld4(p.res + off) + v;
+                st4(p.C + off, v);
+            }
+        }
     }
     __syncthreads();                                // LDS is reused by the next tile's first slab
+    if (!has_next) break;
+    idx = next;
   }
 }
 
