@@ -22,20 +22,22 @@ SIGNATURES = {
     "gn_abi_version": [C.POINTER(C.c_char_p)],
     "gn_build_csr": [_P, _I, _I, _P, _P, _P, _P],
     "gn_out_degree": [_P, _I, _P, _P],
-    "gn_edge_geometry": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P],
+    "gn_edge_geometry": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P],
     "gn_node_init": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P],
     "gn_edge_init": [_P, _P, _P, _P, _I, _I, _I, _P, _P],
     "gn_layernorm_silu": [_P, _P, _P, _F, _I, _I, _P, _P],
+    "gn_layernorm": [_P, _P, _P, _F, _I, _I, _P, _P],
+    "gn_tensor_norm": [_P, _P, _F, _I, _I, _I, _P, _P],
     "gn_gemm": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "gn_attn_softmax": [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P],
     "gn_message_aggregate": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "gn_htr_edge": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
+    "gn_htr_edge": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "gn_eqff_context": [_P, _P, _F, _I, _I, _I, _P, _P],
     "gn_eqff_update": [_P, _P, _I, _I, _I, _P, _P, _P],
     "gn_gemm_ex": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],
     "gn_gemm_split": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],
     "gn_split_bf16x3": [_P, C.c_long, _P, _P],
-    "gn_htr_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
+    "gn_htr_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "gn_message_backward": [_P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                             _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.c_long, _I, _I, _I, _I, _I, _I, _P],
     "gn_message_backward_groups": [_I, _I, _I],
@@ -44,7 +46,9 @@ SIGNATURES = {
     "gn_edge_init_backward": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "gn_node_init_backward": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "gn_layernorm_silu_backward": [_P, _P, _P, _F, _P, _I, _I, _P, _P],
-    "gn_edge_geometry_backward": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _F, _P, _I, _P, _I, _P, _P, _P, _P],
+    "gn_layernorm_backward": [_P, _P, _F, _P, _I, _I, _P, _P],
+    "gn_tensor_norm_backward": [_P, _P, _P, _F, _I, _I, _I, _P, _P],
+    "gn_edge_geometry_backward": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _I, _P, _I, _P, _P, _P, _P],
     "gn_pos_scatter": [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P],
     "gn_head_energy": [_P, _P, _F, _F, _F, _P, _P, _P, _I, _I, _P, _P, _P],
     "gn_head_grad": [_P, _P, _F, _I, _I, _P, _P],

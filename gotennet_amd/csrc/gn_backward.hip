@@ -823,7 +823,8 @@ __global__ __launch_bounds__(256) void node_init_bwd_kernel(
 }
 
 // y = SiLU(LN(x) gamma + beta): gx = rstd (g_xh - mean(g_xh) - xh mean(g_xh xh)), g_xh = g_out SiLU'(v) gamma
-__global__ __launch_bounds__(256) void layernorm_silu_bwd_kernel(
+template <bool SILU>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     const float* __restrict__ gout, int N, int F, float* __restrict__ gx) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -840,13 +841,13 @@ __global__ __launch_bounds__(256) void layernorm_silu_bwd_kernel(
     float s1 = 0.f, s2 = 0.f;
     for (int f = lane; f < F; f += 64) {
         const float xh = (xr[f] - mean) * rstd;
-        const float g = gr[f] * dsilu(xh * gamma[f] + beta[f]) * gamma[f];
+        const float g = gr[f] * (SILU ? dsilu(xh * gamma[f] + beta[f]) : 1.0f) * gamma[f];
         s1 += g; s2 += g * xh;
     }
     s1 = wave_sum(s1) / (float)F; s2 = wave_sum(s2) / (float)F;
     for (int f = lane; f < F; f += 64) {
         const float xh = (xr[f] - mean) * rstd;
-        const float g = gr[f] * dsilu(xh * gamma[f] + beta[f]) * gamma[f];
+        const float g = gr[f] * (SILU ? dsilu(xh * gamma[f] + beta[f]) : 1.0f) * gamma[f];
         gx[(size_t)row * F + f] = rstd * (g - s1 - xh * s2);
     }
 }
@@ -868,7 +869,7 @@ __host__ __device__ inline Dual3 operator*(Dual3 a, float s) { return s * a; }
 template <int LMAX>
 __global__ void edge_geometry_bwd_kernel(
     const float* __restrict__ vec, const float* __restrict__ dist, const int* __restrict__ src, const int* __restrict__ dst,
-    int E, int R, const float* __restrict__ means, const float* __restrict__ betas, float cutoff, float alpha,
+    int E, int R, int basis, const float* __restrict__ means, const float* __restrict__ betas, float cutoff, float alpha,
     const float* __restrict__ g_rl, int n_rl, const float* __restrict__ g_cut, int n_cut,
     const float* __restrict__ g_phi, float* __restrict__ g_vec, float* __restrict__ g_diff) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
@@ -882,21 +883,34 @@ __global__ void edge_geometry_bwd_kernel(
     const float pi = 3.14159265358979323846f;
     const float d = dist[e];
     float gd = 0.f;
+    if (basis == 1) {                                // d/dd [ sin(a d) / d ]   (d > 0 here: self-loops returned above)
+        for (int r = 0; r < R; ++r) {
+            const float a = means[r], ad = a * d;
+            gd += g_phi[(size_t)e * R + r] * (a * cosf(ad) / d - sinf(ad) / (d * d));
+        }
+    } else if (basis == 2) {                         // d/dd exp(c (d - o)^2) = 2 c (d - o) exp(.)
+        for (int r = 0; r < R; ++r) {
+            const float w = betas[r], q = d - means[r], c2 = -0.5f / (w * w);
+            gd += g_phi[(size_t)e * R + r] * expf(c2 * (q * q)) * (2.0f * c2 * q);
+        }
+    }
     if (d < cutoff) {
         const float arg = d * pi / cutoff;
         const float c = 0.5f * (cosf(arg) + 1.0f);
         const float dc = -0.5f * (pi / cutoff) * sinf(arg);
-        const float u = expf(alpha * (-d));
         float s = 0.f;
-        for (int r = 0; r < R; ++r) {
-            const float w = u - means[r];
-            const float G = expf(-betas[r] * (w * w));
-            // d/dd [ c G ] = dc G + c G (-2 beta w) (-alpha u)
-            s += g_phi[(size_t)e * R + r] * G * (dc + c * (2.0f * betas[r] * w * alpha * u));
+        if (basis == 0) {
+            const float u = expf(alpha * (-d));
+            for (int r = 0; r < R; ++r) {
+                const float w = u - means[r];
+                const float G = expf(-betas[r] * (w * w));
+                // d/dd [ c G ] = dc G + c G (-2 beta w) (-alpha u)
+                s += g_phi[(size_t)e * R + r] * G * (dc + c * (2.0f * betas[r] * w * alpha * u));
+            }
         }
         float gc = 0.f;                              // fixed-order sum of the per-kernel slices
         for (int q = 0; q < n_cut; ++q) gc += g_cut[(size_t)q * E + e];
-        gd = s + gc * dc;
+        gd += s + gc * dc;
     }
     g_diff[e] = gd;
     const float x = vec[3 * e], y = vec[3 * e + 1], z = vec[3 * e + 2];
@@ -982,13 +996,17 @@ static bool bwd_dim_ok(int F) { return F >= 16 && F <= 256 && gn::is_pow2(F); }
         default: hipLaunchKernelGGL(gn::KERNEL<4>, grid, block, 0, st, __VA_ARGS__); break;            \
     }
 
-extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* w, const float* EQ,
+extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* w, const float* w_raw,
+                               const float* EQ,
                                const float* EK, const float* rl, const int* rowptr, const int* src, const int* dst,
-                               const int* colptr, const int* perm, int N, int F, int lmax,
+                               const int* colptr, const int* perm, int N, int F, int lmax, int mode,
                                float* gEQ, float* gEK, float* g_rl, float* g_pre_t, void* stream) {
-    if (!bwd_dim_ok(F) || N < 0 || lmax < 1 || lmax > 4) return GN_ERR_BAD_ARG;
+    if (!bwd_dim_ok(F) || N < 0 || lmax < 1 || lmax > 4 || mode < 0 || mode > 15) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (mode)
+        return gn_htr_backward_general(g_t_out, pre_t, w, w_raw, EQ, EK, rl, rowptr, src, dst, colptr, perm, N, F, lmax,
+                                       mode, gEQ, gEK, g_rl, g_pre_t, st);
     const dim3 grid(gn::xcd_grid(N)), block(256);
 #define GN_HTRB(L, LLO, LHI, FIRST)                                                                              \
     hipLaunchKernelGGL((gn::htr_bwd_target_group_kernel<L, LLO, LHI, FIRST>), grid, block, 0, st, g_t_out, pre_t, w, \
@@ -1124,21 +1142,31 @@ extern "C" int gn_layernorm_silu_backward(const float* x, const float* gamma, co
                                           const float* g_out, int N, int F, float* g_x, void* stream) {
     if (N < 0 || F <= 0) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
-    hipLaunchKernelGGL(gn::layernorm_silu_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(gn::layernorm_bwd_kernel<true>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        x, gamma, beta, eps, g_out, N, F, g_x);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
 
+extern "C" int gn_layernorm_backward(const float* x, const float* gamma, float eps,
+                                     const float* g_out, int N, int F, float* g_x, void* stream) {
+    if (N < 0 || F <= 0) return GN_ERR_BAD_ARG;
+    if (N == 0) return GN_OK;
+    hipLaunchKernelGGL(gn::layernorm_bwd_kernel<false>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       x, gamma, gamma, eps, g_out, N, F, g_x);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
 extern "C" int gn_edge_geometry_backward(const float* edge_vec, const float* edge_diff, const int* src, const int* dst,
-                                         int E, int lmax, int R, const float* means, const float* betas, float cutoff,
-                                         const float* g_rl, int n_rl, const float* g_cut, int n_cut,
+                                         int E, int lmax, int R, int basis, const float* means, const float* betas,
+                                         float cutoff, const float* g_rl, int n_rl, const float* g_cut, int n_cut,
                                          const float* g_phi, float* g_vec, float* g_diff, void* stream) {
-    if (E < 0 || lmax < 1 || lmax > 4 || R <= 0 || n_rl < 0 || n_cut < 0) return GN_ERR_BAD_ARG;
+    if (E < 0 || lmax < 1 || lmax > 4 || R <= 0 || n_rl < 0 || n_cut < 0 || basis < 0 || basis > 2) return GN_ERR_BAD_ARG;
     if (E == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((E + 127) / 128), block(128);
-    GN_SWITCH_LMAX(edge_geometry_bwd_kernel, grid, block, st, edge_vec, edge_diff, src, dst, E, R, means, betas,
+    GN_SWITCH_LMAX(edge_geometry_bwd_kernel, grid, block, st, edge_vec, edge_diff, src, dst, E, R, basis, means, betas,
                    cutoff, 5.0f / cutoff, g_rl, n_rl, g_cut, n_cut, g_phi, g_vec, g_diff);
     GN_LAUNCH_CHECK();
     return GN_OK;

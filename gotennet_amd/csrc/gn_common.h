@@ -12,6 +12,14 @@
         if (e__ != hipSuccess) return (int)e__;   \
     } while (0)
 
+// non-default HTR variants (gn_options.hip), reached through gn_htr_edge / gn_htr_backward with mode != 0
+int gn_htr_edge_general(const float* EQ, const float* EK, const float* rl, const int* rowptr, const int* src,
+                        int N, int F, int lmax, int mode, float* w_raw, float* w, hipStream_t st);
+int gn_htr_backward_general(const float* g_t_out, const float* pre_t, const float* w, const float* w_raw,
+                            const float* EQ, const float* EK, const float* rl, const int* rowptr, const int* src,
+                            const int* dst, const int* colptr, const int* perm, int N, int F, int lmax, int mode,
+                            float* gEQ, float* gEK, float* g_rl, float* g_pre_t, hipStream_t st);
+
 namespace gn {
 
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }

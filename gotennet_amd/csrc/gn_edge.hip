@@ -59,16 +59,26 @@ __global__ void edge_sh_kernel(const float* __restrict__ vec, const float* __res
     cut[e] = d < cutoff ? c : 0.0f;
 }
 
-__global__ void edge_rbf_kernel(const float* __restrict__ dist, int E, int R,
-                                const float* __restrict__ means, const float* __restrict__ betas,
+// basis 0: ExpNormalSmearing (layers.py:703-746; p0 = means, p1 = betas, carries the cosine cutoff)
+// basis 1: BesselBasis (layers.py:329-358; p0 = freqs):  sin(a d) / d, with d = 0 -> divide by 1
+// basis 2: GaussianRBF (layers.py:276-326; p0 = offsets, p1 = widths):  exp(-0.5 (d - o)^2 / w^2)
+__global__ void edge_rbf_kernel(const float* __restrict__ dist, int E, int R, int basis,
+                                const float* __restrict__ p0, const float* __restrict__ p1,
                                 float cutoff, float alpha, float* __restrict__ phi) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)E * R) return;
     const int e = (int)(idx / R), r = (int)(idx % R);
-    const float d = dist[e];                      // layers.py:744-746
-    const float c = d < cutoff ? 0.5f * (cosf(d * 3.14159265358979323846f / cutoff) + 1.0f) : 0.0f;
-    const float u = expf(alpha * (-d)) - means[r];
-    phi[idx] = c * expf(-betas[r] * (u * u));
+    const float d = dist[e];
+    if (basis == 1) {
+        phi[idx] = sinf(d * p0[r]) / (d == 0.0f ? 1.0f : d);
+    } else if (basis == 2) {
+        const float w = p1[r], q = d - p0[r];
+        phi[idx] = expf((-0.5f / (w * w)) * (q * q));
+    } else {                                          // layers.py:744-746
+        const float c = d < cutoff ? 0.5f * (cosf(d * 3.14159265358979323846f / cutoff) + 1.0f) : 0.0f;
+        const float u = expf(alpha * (-d)) - p0[r];
+        phi[idx] = c * expf(-p1[r] * (u * u));
+    }
 }
 
 // ---------------------------------------------------------------------------------- K2
@@ -144,9 +154,9 @@ extern "C" int gn_out_degree(const int* src, int E, int* outdeg, void* stream) {
 }
 
 extern "C" int gn_edge_geometry(const float* edge_vec, const float* edge_diff, const int* src, const int* dst, int E,
-                                int lmax, int R, const float* means, const float* betas, float cutoff,
+                                int lmax, int R, int basis, const float* means, const float* betas, float cutoff,
                                 float* rl, float* phi, float* cut, void* stream) {
-    if (E < 0 || lmax < 1 || lmax > 4 || R <= 0) return GN_ERR_BAD_ARG;
+    if (E < 0 || lmax < 1 || lmax > 4 || R <= 0 || basis < 0 || basis > 2) return GN_ERR_BAD_ARG;
     if (E == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((E + 255) / 256), block(256);
@@ -159,7 +169,7 @@ extern "C" int gn_edge_geometry(const float* edge_vec, const float* edge_diff, c
     GN_LAUNCH_CHECK();
     const size_t tot = (size_t)E * R;
     hipLaunchKernelGGL(gn::edge_rbf_kernel, dim3((unsigned)((tot + 255) / 256)), block, 0, st,
-                       edge_diff, E, R, means, betas, cutoff, 5.0f / cutoff, phi);
+                       edge_diff, E, R, basis, means, betas, cutoff, 5.0f / cutoff, phi);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }

@@ -352,10 +352,11 @@ extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, co
 }
 
 extern "C" int gn_htr_edge(const float* EQ, const float* EK, const float* rl, const int* rowptr, const int* src,
-                           int N, int F, int lmax, float* w, void* stream) {
-    if (!feature_dim_ok(F) || N < 0 || lmax < 1 || lmax > 4) return GN_ERR_BAD_ARG;
+                           int N, int F, int lmax, int mode, float* w_raw, float* w, void* stream) {
+    if (!feature_dim_ok(F) || N < 0 || lmax < 1 || lmax > 4 || mode < 0 || mode > 15) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (mode) return gn_htr_edge_general(EQ, EK, rl, rowptr, src, N, F, lmax, mode, w_raw, w, st);
     const dim3 grid(gn::xcd_grid(N)), block(256);
     switch (lmax) {
         case 1: hipLaunchKernelGGL(gn::htr_edge_kernel<1>, grid, block, 0, st, EQ, EK, rl, rowptr, src, N, F, w); break;

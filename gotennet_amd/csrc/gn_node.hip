@@ -4,7 +4,8 @@
 namespace gn {
 
 // one wave per row; torch.nn.LayerNorm semantics (biased variance, eps inside the sqrt)
-__global__ __launch_bounds__(256) void layernorm_silu_kernel(
+template <bool SILU>
+__global__ __launch_bounds__(256) void layernorm_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     float eps, int N, int F, float* __restrict__ y) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -19,7 +20,7 @@ __global__ __launch_bounds__(256) void layernorm_silu_kernel(
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)F + eps);
     for (int f = lane; f < F; f += 64) {
         const float v = (xr[f] - mean) * rstd * gamma[f] + beta[f];
-        y[(size_t)row * F + f] = silu(v);
+        y[(size_t)row * F + f] = SILU ? silu(v) : v;
     }
 }
 
@@ -63,7 +64,17 @@ extern "C" int gn_layernorm_silu(const float* x, const float* gamma, const float
                                  int N, int F, float* y, void* stream) {
     if (N < 0 || F <= 0) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
-    hipLaunchKernelGGL(gn::layernorm_silu_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(gn::layernorm_kernel<true>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       x, gamma, beta, eps, N, F, y);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+extern "C" int gn_layernorm(const float* x, const float* gamma, const float* beta, float eps,
+                            int N, int F, float* y, void* stream) {
+    if (N < 0 || F <= 0) return GN_ERR_BAD_ARG;
+    if (N == 0) return GN_OK;
+    hipLaunchKernelGGL(gn::layernorm_kernel<false>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        x, gamma, beta, eps, N, F, y);
     GN_LAUNCH_CHECK();
     return GN_OK;

@@ -35,7 +35,9 @@ class LayerWeights:
     Wm1: torch.Tensor; bm1: torch.Tensor
     Wt: Optional[torch.Tensor] = None; bt: Optional[torch.Tensor] = None   # gamma_t
     Wvq: Optional[torch.Tensor] = None
-    Wvk: List[torch.Tensor] = field(default_factory=list)
+    Wvk: List[torch.Tensor] = field(default_factory=list)   # one per degree, or ONE shared weight (sep_htr=False)
+    ln_w: Optional[torch.Tensor] = None; ln_b: Optional[torch.Tensor] = None   # optional nn.LayerNorm on h
+    tln_w: Optional[torch.Tensor] = None                                       # optional TensorLayerNorm weight
     T: dict = field(default_factory=dict)         # lazily built transposes for the backward
 
 
@@ -45,7 +47,7 @@ class PackedWeights:
     Winit: torch.Tensor; binit: torch.Tensor      # [W_ndp; W_erp] [2F, R]
     Wa: torch.Tensor; ba: torch.Tensor; ln_w: torch.Tensor; ln_b: torch.Tensor
     Wb: torch.Tensor; bb: torch.Tensor
-    means: torch.Tensor; betas: torch.Tensor
+    rb0: torch.Tensor; rb1: torch.Tensor          # radial-basis parameter vectors (means/betas, freqs, offsets/widths)
     layers: List[LayerWeights] = field(default_factory=list)
     T: dict = field(default_factory=dict)
 
@@ -64,6 +66,10 @@ class Config:
     F: int; L: int; R: int; H: int; lmax: int; M: int
     cutoff: float; eps: float
     scale_edge: bool; sep_dir: bool; sep_tensor: bool
+    basis: int = 0            # gn_edge_geometry basis code: 0 expnorm, 1 Bessel, 2 Gaussian
+    htr_mode: int = 0         # GN_HTR_* bits (sep_htr=False, "norej", gamma_w gate)
+    layernorm: bool = False   # nn.LayerNorm on h at the GATA input (gotennet.py:397)
+    steerable_norm: bool = False   # TensorLayerNorm on X at the GATA input (gotennet.py:398)
 
     @property
     def D(self) -> int:
@@ -174,7 +180,7 @@ class Graph:
         self.phi = torch.empty((E, cfg.R), **f32)
         self.cut = torch.empty(E, **f32)
         call("gn_edge_geometry", ptr(edge_vec), ptr(edge_diff), ptr(self.src), ptr(self.dst), E,
-             cfg.lmax, cfg.R, ptr(pw.means), ptr(pw.betas), float(cfg.cutoff),
+             cfg.lmax, cfg.R, cfg.basis, ptr(pw.rb0), ptr(pw.rb1), float(cfg.cutoff),
              ptr(self.rl), ptr(self.phi), ptr(self.cut), _stream())
         self.perm = self.colptr = None
 
@@ -194,6 +200,7 @@ class LayerTape:
     nproj: torch.Tensor = None; xs: torch.Tensor = None; vs: torch.Tensor = None
     eproj: torch.Tensor = None; attn: torch.Tensor = None
     EQ: torch.Tensor = None; EK: torch.Tensor = None; w: torch.Tensor = None; pre_t: torch.Tensor = None
+    w_raw: torch.Tensor = None; h_raw: torch.Tensor = None; X_raw: torch.Tensor = None
     Xp: torch.Tensor = None; ctx: torch.Tensor = None; pre_g1: torch.Tensor = None; mm: torch.Tensor = None
 
 
@@ -242,8 +249,17 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
 
     for li, lw in enumerate(pw.layers):
         last = lw.Wt is None
+        h_raw, X_raw = h, X
+        if cfg.layernorm:                          # gotennet.py:397-398: the layer (and its residuals) see the normalised values
+            hn = new(N, F_)
+            call("gn_layernorm", ptr(h), ptr(lw.ln_w), ptr(lw.ln_b), 1e-5, N, F_, ptr(hn), _stream())
+            h = hn
+        if cfg.steerable_norm:
+            Xn = new(N, D, F_)
+            call("gn_tensor_norm", ptr(X), ptr(lw.tln_w), 1e-12, N, F_, lmax, ptr(Xn), _stream())
+            X = Xn
         if save:                                   # every layer keeps its own activations
-            lt = LayerTape(h_in=h, X_in=X, t_in=t)
+            lt = LayerTape(h_in=h, X_in=X, t_in=t, h_raw=h_raw, X_raw=X_raw)
             tape.layers.append(lt)
             h2, X2 = new(N, F_), new(N, D, F_)
             t2 = None if last else new(E, F_)
@@ -254,6 +270,7 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
                 EQ, EK, w = new(N, D, F_), new(N, D, F_), new(E, F_)
                 lt.pre_t = new(E, F_)
                 lt.EQ, lt.EK, lt.w = EQ, EK, w
+                lt.w_raw = new(E, F_) if (cfg.htr_mode >> 2) else None
             lt.nproj, lt.xs, lt.vs, lt.eproj, lt.attn = nproj, xs, vs, eproj, attn
             lt.Xp, lt.ctx, lt.pre_g1, lt.mm = Xp, ctx, pre_g1, mm
         # ---- GATA projections (gotennet.py:400-407); SiLU applied by the consumers
@@ -280,12 +297,16 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
         # ---- HTR (429-445, 561-611)
         if not last:
             gemm(X, F_, lw.Wvq, None, EQ, F_, N * D, F_, F_)
-            off = 0
-            for l in range(1, lmax + 1):
-                cnt = 2 * l + 1
-                gemm(X, F_, lw.Wvk[l - 1], None, EK, F_, N * cnt, F_, F_, rowmap=(cnt, D, off))
-                off += cnt
-            call("gn_htr_edge", ptr(EQ), ptr(EK), ptr(g.rl), ptr(g.rowptr), ptr(g.src), N, F_, lmax, ptr(w), _stream())
+            if cfg.htr_mode & 1:                   # sep_htr=False: one W_vk for every row
+                gemm(X, F_, lw.Wvk[0], None, EK, F_, N * D, F_, F_)
+            else:
+                off = 0
+                for l in range(1, lmax + 1):
+                    cnt = 2 * l + 1
+                    gemm(X, F_, lw.Wvk[l - 1], None, EK, F_, N * cnt, F_, F_, rowmap=(cnt, D, off))
+                    off += cnt
+            call("gn_htr_edge", ptr(EQ), ptr(EK), ptr(g.rl), ptr(g.rowptr), ptr(g.src), N, F_, lmax, cfg.htr_mode,
+                 ptr(lt.w_raw) if save else None, ptr(w), _stream())
             gemm(t, F_, lw.Wt, lw.bt, t2, F_, E, F_, F_, act=(0, F_), res=t, gate=w,
                  pre_out=lt.pre_t if save else None)
             t, t2 = t2, t
@@ -310,13 +331,14 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
     # every contributing kernel writes its own slice; the geometry backward sums them in a fixed order
     L = len(pw.layers)
     G = _lib.load().gn_message_backward_groups(lmax, int(cfg.sep_dir), int(cfg.sep_tensor))
-    n_rl, n_cut = 2 * L - 1, G * L + 1
+    n_rl, n_cut = L + sum(lw.Wt is not None for lw in pw.layers), G * L + 1
     g_rl_parts, g_cut_parts = new(n_rl, E, D), new(n_cut, E)
     ga_parts = new(G, E, H) if G > 1 else None
     rl_slice = lambda q: g_rl_parts.data_ptr() + 4 * q * E * D
     cut_slice = lambda q: g_cut_parts.data_ptr() + 4 * q * E
     gh = gh.contiguous()
     gX = torch.zeros((N, D, F_), **f32) if gX is None else gX.contiguous()
+    gh_caller, gX_caller = gh, gX                  # read-only: never enter the work-buffer rotation below
     gt = None                                      # dL/dt of the layer output (None = 0)
 
     gm, gXp, g_g1, g_ctx = new(N, 2 * F_), new(N, D, F_), new(N, F_), new(N, 2 * F_)
@@ -339,24 +361,27 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
         if not last:
             if gt is None:
                 raise RuntimeError("internal: missing edge gradient")
-            call("gn_htr_backward", ptr(gt), ptr(lt.pre_t), ptr(lt.w), ptr(lt.EQ), ptr(lt.EK), ptr(g.rl),
-                 ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm), N, F_, lmax,
+            call("gn_htr_backward", ptr(gt), ptr(lt.pre_t), ptr(lt.w), ptr(lt.w_raw), ptr(lt.EQ), ptr(lt.EK), ptr(g.rl),
+                 ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm), N, F_, lmax, cfg.htr_mode,
                  ptr(gEQ), ptr(gEK), rl_slice(L + li), ptr(g_pre_t), _stream())
             gemm(gEQ, F_, _T(lw, "Wvq"), None, gX1, F_, N * D, F_, F_, res=gX1)
             off = 0
             for l in range(1, lmax + 1):
-                cnt = 2 * l + 1
+                joint = bool(cfg.htr_mode & 1)
+                cnt = D if joint else 2 * l + 1
                 wkT = lw.T.get(("Wvk", l))
                 if wkT is None:
                     wkT = lw.Wvk[l - 1].t().contiguous()
                     lw.T[("Wvk", l)] = wkT
                 gemm(gEK, F_, wkT, None, gX1, F_, N * cnt, F_, F_, rowmap=(cnt, D, off), res=gX1)
                 off += cnt
+                if joint:
+                    break
             # gt_a = gt + ((gt * w) * SiLU'(pre_t)) Wt
             gemm(g_pre_t, F_, _T(lw, "Wt"), None, gt_a, F_, E, F_, F_, res=gt)
             gt_in = gt_a
         else:
-            gt_in = None
+            gt_in = gt                             # no edge update in this layer: t passes through unchanged
         # ---- message backward
         call("gn_message_backward", ptr(lt.xs), ptr(lt.vs), M * F_, ptr(lt.eproj), lde, ptr(lt.attn),
              ptr(lt.nproj), 4 * F_, ptr(lt.X_in), ptr(g.rl), ptr(g.cut), ptr(g.outdeg),
@@ -372,7 +397,18 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
         gemm(g_eproj, lde, _T(lw, "We"), None, gt_b, F_, E, F_, lde, res=gt_in)
         gh, gh2 = gh2, gh
         gX, gX2 = gX2, gX
+        if gh2 is gh_caller:
+            gh2 = new(N, F_)
+        if gX2 is gX_caller:
+            gX2 = new(N, D, F_)
         gt, gt_b = gt_b, (gt if gt is not None else new(E, F_))
+        # ---- optional input norms (gotennet.py:397-398): back to the un-normalised h / X
+        if cfg.layernorm:
+            call("gn_layernorm_backward", ptr(lt.h_raw), ptr(lw.ln_w), 1e-5, ptr(gh), N, F_, ptr(gh2), _stream())
+            gh, gh2 = gh2, gh
+        if cfg.steerable_norm:
+            call("gn_tensor_norm_backward", ptr(lt.X_raw), ptr(lw.tln_w), ptr(gX), 1e-12, N, F_, lmax, ptr(gX2), _stream())
+            gX, gX2 = gX2, gX
 
     # ---- init backward (layers.py:1658-1714) ------------------------------------------
     g_feat = new(E, 2 * F_)
@@ -389,7 +425,7 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
     gemm(g_feat, 2 * F_, _T(pw, "Winit"), None, g_phi, R, E, R, 2 * F_)
     g_vec, g_diff = new(E, 3), new(E)
     call("gn_edge_geometry_backward", ptr(g.edge_vec), ptr(g.edge_diff), ptr(g.src), ptr(g.dst), E, lmax, R,
-         ptr(pw.means), ptr(pw.betas), float(cfg.cutoff), ptr(g_rl_parts), n_rl, ptr(g_cut_parts), n_cut,
+         cfg.basis, ptr(pw.rb0), ptr(pw.rb1), float(cfg.cutoff), ptr(g_rl_parts), n_rl, ptr(g_cut_parts), n_cut,
          ptr(g_phi), ptr(g_vec), ptr(g_diff), _stream())
     return g_vec, g_diff
 

@@ -19,7 +19,7 @@ from torch import Tensor
 
 from . import engine
 from ._lib import GotenNetHipError
-from .layers import (MLP, CosineCutoff, Dense, EdgeInit, NodeInit, get_weight_init_by_string,
+from .layers import (BASIS_CODE, MLP, CosineCutoff, Dense, EdgeInit, NodeInit, get_weight_init_by_string,
                      resolve_activation, str2basis)
 
 
@@ -75,21 +75,28 @@ class GATA(nn.Module):
                  evec_dim: Optional[int] = None, emlp_dim: Optional[int] = None, sep_htr: bool = True,
                  sep_dir: bool = True, sep_tensor: bool = True, lmax: int = 2, edge_ln: str = ""):
         super().__init__()
-        if isinstance(edge_updates, str):
-            allowed = ["gated", "gatedt", "norej", "norm", "mlp", "mlpa", "act", "linw", "linwa", "ln", "postln"]
-            if not all(p in allowed for p in edge_updates.split("_")):
-                raise ValueError(f"Invalid edge update parts. Allowed parts are {allowed}")
-            raise NotImplementedError("string edge_updates variants are not on the accelerated path (only True)")
+        # gotennet.py:139-190: '_'-separated variants of the edge update
+        self.update_info = info = {"gated": False, "rej": True, "mlp": False, "mlpa": False, "lin_w": 0, "lin_ln": 0}
+        parts = edge_updates.split("_") if isinstance(edge_updates, str) else []
+        allowed = ["gated", "gatedt", "norej", "norm", "mlp", "mlpa", "act", "linw", "linwa", "ln", "postln"]
+        if not all(p in allowed for p in parts):
+            raise ValueError(f"Invalid edge update parts. Allowed parts are {allowed}")
+        for p in ("mlp", "mlpa", "linw", "linwa", "ln", "postln"):
+            if p in parts:
+                raise NotImplementedError(f"edge_updates part {p!r} is not on the accelerated path "
+                                          "(gated, gatedt, act, norej, norm are)")
+        for p in ("gated", "gatedt", "act"):
+            if p in parts:
+                info["gated"] = p
+        if "norej" in parts:
+            info["rej"] = False
         if aggr != "add":
             raise NotImplementedError("aggr must be 'add'")
-        if layer_norm or steerable_norm or edge_ln:
-            raise NotImplementedError("layernorm / steerable_norm / edge_ln are not on the accelerated path yet")
-        if not sep_htr:
-            raise NotImplementedError("sep_htr=False is not on the accelerated path yet")
+        if edge_ln:
+            raise NotImplementedError("edge_ln is not on the accelerated path")
         if evec_dim not in (None, n_atom_basis) or emlp_dim not in (None, n_atom_basis):
             raise NotImplementedError("evec_dim / emlp_dim must equal n_atom_basis")
-        if not edge_updates:
-            raise NotImplementedError("edge_updates=False is not on the accelerated path yet")
+        self.layernorm_, self.steerable_norm_ = layer_norm, steerable_norm
         self.n_atom_basis, self.lmax, self.num_heads = n_atom_basis, lmax, num_heads
         self.last_layer, self.edge_updates, self.scale_edge = last_layer, edge_updates, scale_edge
         self.sep_htr, self.sep_dir, self.sep_tensor = sep_htr, sep_dir, sep_tensor
@@ -108,15 +115,42 @@ class GATA(nn.Module):
             self.gamma_t = MLP([n_atom_basis, n_atom_basis], activation=activation, last_activation=activation,
                                weight_init=weight_init, bias_init=bias_init, norm=edge_ln)
             self.W_vq = D_(n_atom_basis, n_atom_basis, activation=None, bias=False)
-            self.W_vk = nn.ModuleList([D_(n_atom_basis, n_atom_basis, activation=None, bias=False)
-                                       for _ in range(lmax)])
-            self.gamma_w = nn.Sequential()
+            if sep_htr:
+                self.W_vk = nn.ModuleList([D_(n_atom_basis, n_atom_basis, activation=None, bias=False)
+                                           for _ in range(lmax)])
+            else:
+                self.W_vk = D_(n_atom_basis, n_atom_basis, activation=None, bias=False)
+            self.gamma_w = nn.Sequential()            # parameter-free (Sigmoid / Tanh / SiLU): applied by gn_htr_edge
         self.W_rs = D_(n_atom_basis, n_atom_basis * multiplier, activation=None)
+        # gotennet.py:305-315
+        self.layernorm = nn.LayerNorm(n_atom_basis) if layer_norm != "" else nn.Identity()
+        self.tensor_layernorm = TensorLayerNorm(n_atom_basis, trainable=False, lmax=lmax) if steerable_norm != "" \
+            else nn.Identity()
+
+    @property
+    def htr_mode(self) -> int:
+        """``mode`` argument of gn_htr_edge / gn_htr_backward (include/gotennet_hip.h)."""
+        gate = {False: 0, "gated": 1, "gatedt": 2, "act": 3}[self.update_info["gated"]]
+        return (0 if self.sep_htr else 1) | (0 if self.update_info["rej"] else 2) | (gate << 2)
 
     def reset_parameters(self):
         for m in self.modules():
-            if isinstance(m, Dense):
+            if isinstance(m, (Dense, nn.LayerNorm, TensorLayerNorm)):
                 m.reset_parameters()
+
+
+class TensorLayerNorm(nn.Module):
+    """Buffer container for the reference TensorLayerNorm (layers.py:1497-1527); gn_tensor_norm computes it."""
+
+    def __init__(self, hidden_channels, trainable, lmax=1, **kwargs):
+        super().__init__()
+        if trainable:
+            raise NotImplementedError("trainable TensorLayerNorm")
+        self.hidden_channels, self.eps, self.lmax = hidden_channels, 1e-12, lmax
+        self.register_buffer("weight", torch.ones(hidden_channels))
+
+    def reset_parameters(self):
+        self.weight.data.fill_(1.0)
 
 
 class EQFF(nn.Module):
@@ -237,7 +271,8 @@ class GotenNet(nn.Module):
         return engine.Config(F=self.n_atom_basis, L=self.n_interactions, R=self.n_rbf, H=self.num_heads,
                              lmax=self.lmax, M=g0.multiplier, cutoff=float(self.cutoff), eps=float(self.epsilon),
                              scale_edge=bool(self.scale_edge), sep_dir=bool(self.sep_dir),
-                             sep_tensor=bool(self.sep_tensor))
+                             sep_tensor=bool(self.sep_tensor), basis=BASIS_CODE[type(self.radial_basis)][0],
+                             htr_mode=g0.htr_mode, layernorm=bool(g0.layernorm_), steerable_norm=bool(g0.steerable_norm_))
 
     def packed_weights(self) -> engine.PackedWeights:
         """Concatenate the projections that share an input into single GEMM operands
@@ -256,7 +291,8 @@ class GotenNet(nn.Module):
             binit=c(ni.W_ndp.dense_layers[0].bias, ei.W_erp.bias),
             Wa=d(mlp[0].weight), ba=d(mlp[0].bias), ln_w=d(mlp[0].norm.weight), ln_b=d(mlp[0].norm.bias),
             Wb=d(mlp[1].weight), bb=d(mlp[1].bias),
-            means=d(self.radial_basis.means), betas=d(self.radial_basis.betas))
+            rb0=d(getattr(self.radial_basis, BASIS_CODE[type(self.radial_basis)][1]).float()),
+            rb1=d(getattr(self.radial_basis, BASIS_CODE[type(self.radial_basis)][2]).float()))
         for gata, eq in zip(self.gata_list, self.eqff_list):
             lw = engine.LayerWeights(
                 Wn1=c(gata.W_q.weight, gata.W_k.weight, gata.gamma_s[0].weight, gata.gamma_v[0].weight),
@@ -267,10 +303,14 @@ class GotenNet(nn.Module):
                 Wvu=d(eq.W_vu.weight),
                 Wm0=d(eq.gamma_m[0].weight), bm0=d(eq.gamma_m[0].bias),
                 Wm1=d(eq.gamma_m[1].weight), bm1=d(eq.gamma_m[1].bias))
-            if not gata.last_layer:
+            if not gata.last_layer and gata.edge_updates:
                 lw.Wt, lw.bt = d(gata.gamma_t.dense_layers[0].weight), d(gata.gamma_t.dense_layers[0].bias)
                 lw.Wvq = d(gata.W_vq.weight)
-                lw.Wvk = [d(wk.weight) for wk in gata.W_vk]
+                lw.Wvk = [d(wk.weight) for wk in gata.W_vk] if gata.sep_htr else [d(gata.W_vk.weight)]
+            if gata.layernorm_:
+                lw.ln_w, lw.ln_b = d(gata.layernorm.weight), d(gata.layernorm.bias)
+            if gata.steerable_norm_:
+                lw.tln_w = d(gata.tensor_layernorm.weight)
             pw.layers.append(lw)
         self._packed, self._packed_key = pw, key
         return pw

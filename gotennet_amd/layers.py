@@ -117,13 +117,50 @@ class ExpNormalSmearing(nn.Module):
         self.betas.data.copy_(betas)
 
 
+class GaussianRBF(nn.Module):
+    """Buffers ``widths``/``offsets`` as in reference layers.py:294-326 (evaluated by gn_edge_geometry, basis 2)."""
+
+    def __init__(self, n_rbf: int, cutoff: float, start: float = 0.0, trainable: bool = False):
+        super().__init__()
+        if trainable:
+            raise NotImplementedError("trainable radial basis")
+        self.n_rbf = n_rbf
+        offset = torch.linspace(start, cutoff, n_rbf)
+        widths = torch.abs(offset[1] - offset[0]) * torch.ones_like(offset)
+        self.register_buffer("widths", widths)
+        self.register_buffer("offsets", offset)
+
+
+class BesselBasis(nn.Module):
+    """Buffers ``freqs``/``norm1`` as in reference layers.py:329-347 (evaluated by gn_edge_geometry, basis 1)."""
+
+    def __init__(self, cutoff=5.0, n_rbf=None, trainable=False):
+        super().__init__()
+        if n_rbf is None:
+            raise ValueError("n_rbf must be specified for BesselBasis")
+        self.n_rbf = n_rbf
+        freqs = torch.arange(1, n_rbf + 1) * math.pi / cutoff
+        self.register_buffer("freqs", freqs)
+        self.register_buffer("norm1", torch.tensor(1.0))
+
+
+#: gn_edge_geometry `basis` code and the two parameter vectors it reads, per radial-basis class
+BASIS_CODE = {ExpNormalSmearing: (0, "means", "betas"), BesselBasis: (1, "freqs", "freqs"),
+              GaussianRBF: (2, "offsets", "widths")}
+
+
 def str2basis(basis: Union[str, Callable]):
+    """Reference layers.py:749-776 (same spellings accepted)."""
     if not isinstance(basis, str):
+        if basis not in BASIS_CODE:
+            raise NotImplementedError(f"radial basis {basis!r} has no HIP kernel (expnorm, BesselBasis, GaussianRBF do)")
         return basis
+    if basis.lower().replace("-", "").replace("_", "").replace(" ", "") == "besselbasis":
+        return BesselBasis
+    if basis == "GaussianRBF":
+        return GaussianRBF
     if basis.lower() == "expnorm":
         return ExpNormalSmearing
-    if basis.lower().replace("_", "") in ("besselbasis", "gaussianrbf"):
-        raise NotImplementedError(f"radial basis {basis!r}: only 'expnorm' is on the accelerated path")
     raise ValueError("Unknown radial basis: {}".format(basis))
 
 

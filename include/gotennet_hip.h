@@ -56,7 +56,7 @@ int gn_out_degree(const int* src, int E, int* outdeg, void* stream);
  * (layers.py:805-902), ExpNormalSmearing (layers.py:744-746), CosineCutoff (layers.py:149-152).
  * rl [E,D], phi [E,R], cut [E]. edge_vec is NOT modified. */
 int gn_edge_geometry(const float* edge_vec, const float* edge_diff, const int* src, const int* dst, int E,
-                     int lmax, int R, const float* means, const float* betas, float cutoff,
+                     int lmax, int R, int basis, const float* means, const float* betas, float cutoff,
                      float* rl, float* phi, float* cut, void* stream);
 
 /* ---- K2/K3 initialisation ------------------------------------------------------------ */
@@ -78,6 +78,15 @@ int gn_edge_init(const float* h, const int* rowptr, const int* src, const float*
  * layers.py:518-529, inside NodeInit's W_nrd_nru).  In place allowed (y == x). */
 int gn_layernorm_silu(const float* x, const float* gamma, const float* beta, float eps,
                       int N, int F, float* y, void* stream);
+
+/* ---- optional GATA input norms (gotennet.py:305-315, 397-398; off by default) ----------- */
+/* y = LayerNorm(x) * gamma + beta (nn.LayerNorm(F), `layernorm != ""`). */
+int gn_layernorm(const float* x, const float* gamma, const float* beta, float eps,
+                 int N, int F, float* y, void* stream);
+/* TensorLayerNorm (layers.py:1497-1563, `steerable_norm != ""`): per atom and degree block l,
+ * s_f = |X_l[:, f]|, c_f = max(s_f, eps), n_f = (c_f - min_f c) / (max_f c - min_f c) (denominator 1 if equal),
+ * Y = relu(n_f) * X / c_f * weight_f.  X, Y are [N,D,F]; eps = 1e-12 in the reference. */
+int gn_tensor_norm(const float* X, const float* weight, float eps, int N, int F, int lmax, float* Y, void* stream);
 
 /* ---- dense projections (K4/K5/K7/K8), fp32 MFMA --------------------------------------- */
 /* C[r, n] = epi( sum_k A[r, k] * W[n, k] + bias[n] )      (nn.Linear layout W[out,in]; Dense, layers.py:457-529)
@@ -143,8 +152,19 @@ int gn_message_aggregate(const float* x, const float* v, int ldxv, const float* 
 /* ---- K7 HTR edge weights -------------------------------------------------------------- */
 /* w[e,f] = sum_l sum_m P(EQ[i])_m * P(EK[j])_m with P(a) = a - (a . rl_l) rl_l per degree block
  * (gotennet.py:351-364, 580-609; sep_htr=True, rejection on).  EQ, EK are [N,D,F]; w is [E,F]. */
+/* `mode` selects the reference's non-default edge-update variants (gotennet.py:139-190, 285-291, 580-599):
+ *   GN_HTR_JOINT  sep_htr=False: one rejection block over all D rows instead of one per degree;
+ *   GN_HTR_NOREJ  "norej": no vector rejection;
+ *   GN_HTR_GATE_* gamma_w applied to w: "gated" sigmoid, "gatedt" tanh, "act" SiLU.
+ * mode = 0 is the default path.  w_raw (optional, may be NULL) receives w before the gate (the backward needs it
+ * when a gate is set). */
+#define GN_HTR_JOINT 1
+#define GN_HTR_NOREJ 2
+#define GN_HTR_GATE_SIGMOID (1 << 2)
+#define GN_HTR_GATE_TANH (2 << 2)
+#define GN_HTR_GATE_SILU (3 << 2)
 int gn_htr_edge(const float* EQ, const float* EK, const float* rl, const int* rowptr, const int* src,
-                int N, int F, int lmax, float* w, void* stream);
+                int N, int F, int lmax, int mode, float* w_raw, float* w, void* stream);
 
 /* ---- K8 EQFF node-local pieces -------------------------------------------------------- */
 /* ctx[n, 0:F] = h[n]; ctx[n, F:2F] = sqrt(sum_m Xp[n,m,:]^2 + eps)   (gotennet.py:731-735) */
@@ -159,9 +179,10 @@ int gn_eqff_update(const float* m, const float* Xp, int N, int F, int D, float* 
 
 /* HTR (gotennet.py:561-611) backward: g_t_out = dL/dt' [E,F], pre_t = W_t t + b and w (saved), w.r.t. EQ, EK,
  * rl, and g_pre_t = g_t_out * w * SiLU'(pre_t) [E,F] (the operand of the W_t^T product). */
-int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* w, const float* EQ, const float* EK,
+int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* w, const float* w_raw,
+                    const float* EQ, const float* EK,
                     const float* rl, const int* rowptr, const int* src, const int* dst,
-                    const int* colptr, const int* perm, int N, int F, int lmax,
+                    const int* colptr, const int* perm, int N, int F, int lmax, int mode,
                     float* gEQ, float* gEK, float* g_rl, float* g_pre_t, void* stream);
 
 /* GATA message/softmax/aggregate (gotennet.py:452-559, 613-640) backward.  Inputs: saved x, v [N,MF];
@@ -199,12 +220,18 @@ int gn_node_init_backward(const float* g_ctx, const int* z, const float* feat, i
                           float* g_feat, float* g_cut, void* stream);
 int gn_layernorm_silu_backward(const float* x, const float* gamma, const float* beta, float eps,
                                const float* g_out, int N, int F, float* g_x, void* stream);
+/* input-gradients of gn_layernorm / gn_tensor_norm (x / X are the un-normalised inputs).  torch.max / torch.min
+ * route their gradient to one channel: the first extremal one. */
+int gn_layernorm_backward(const float* x, const float* gamma, float eps,
+                          const float* g_out, int N, int F, float* g_x, void* stream);
+int gn_tensor_norm_backward(const float* X, const float* weight, const float* g_Y, float eps, int N, int F,
+                            int lmax, float* g_X, void* stream);
 
 /* Edge geometry (K1) backward: (sum of the n_rl slices g_rl [n_rl,E,D], sum of the n_cut slices g_cut [n_cut,E],
  * g_phi [E,R]) -> g_vec [E,3] through the unit vector and harmonics, g_diff [E] through cutoff and radial
  * basis.  Self-loops get zeros. */
 int gn_edge_geometry_backward(const float* edge_vec, const float* edge_diff, const int* src, const int* dst,
-                              int E, int lmax, int R, const float* means, const float* betas, float cutoff,
+                              int E, int lmax, int R, int basis, const float* means, const float* betas, float cutoff,
                               const float* g_rl, int n_rl, const float* g_cut, int n_cut, const float* g_phi,
                               float* g_vec, float* g_diff, void* stream);
 /* out[n] = sign * ( sum_{src(e)=n} gv_e - sum_{dst(e)=n} gv_e ), gv = g_vec + g_diff * edge_vec/|edge_vec|

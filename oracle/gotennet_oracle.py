@@ -39,9 +39,32 @@ def default_config(**kw) -> dict:
         n_atom_basis=128, n_interactions=8, n_rbf=32, cutoff=5.0, max_z=100,
         epsilon=1e-8, num_heads=8, scale_edge=True, lmax=1,
         sep_htr=True, sep_dir=False, sep_tensor=False,
+        radial_basis="expnorm", edge_updates=True, layernorm="", steerable_norm="",
     )
     cfg.update(kw)
     return cfg
+
+
+def edge_update_info(edge_updates) -> dict:
+    """gotennet.py:139-190: the '_'-separated string form of ``edge_updates``.  Only the parts the HIP path
+    carries are restated: rejection on/off and the element-wise gate on w_ij."""
+    info = dict(enabled=bool(edge_updates), rej=True, gate="")
+    parts = edge_updates.split("_") if isinstance(edge_updates, str) else []
+    allowed = ["gated", "gatedt", "norej", "norm", "mlp", "mlpa", "act", "linw", "linwa", "ln", "postln"]
+    if not all(part in allowed for part in parts):
+        raise ValueError(f"Invalid edge update parts. Allowed parts are {allowed}")
+    for part in ("mlp", "mlpa", "linw", "linwa", "ln", "postln"):
+        if part in parts:
+            raise NotImplementedError(f"edge_updates part {part!r} is not restated")
+    if "gated" in parts:
+        info["gate"] = "sigmoid"
+    if "gatedt" in parts:
+        info["gate"] = "tanh"
+    if "act" in parts:
+        info["gate"] = "silu"
+    if "norej" in parts:
+        info["rej"] = False
+    return info
 
 
 def multiplier(cfg: dict) -> int:
@@ -79,6 +102,32 @@ def expnorm_smearing(d: Tensor, means: Tensor, betas: Tensor, cutoff: float) -> 
     alpha = 5.0 / cutoff
     d = d.unsqueeze(-1)
     return cosine_cutoff(d, cutoff) * torch.exp(-betas * (torch.exp(alpha * (-d)) - means) ** 2)
+
+
+def bessel_basis(d: Tensor, freqs: Tensor) -> Tensor:
+    """layers.py:349-358 (BesselBasis.forward): sin(a d) / d, d = 0 divides by 1."""
+    d = d.unsqueeze(-1)
+    return torch.sin(d * freqs) / torch.where(d == 0, torch.ones_like(d), d)
+
+
+def gaussian_rbf(d: Tensor, offsets: Tensor, widths: Tensor) -> Tensor:
+    """layers.py:276-291 as called by GaussianRBF.forward (325-326) on a 1-D distance vector."""
+    coeff = -0.5 / torch.pow(widths, 2)
+    return torch.exp(coeff * torch.pow(d.unsqueeze(-1) - offsets, 2))
+
+
+def radial_basis(sd: Dict[str, Tensor], cfg: dict, d: Tensor) -> Tensor:
+    """str2basis (layers.py:749-776) + the selected module's forward; buffers come from the state_dict."""
+    name = cfg.get("radial_basis", "expnorm")
+    norm = name.lower().replace("-", "").replace("_", "").replace(" ", "")
+    kind = "bessel" if norm == "besselbasis" else "gaussian" if name == "GaussianRBF" else norm
+    if kind == "expnorm":
+        return expnorm_smearing(d, sd["radial_basis.means"], sd["radial_basis.betas"], cfg["cutoff"])
+    if kind == "bessel":
+        return bessel_basis(d, sd["radial_basis.freqs"])
+    if kind == "gaussian":
+        return gaussian_rbf(d, sd["radial_basis.offsets"], sd["radial_basis.widths"])
+    raise ValueError(f"Unknown radial basis: {kind}")
 
 
 def real_harmonics(lmax: int, u: Tensor) -> Tensor:
@@ -179,6 +228,32 @@ def _mlp2(x, sd, key):
     return linear(F.silu(linear(x, sd, key + ".0")), sd, key + ".1")
 
 
+def tensor_layernorm(X: Tensor, lmax: int, weight: Tensor, eps: float = 1e-12) -> Tensor:
+    """layers.py:1529-1563 (TensorLayerNorm, max-min norm per degree block).  The reference's early
+    ``(dist == 0).all() -> zeros`` return equals the formula below (0 / eps * relu(0) = 0)."""
+    outs = []
+    for part in torch.split(X, degree_sizes(lmax), dim=1):
+        dist = torch.norm(part, dim=1, keepdim=True).clamp(min=eps)
+        direct = part / dist
+        max_val, _ = torch.max(dist, dim=-1)
+        min_val, _ = torch.min(dist, dim=-1)
+        delta = (max_val - min_val).view(-1)
+        delta = torch.where(delta == 0, torch.ones_like(delta), delta)
+        dist = (dist - min_val.view(-1, 1, 1)) / delta.view(-1, 1, 1)
+        outs.append(F.relu(dist) * direct)
+    return torch.cat(outs, dim=1) * weight.unsqueeze(0).unsqueeze(0)
+
+
+def gata_input_norms(sd, cfg, p, h, X):
+    """gotennet.py:397-398: optional nn.LayerNorm on h and TensorLayerNorm on X; the residuals at 426-427
+    then add to the NORMALISED values."""
+    if cfg.get("layernorm", ""):
+        h = F.layer_norm(h, (h.shape[-1],), sd[p + "layernorm.weight"], sd[p + "layernorm.bias"], 1e-5)
+    if cfg.get("steerable_norm", ""):
+        X = tensor_layernorm(X, cfg["lmax"], sd[p + "tensor_layernorm.weight"])
+    return h, X
+
+
 def gata_message_aggregate(sd, cfg, p, edge_index, h, X, rl, t, r, n_edges):
     """gotennet.py:400-427 + message 452-559 + aggregate 613-640.
 
@@ -235,23 +310,37 @@ def _rejection(rep: Tensor, rl: Tensor) -> Tensor:
 
 
 def gata_htr(sd, cfg, p, edge_index, X, rl, t):
-    """gotennet.py:429-445 + edge_update 561-611 (sep_htr=True, edge_updates=True:
-    rejection on, gamma_w = identity, gamma_t = SiLU(Dense))."""
+    """gotennet.py:429-445 + edge_update 561-611: gamma_t = SiLU(Dense); rejection on/off, per-degree or joint
+    (sep_htr), gamma_w = identity | sigmoid | tanh | SiLU (gotennet.py:285-291)."""
     lmax = cfg["lmax"]
+    info = edge_update_info(cfg.get("edge_updates", True))
     sizes = degree_sizes(lmax)
     j, i = edge_index[0], edge_index[1]
     EQ = F.linear(X, sd[p + "W_vq.weight"])
-    X_split = torch.split(X, sizes, dim=1)
-    EK = torch.cat([F.linear(X_split[a], sd[p + f"W_vk.{a}.weight"]) for a in range(lmax)], dim=1)
-    EQ_i = torch.split(EQ.index_select(0, i), sizes, dim=1)
-    EK_j = torch.split(EK.index_select(0, j), sizes, dim=1)
-    rl_s = torch.split(rl, sizes, dim=1)
+    if cfg["sep_htr"]:
+        X_split = torch.split(X, sizes, dim=1)
+        EK = torch.cat([F.linear(X_split[a], sd[p + f"W_vk.{a}.weight"]) for a in range(lmax)], dim=1)
+        blocks = sizes
+    else:
+        EK = F.linear(X, sd[p + "W_vk.weight"])
+        blocks = [sum(sizes)]
+    EQ_i = torch.split(EQ.index_select(0, i), blocks, dim=1)
+    EK_j = torch.split(EK.index_select(0, j), blocks, dim=1)
+    rl_s = torch.split(rl, blocks, dim=1)
     w = None
-    for a in range(lmax):
-        eq = _rejection(EQ_i[a], rl_s[a])
-        ek = _rejection(EK_j[a], -rl_s[a])
+    for a in range(len(blocks)):
+        eq, ek = EQ_i[a], EK_j[a]
+        if info["rej"]:
+            eq = _rejection(eq, rl_s[a])
+            ek = _rejection(ek, -rl_s[a])
         wl = (eq * ek).sum(dim=1)
         w = wl if w is None else w + wl
+    if info["gate"] == "sigmoid":
+        w = torch.sigmoid(w)
+    elif info["gate"] == "tanh":
+        w = torch.tanh(w)
+    elif info["gate"] == "silu":
+        w = F.silu(w)
     return t + F.silu(linear(t, sd, p + "gamma_t.dense_layers.0")) * w
 
 
@@ -274,7 +363,7 @@ def gotennet_forward(sd: Dict[str, Tensor], cfg: dict, z: Tensor, edge_index: Te
     Fd, L, lmax = cfg["n_atom_basis"], cfg["n_interactions"], cfg["lmax"]
     dt = sd["A_na.weight"].dtype
     h = sd["A_na.weight"][z]
-    phi = expnorm_smearing(edge_diff, sd["radial_basis.means"], sd["radial_basis.betas"], cfg["cutoff"])
+    phi = radial_basis(sd, cfg, edge_diff)
     h = node_init(sd, cfg, z, h, edge_index, edge_diff, phi)
     t = edge_init(sd, edge_index, phi, h)
     mask = (edge_index[0] != edge_index[1]).unsqueeze(1)
@@ -289,8 +378,9 @@ def gotennet_forward(sd: Dict[str, Tensor], cfg: dict, z: Tensor, edge_index: Te
     trace = []
     for li in range(L):
         p = f"gata_list.{li}."
+        h, X = gata_input_norms(sd, cfg, p, h, X)
         h, X = gata_message_aggregate(sd, cfg, p, edge_index, h, X, rl, t, edge_diff, n_edges)
-        if li != L - 1:
+        if li != L - 1 and cfg.get("edge_updates", True):
             t = gata_htr(sd, cfg, p, edge_index, X, rl, t)
         h, X = eqff(sd, cfg, f"eqff_list.{li}.", h, X)
         if return_trace:

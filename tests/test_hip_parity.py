@@ -15,7 +15,11 @@ def _net_from_case(cfg, sd):
     net = gotennet_amd.GotenNet(
         n_atom_basis=cfg["n_atom_basis"], n_interactions=cfg["n_interactions"], n_rbf=cfg["n_rbf"],
         cutoff_fn=gotennet_amd.CosineCutoff(cfg["cutoff"]), max_z=cfg["max_z"], num_heads=cfg["num_heads"],
-        scale_edge=cfg["scale_edge"], lmax=cfg["lmax"], sep_dir=cfg["sep_dir"], sep_tensor=cfg["sep_tensor"])
+        scale_edge=cfg["scale_edge"], lmax=cfg["lmax"], sep_dir=cfg["sep_dir"], sep_tensor=cfg["sep_tensor"],
+        # non-default flags carried by the opt_* fixtures
+        sep_htr=cfg.get("sep_htr", True), radial_basis=cfg.get("radial_basis", "expnorm"),
+        edge_updates=cfg.get("edge_updates", True), layernorm=cfg.get("layernorm", ""),
+        steerable_norm=cfg.get("steerable_norm", ""))
     net.load_state_dict(sd, strict=True)
     return net.cuda().eval()
 
@@ -91,7 +95,11 @@ def test_wrapper_matches_golden():
     net = gotennet_amd.GotenNetWrapper(
         n_atom_basis=cfg["n_atom_basis"], n_interactions=cfg["n_interactions"], n_rbf=cfg["n_rbf"],
         cutoff_fn=gotennet_amd.CosineCutoff(cfg["cutoff"]), max_z=cfg["max_z"], num_heads=cfg["num_heads"],
-        scale_edge=cfg["scale_edge"], lmax=cfg["lmax"], sep_dir=cfg["sep_dir"], sep_tensor=cfg["sep_tensor"])
+        scale_edge=cfg["scale_edge"], lmax=cfg["lmax"], sep_dir=cfg["sep_dir"], sep_tensor=cfg["sep_tensor"],
+        # non-default flags carried by the opt_* fixtures
+        sep_htr=cfg.get("sep_htr", True), radial_basis=cfg.get("radial_basis", "expnorm"),
+        edge_updates=cfg.get("edge_updates", True), layernorm=cfg.get("layernorm", ""),
+        steerable_norm=cfg.get("steerable_norm", ""))
     net.load_state_dict(sd, strict=True)
     net = net.cuda().eval()
     inp = types.SimpleNamespace(z=t["z"].cuda(), pos=t["pos"].cuda(), batch=t["batch"].cuda())

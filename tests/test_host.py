@@ -34,8 +34,11 @@ def test_state_dict_layout_matches_golden_checkpoint():
         net = gotennet_amd.GotenNet(
             n_atom_basis=cfg["n_atom_basis"], n_interactions=cfg["n_interactions"], n_rbf=cfg["n_rbf"],
             cutoff_fn=gotennet_amd.CosineCutoff(cfg["cutoff"]), max_z=cfg["max_z"], num_heads=cfg["num_heads"],
-            scale_edge=cfg["scale_edge"], lmax=cfg["lmax"], sep_dir=cfg["sep_dir"], sep_tensor=cfg["sep_tensor"])
-        assert list(net.state_dict().keys()) == list(sd.keys())
+            scale_edge=cfg["scale_edge"], lmax=cfg["lmax"], sep_dir=cfg["sep_dir"], sep_tensor=cfg["sep_tensor"],
+            sep_htr=cfg.get("sep_htr", True), radial_basis=cfg.get("radial_basis", "expnorm"),
+            edge_updates=cfg.get("edge_updates", True), layernorm=cfg.get("layernorm", ""),
+            steerable_norm=cfg.get("steerable_norm", ""))
+        assert sorted(net.state_dict().keys()) == sorted(sd.keys()), name
         net.load_state_dict(sd, strict=True)
         assert net.hidden_dim == cfg["n_atom_basis"] and net.cutoff == cfg["cutoff"]
 
@@ -57,7 +60,9 @@ def test_unsupported_flags_raise_before_launch():
     with pytest.raises(NotImplementedError):
         gotennet_amd.GotenNet(cutoff_fn=cut, lmax=5)
     with pytest.raises(NotImplementedError):
-        gotennet_amd.GotenNet(cutoff_fn=cut, layernorm="layer")
+        gotennet_amd.GotenNet(cutoff_fn=cut, edge_ln="layer")
+    with pytest.raises(NotImplementedError):
+        gotennet_amd.GotenNet(cutoff_fn=cut, edge_updates="gated_mlp")
     with pytest.raises(ValueError):
         gotennet_amd.GotenNet(cutoff_fn=cut, edge_updates="bogus")
     with pytest.raises(ValueError):

@@ -50,6 +50,29 @@ CASES = {
     "l2_sep_shuffled_noloop": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=2, num_heads=8,
                                     scale_edge=False, sep_dir=True, sep_tensor=True, max_z=10),
                                dict(mols=[6, 5], box=3.0, seed=6, shuffle=True, loop=False)),
+    # ---- non-default flags --------------------------------------------------------
+    "opt_bessel_norej": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=2, num_heads=8, scale_edge=False,
+                              sep_dir=True, sep_tensor=True, max_z=10, radial_basis="BesselBasis",
+                              edge_updates="norej"), dict(mols=[6, 5], box=3.0, seed=11)),
+    "opt_gauss_jointhtr_gated": (dict(n_atom_basis=32, n_interactions=3, n_rbf=8, lmax=2, num_heads=8,
+                                      scale_edge=True, sep_dir=True, sep_tensor=True, max_z=10,
+                                      radial_basis="GaussianRBF", sep_htr=False, edge_updates="gated"),
+                                 dict(mols=[6, 4], box=3.0, seed=12)),
+    "opt_jointhtr_l3_tanh": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=3, num_heads=8, scale_edge=False,
+                                  sep_dir=True, sep_tensor=True, max_z=10, sep_htr=False, edge_updates="gatedt_norm"),
+                             dict(mols=[5, 4], box=2.8, seed=13)),
+    "opt_noupd_act": (dict(n_atom_basis=32, n_interactions=3, n_rbf=8, lmax=1, num_heads=4, scale_edge=True,
+                           sep_dir=False, sep_tensor=False, max_z=10, edge_updates=False),
+                      dict(mols=[6, 5], box=3.0, seed=14)),
+    "opt_act_norej_joint": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=2, num_heads=8, scale_edge=False,
+                                 sep_dir=False, sep_tensor=True, max_z=10, sep_htr=False, edge_updates="act_norej"),
+                            dict(mols=[7, 3], box=3.0, seed=15)),
+    "opt_layernorm_tln": (dict(n_atom_basis=32, n_interactions=3, n_rbf=8, lmax=2, num_heads=8, scale_edge=False,
+                               sep_dir=True, sep_tensor=True, max_z=10, layernorm="layer", steerable_norm="tensor"),
+                          dict(mols=[6, 5], box=3.0, seed=16)),
+    "opt_tln_l4": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=4, num_heads=8, scale_edge=True,
+                        sep_dir=True, sep_tensor=True, max_z=10, steerable_norm="tensor"),
+                   dict(mols=[5], box=2.6, seed=17)),
 }
 
 CUTOFF = 5.0
@@ -69,7 +92,7 @@ def randomise(module, seed):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for name, p in module.named_parameters():
-            if name.endswith("norm.weight"):
+            if name.endswith("norm.weight") and "tensor_layernorm" not in name:
                 p.copy_(1.0 + 0.2 * (torch.rand(p.shape, generator=g) - 0.5))
             elif p.dim() == 1:  # biases
                 p.copy_(0.1 * (torch.rand(p.shape, generator=g) - 0.5))
@@ -81,6 +104,9 @@ def randomise(module, seed):
                 fan_out, fan_in = p.shape
                 a = (6.0 / (fan_in + fan_out)) ** 0.5  # xavier-uniform bound
                 p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * a)
+        for name, b in module.named_buffers():
+            if name.endswith("tensor_layernorm.weight"):   # a buffer of ones in the reference; loaded from checkpoints
+                b.copy_(1.0 + 0.2 * (torch.rand(b.shape, generator=g) - 0.5))
 
 
 def run_reference(net, z, ei, w, vec, trace=False):
@@ -178,7 +204,7 @@ def build(name, hp, spec):
         edge_diff=w.numpy(), edge_vec=vec.numpy(),
         h=h.numpy(), X=X.numpy(), h_f64=h64.numpy(), X_f64=X64.numpy(),
         phi=phi.numpy(), rl=rl.numpy(),
-        cfg=np.frombuffer(json.dumps(dict(cutoff=CUTOFF, epsilon=1e-8, sep_htr=True, n_mol=n_mol, **hp)).encode(), dtype=np.uint8),
+        cfg=np.frombuffer(json.dumps({**dict(cutoff=CUTOFF, epsilon=1e-8, sep_htr=True, n_mol=n_mol), **hp}).encode(), dtype=np.uint8),
     )
     for li, (lh, lX, lt) in enumerate(layers):
         arrays[f"layer{li}/h"] = lh.numpy()
@@ -218,6 +244,9 @@ def sh_kat():
 
 if __name__ == "__main__":
     torch.set_num_threads(1)  # deterministic reduction order for the goldens
+    only = sys.argv[1:]                    # optional: names of the fixtures to (re)generate
     for name, (hp, spec) in CASES.items():
-        build(name, hp, spec)
-    sh_kat()
+        if not only or name in only:
+            build(name, hp, spec)
+    if not only:
+        sh_kat()
