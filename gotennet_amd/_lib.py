@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_PKG, "libgotennet_hip.so")
 GN_ERR_BAD_ARG = 10001
 ABI_VERSION = 1
 
-_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 
 # symbol -> argtypes (mirrors include/gotennet_hip.h one for one)
 SIGNATURES = {
@@ -48,6 +48,9 @@ SIGNATURES = {
     "gn_layernorm_silu_backward": [_P, _P, _P, _F, _P, _I, _I, _P, _P],
     "gn_layernorm_backward": [_P, _P, _F, _P, _I, _I, _P, _P],
     "gn_tensor_norm_backward": [_P, _P, _P, _F, _I, _I, _I, _P, _P],
+    "gn_gate": [_P, _I, _L, _P, _P],
+    "gn_gate_backward": [_P, _P, _I, _L, _P, _P],
+    "gn_edge_gate_backward": [_P, _P, _I, _P, _L, _P, _P, _P],
     "gn_edge_geometry_backward": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _I, _P, _I, _P, _P, _P, _P],
     "gn_pos_scatter": [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P],
     "gn_head_energy": [_P, _P, _F, _F, _F, _P, _P, _P, _I, _I, _P, _P, _P],

@@ -1001,7 +1001,7 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
                                const float* EK, const float* rl, const int* rowptr, const int* src, const int* dst,
                                const int* colptr, const int* perm, int N, int F, int lmax, int mode,
                                float* gEQ, float* gEK, float* g_rl, float* g_pre_t, void* stream) {
-    if (!bwd_dim_ok(F) || N < 0 || lmax < 1 || lmax > 4 || mode < 0 || mode > 15) return GN_ERR_BAD_ARG;
+    if (!bwd_dim_ok(F) || N < 0 || lmax < 1 || lmax > 4 || mode < 0 || mode > 31) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
     if (mode)

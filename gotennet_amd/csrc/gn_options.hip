@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void htr_bwd_target_general_kernel(
     const float* __restrict__ gtp, const float* __restrict__ pre_t, const float* __restrict__ w,
     const float* __restrict__ w_raw, const float* __restrict__ EQ, const float* __restrict__ EK,
     const float* __restrict__ rl, const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F,
-    int joint, int rej, int gate, float* __restrict__ gEQ, float* __restrict__ g_rl, float* __restrict__ g_pre_t) {
+    int joint, int rej, int gate, int direct, float* __restrict__ gEQ, float* __restrict__ g_rl,
+    float* __restrict__ g_pre_t) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     __shared__ __attribute__((aligned(16))) float red[1024];
     const int i = xcd_item(blockIdx.x, N);
@@ -107,10 +108,13 @@ __global__ __launch_bounds__(256) void htr_bwd_target_general_kernel(
 #pragma unroll
     for (int m = 0; m < D; ++m) { eq[m] = ld4(EQ + ((size_t)i * D + m) * F + c0); acc[m] = zero4(); }
     for (int e = e0 + slot; e < e1; e += ns) {
-        const float4 gte = ld4(gtp + (size_t)e * F + c0), pte = ld4(pre_t + (size_t)e * F + c0);
-        st4(g_pre_t + (size_t)e * F + c0, gte * ld4(w + (size_t)e * F + c0) * dsilu4o(pte));
-        float4 gw = gte * silu4o(pte);
-        if (gate) gw = gw * dgate4(ld4(w_raw + (size_t)e * F + c0), gate);
+        float4 gw = ld4(gtp + (size_t)e * F + c0);       // direct: this already is dL/dw
+        if (!direct) {
+            const float4 pte = ld4(pre_t + (size_t)e * F + c0);
+            st4(g_pre_t + (size_t)e * F + c0, gw * ld4(w + (size_t)e * F + c0) * dsilu4o(pte));
+            gw = gw * silu4o(pte);
+            if (gate) gw = gw * dgate4(ld4(w_raw + (size_t)e * F + c0), gate);
+        }
         const float* kj = EK + (size_t)src[e] * D * F + c0;
         const float* re = rl + (size_t)e * D;
         float4 pa[LMAX], pb[LMAX];
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256) void htr_bwd_source_general_kernel(
     const float* __restrict__ gtp, const float* __restrict__ pre_t, const float* __restrict__ w_raw,
     const float* __restrict__ EQ, const float* __restrict__ rl,
     const int* __restrict__ colptr, const int* __restrict__ perm, const int* __restrict__ dst, int N, int F,
-    int joint, int rej, int gate, float* __restrict__ gEK) {
+    int joint, int rej, int gate, int direct, float* __restrict__ gEK) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     __shared__ __attribute__((aligned(16))) float red[1024];
     const int j = xcd_item(blockIdx.x, N);
@@ -176,8 +180,11 @@ __global__ __launch_bounds__(256) void htr_bwd_source_general_kernel(
     for (int m = 0; m < D; ++m) acc[m] = zero4();
     for (int pp = p0 + slot; pp < p1; pp += ns) {
         const int e = perm[pp];
-        float4 gw = ld4(gtp + (size_t)e * F + c0) * silu4o(ld4(pre_t + (size_t)e * F + c0));
-        if (gate) gw = gw * dgate4(ld4(w_raw + (size_t)e * F + c0), gate);
+        float4 gw = ld4(gtp + (size_t)e * F + c0);
+        if (!direct) {
+            gw = gw * silu4o(ld4(pre_t + (size_t)e * F + c0));
+            if (gate) gw = gw * dgate4(ld4(w_raw + (size_t)e * F + c0), gate);
+        }
         const float* qi = EQ + (size_t)dst[e] * D * F + c0;
         const float* re = rl + (size_t)e * D;
         float4 pa[LMAX];
@@ -324,6 +331,28 @@ __global__ __launch_bounds__(256) void tensor_norm_bwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------ element-wise pieces of the composed edge update
+// (gamma_t = 2-layer MLP "mlp"/"mlpa", gamma_w with W_edp "linw"/"linwa" and LayerNorms "ln"/"postln")
+__global__ void gate_kernel(const float* __restrict__ x, int kind, size_t n4, float* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) st4(y + 4 * i, gate4(ld4(x + 4 * i), kind));
+}
+__global__ void gate_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, int kind, size_t n4,
+                                float* __restrict__ gx) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) st4(gx + 4 * i, ld4(g + 4 * i) * dgate4(ld4(x + 4 * i), kind));
+}
+// t' = t + act(pre) * wg:  g_pre = g act'(pre) wg,  g_wg = g act(pre)      (act: 0 identity, 3 SiLU)
+__global__ void edge_gate_bwd_kernel(const float* __restrict__ g, const float* __restrict__ pre, int act,
+                                     const float* __restrict__ wg, size_t n4, float* __restrict__ g_pre,
+                                     float* __restrict__ g_wg) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 gv = ld4(g + 4 * i), p = ld4(pre + 4 * i);
+    st4(g_pre + 4 * i, gv * dgate4(p, act) * ld4(wg + 4 * i));
+    st4(g_wg + 4 * i, gv * gate4(p, act));
+}
+
 }  // namespace gn
 
 // ====================================================================================== C ABI
@@ -350,13 +379,14 @@ int gn_htr_backward_general(const float* g_t_out, const float* pre_t, const floa
                             const int* dst, const int* colptr, const int* perm, int N, int F, int lmax, int mode,
                             float* gEQ, float* gEK, float* g_rl, float* g_pre_t, hipStream_t st) {
     const int joint = mode & GN_HTR_JOINT ? 1 : 0, rej = mode & GN_HTR_NOREJ ? 0 : 1, gate = (mode >> 2) & 3;
-    if (gate && !w_raw) return GN_ERR_BAD_ARG;
+    const int direct = mode & GN_HTR_DIRECT ? 1 : 0;
+    if (!direct && gate && !w_raw) return GN_ERR_BAD_ARG;
     const dim3 grid(gn::xcd_grid(N)), block(256);
     GN_OPT_SWITCH(htr_bwd_target_general_kernel, grid, block, st, g_t_out, pre_t, w, w_raw, EQ, EK, rl, rowptr, src,
-                  N, F, joint, rej, gate, gEQ, g_rl, g_pre_t);
+                  N, F, joint, rej, gate, direct, gEQ, g_rl, g_pre_t);
     GN_LAUNCH_CHECK();
     GN_OPT_SWITCH(htr_bwd_source_general_kernel, grid, block, st, g_t_out, pre_t, w_raw, EQ, rl, colptr, perm, dst,
-                  N, F, joint, rej, gate, gEK);
+                  N, F, joint, rej, gate, direct, gEK);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
@@ -379,6 +409,35 @@ extern "C" int gn_tensor_norm_backward(const float* X, const float* weight, cons
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((N * lmax + 3) / 4), block(256);
     GN_OPT_SWITCH(tensor_norm_bwd_kernel, grid, block, st, X, weight, g_Y, eps, N, F, g_X);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+static inline unsigned blocks_for(size_t n4) { return (unsigned)((n4 + 255) / 256); }
+
+extern "C" int gn_gate(const float* x, int kind, long n, float* y, void* stream) {
+    if (n < 0 || (n & 3) || kind < 0 || kind > 3) return GN_ERR_BAD_ARG;
+    if (n == 0) return GN_OK;
+    hipLaunchKernelGGL(gn::gate_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, x, kind, (size_t)n / 4, y);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+extern "C" int gn_gate_backward(const float* g, const float* x, int kind, long n, float* g_x, void* stream) {
+    if (n < 0 || (n & 3) || kind < 0 || kind > 3) return GN_ERR_BAD_ARG;
+    if (n == 0) return GN_OK;
+    hipLaunchKernelGGL(gn::gate_bwd_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, g, x, kind,
+                       (size_t)n / 4, g_x);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+extern "C" int gn_edge_gate_backward(const float* g, const float* pre, int act, const float* wg, long n,
+                                     float* g_pre, float* g_wg, void* stream) {
+    if (n < 0 || (n & 3) || (act != 0 && act != 3)) return GN_ERR_BAD_ARG;
+    if (n == 0) return GN_OK;
+    hipLaunchKernelGGL(gn::edge_gate_bwd_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, g, pre, act,
+                       wg, (size_t)n / 4, g_pre, g_wg);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }

@@ -38,6 +38,11 @@ class LayerWeights:
     Wvk: List[torch.Tensor] = field(default_factory=list)   # one per degree, or ONE shared weight (sep_htr=False)
     ln_w: Optional[torch.Tensor] = None; ln_b: Optional[torch.Tensor] = None   # optional nn.LayerNorm on h
     tln_w: Optional[torch.Tensor] = None                                       # optional TensorLayerNorm weight
+    # composed edge update (edge_updates "mlp"/"mlpa"/"linw"/"linwa"/"ln"/"postln", gotennet.py:236-291)
+    Wt0: Optional[torch.Tensor] = None; bt0: Optional[torch.Tensor] = None     # gamma_t hidden layer
+    t_ln_w: Optional[torch.Tensor] = None; t_ln_b: Optional[torch.Tensor] = None   # its LayerNorm (edge_ln)
+    Wedp: Optional[torch.Tensor] = None; bedp: Optional[torch.Tensor] = None   # W_edp
+    w_ln_w: Optional[torch.Tensor] = None; w_ln_b: Optional[torch.Tensor] = None   # LayerNorm before / after W_edp
     T: dict = field(default_factory=dict)         # lazily built transposes for the backward
 
 
@@ -70,6 +75,11 @@ class Config:
     htr_mode: int = 0         # GN_HTR_* bits (sep_htr=False, "norej", gamma_w gate)
     layernorm: bool = False   # nn.LayerNorm on h at the GATA input (gotennet.py:397)
     steerable_norm: bool = False   # TensorLayerNorm on X at the GATA input (gotennet.py:398)
+    composed_update: bool = False  # gamma_t 2-layer MLP and/or W_edp in gamma_w: sequenced by _edge_update_composed
+    gate_kind: int = 0        # gamma_w's final element-wise gate: 0 none, 1 sigmoid, 2 tanh, 3 SiLU
+    t_last_act: int = 3       # activation of gamma_t's last layer: 3 SiLU, 0 none ("mlp")
+    lin_w: int = 0            # 0 no W_edp, 1 "linw", 2 "linwa" (SiLU before W_edp)
+    lin_ln: int = 0           # 0 none, 1 "ln" (LayerNorm before W_edp), 2 "postln" (inside the W_edp Dense)
 
     @property
     def D(self) -> int:
@@ -201,6 +211,7 @@ class LayerTape:
     eproj: torch.Tensor = None; attn: torch.Tensor = None
     EQ: torch.Tensor = None; EK: torch.Tensor = None; w: torch.Tensor = None; pre_t: torch.Tensor = None
     w_raw: torch.Tensor = None; h_raw: torch.Tensor = None; X_raw: torch.Tensor = None
+    upd: dict = None                               # intermediates of the composed edge update
     Xp: torch.Tensor = None; ctx: torch.Tensor = None; pre_g1: torch.Tensor = None; mm: torch.Tensor = None
 
 
@@ -307,14 +318,101 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
                     off += cnt
             call("gn_htr_edge", ptr(EQ), ptr(EK), ptr(g.rl), ptr(g.rowptr), ptr(g.src), N, F_, lmax, cfg.htr_mode,
                  ptr(lt.w_raw) if save else None, ptr(w), _stream())
-            gemm(t, F_, lw.Wt, lw.bt, t2, F_, E, F_, F_, act=(0, F_), res=t, gate=w,
-                 pre_out=lt.pre_t if save else None)
+            if cfg.composed_update:
+                upd = _edge_update_composed(cfg, lw, t, w, t2, E, lt.pre_t if save else None)
+                if save:
+                    lt.upd = upd
+            else:
+                gemm(t, F_, lw.Wt, lw.bt, t2, F_, E, F_, F_, act=(0, F_), res=t, gate=w,
+                     pre_out=lt.pre_t if save else None)
             t, t2 = t2, t
         fork.join()                                # X is updated in place only after HTR has read it
         call("gn_eqff_update", ptr(mm), ptr(Xp), N, F_, D, ptr(h), ptr(X), _stream())
         if trace is not None:
             trace.append((h.clone(), X.clone(), t.clone()))
     return h, X, tape
+
+
+def _edge_update_composed(cfg: Config, lw: LayerWeights, t, w_raw, t2, E: int, pre_t):
+    """t2 = t + gamma_t(t) * gamma_w(w) for the non-default variants (gotennet.py:236-291, 611):
+    gamma_w = [LayerNorm "ln"] -> [SiLU "linwa"] -> W_edp "linw"/"linwa" [-> LayerNorm "postln"] -> [gate];
+    gamma_t = Dense -> [LayerNorm edge_ln] -> SiLU -> Dense [-> SiLU unless "mlp"]  ("mlp"/"mlpa"), or the
+    default SiLU(Dense).  Returns the intermediates the backward needs."""
+    F_ = cfg.F
+    new = lambda: torch.empty((E, F_), dtype=torch.float32, device=t.device)
+    st = _stream()
+    u = dict(w_raw=w_raw)
+    x = w_raw
+    if cfg.lin_w:
+        a_in = x
+        if cfg.lin_ln == 1:
+            a_in = new()
+            call("gn_layernorm", ptr(x), ptr(lw.w_ln_w), ptr(lw.w_ln_b), 1e-5, E, F_, ptr(a_in), st)
+        lin = new()
+        gemm(a_in, F_, lw.Wedp, lw.bedp, lin, F_, E, F_, F_, pro=(1, 0, F_) if cfg.lin_w == 2 else (0, 0, 0))
+        x = lin
+        if cfg.lin_ln == 2:
+            x = new()
+            call("gn_layernorm", ptr(lin), ptr(lw.w_ln_w), ptr(lw.w_ln_b), 1e-5, E, F_, ptr(x), st)
+        u.update(a_in=a_in, lin=lin)
+    u["pre_gate"] = x
+    if cfg.gate_kind:
+        wg = new()
+        call("gn_gate", ptr(x), cfg.gate_kind, E * F_, ptr(wg), st)
+    else:
+        wg = x
+    u["wg"] = wg
+    act = (0, F_) if cfg.t_last_act == 3 else (0, 0)
+    if lw.Wt0 is not None:
+        hid = new()
+        gemm(t, F_, lw.Wt0, lw.bt0, hid, F_, E, F_, F_)
+        u_in = hid
+        if lw.t_ln_w is not None:
+            u_in = new()
+            call("gn_layernorm", ptr(hid), ptr(lw.t_ln_w), ptr(lw.t_ln_b), 1e-5, E, F_, ptr(u_in), st)
+        gemm(u_in, F_, lw.Wt, lw.bt, t2, F_, E, F_, F_, act=act, res=t, gate=wg, pre_out=pre_t, pro=(1, 0, F_))
+        u.update(hid=hid, u_in=u_in)
+    else:
+        gemm(t, F_, lw.Wt, lw.bt, t2, F_, E, F_, F_, act=act, res=t, gate=wg, pre_out=pre_t)
+    return u
+
+
+def _edge_update_composed_backward(cfg: Config, lw: LayerWeights, lt, gt, gt_a, E: int):
+    """Input-gradients of _edge_update_composed: writes gt_a = gt + (d/dt through gamma_t) and returns dL/dw [E,F]."""
+    F_ = cfg.F
+    new = lambda: torch.empty((E, F_), dtype=torch.float32, device=gt.device)
+    st = _stream()
+    u = lt.upd
+    g_pre, g_wg = new(), new()
+    call("gn_edge_gate_backward", ptr(gt), ptr(lt.pre_t), cfg.t_last_act, ptr(u["wg"]), E * F_, ptr(g_pre), ptr(g_wg), st)
+    if lw.Wt0 is not None:
+        g_u = new()
+        gemm(g_pre, F_, _T(lw, "Wt"), None, g_u, F_, E, F_, F_, dgate=u["u_in"])
+        if lw.t_ln_w is not None:
+            g_h = new()
+            call("gn_layernorm_backward", ptr(u["hid"]), ptr(lw.t_ln_w), 1e-5, ptr(g_u), E, F_, ptr(g_h), st)
+            g_u = g_h
+        gemm(g_u, F_, _T(lw, "Wt0"), None, gt_a, F_, E, F_, F_, res=gt)
+    else:
+        gemm(g_pre, F_, _T(lw, "Wt"), None, gt_a, F_, E, F_, F_, res=gt)
+    gq = g_wg
+    if cfg.gate_kind:
+        g2 = new()
+        call("gn_gate_backward", ptr(gq), ptr(u["pre_gate"]), cfg.gate_kind, E * F_, ptr(g2), st)
+        gq = g2
+    if cfg.lin_w:
+        if cfg.lin_ln == 2:
+            g2 = new()
+            call("gn_layernorm_backward", ptr(u["lin"]), ptr(lw.w_ln_w), 1e-5, ptr(gq), E, F_, ptr(g2), st)
+            gq = g2
+        g3 = new()
+        gemm(gq, F_, _T(lw, "Wedp"), None, g3, F_, E, F_, F_, dgate=u["a_in"] if cfg.lin_w == 2 else None)
+        gq = g3
+        if cfg.lin_ln == 1:
+            g4 = new()
+            call("gn_layernorm_backward", ptr(u["w_raw"]), ptr(lw.w_ln_w), 1e-5, ptr(gq), E, F_, ptr(g4), st)
+            gq = g4
+    return gq
 
 
 def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: Tape,
@@ -361,9 +459,15 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
         if not last:
             if gt is None:
                 raise RuntimeError("internal: missing edge gradient")
-            call("gn_htr_backward", ptr(gt), ptr(lt.pre_t), ptr(lt.w), ptr(lt.w_raw), ptr(lt.EQ), ptr(lt.EK), ptr(g.rl),
-                 ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm), N, F_, lmax, cfg.htr_mode,
-                 ptr(gEQ), ptr(gEK), rl_slice(L + li), ptr(g_pre_t), _stream())
+            if cfg.composed_update:                # gt_a = gt + gamma_t backward; g_w = gamma_w backward
+                g_w = _edge_update_composed_backward(cfg, lw, lt, gt, gt_a, E)
+                call("gn_htr_backward", ptr(g_w), None, None, None, ptr(lt.EQ), ptr(lt.EK), ptr(g.rl),
+                     ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm), N, F_, lmax, cfg.htr_mode | 16,
+                     ptr(gEQ), ptr(gEK), rl_slice(L + li), None, _stream())
+            else:
+                call("gn_htr_backward", ptr(gt), ptr(lt.pre_t), ptr(lt.w), ptr(lt.w_raw), ptr(lt.EQ), ptr(lt.EK),
+                     ptr(g.rl), ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm), N, F_, lmax,
+                     cfg.htr_mode, ptr(gEQ), ptr(gEK), rl_slice(L + li), ptr(g_pre_t), _stream())
             gemm(gEQ, F_, _T(lw, "Wvq"), None, gX1, F_, N * D, F_, F_, res=gX1)
             off = 0
             for l in range(1, lmax + 1):
@@ -378,7 +482,8 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
                 if joint:
                     break
             # gt_a = gt + ((gt * w) * SiLU'(pre_t)) Wt
-            gemm(g_pre_t, F_, _T(lw, "Wt"), None, gt_a, F_, E, F_, F_, res=gt)
+            if not cfg.composed_update:
+                gemm(g_pre_t, F_, _T(lw, "Wt"), None, gt_a, F_, E, F_, F_, res=gt)
             gt_in = gt_a
         else:
             gt_in = gt                             # no edge update in this layer: t passes through unchanged

@@ -81,19 +81,18 @@ class GATA(nn.Module):
         allowed = ["gated", "gatedt", "norej", "norm", "mlp", "mlpa", "act", "linw", "linwa", "ln", "postln"]
         if not all(p in allowed for p in parts):
             raise ValueError(f"Invalid edge update parts. Allowed parts are {allowed}")
-        for p in ("mlp", "mlpa", "linw", "linwa", "ln", "postln"):
-            if p in parts:
-                raise NotImplementedError(f"edge_updates part {p!r} is not on the accelerated path "
-                                          "(gated, gatedt, act, norej, norm are)")
         for p in ("gated", "gatedt", "act"):
             if p in parts:
                 info["gated"] = p
         if "norej" in parts:
             info["rej"] = False
+        info["mlp"], info["mlpa"] = "mlp" in parts, "mlpa" in parts
+        info["lin_w"] = 2 if "linwa" in parts else 1 if "linw" in parts else 0
+        info["lin_ln"] = 2 if "postln" in parts else 1 if "ln" in parts else 0
         if aggr != "add":
             raise NotImplementedError("aggr must be 'add'")
-        if edge_ln:
-            raise NotImplementedError("edge_ln is not on the accelerated path")
+        if edge_ln not in ("", None, "layer"):
+            raise NotImplementedError(f"edge_ln={edge_ln!r}: only '' and 'layer' are on the accelerated path")
         if evec_dim not in (None, n_atom_basis) or emlp_dim not in (None, n_atom_basis):
             raise NotImplementedError("evec_dim / emlp_dim must equal n_atom_basis")
         self.layernorm_, self.steerable_norm_ = layer_norm, steerable_norm
@@ -112,7 +111,9 @@ class GATA(nn.Module):
                                      D_(n_atom_basis, multiplier * n_atom_basis, activation=None))
         self.W_re = D_(n_atom_basis, n_atom_basis, activation=activation)
         if not last_layer and edge_updates:
-            self.gamma_t = MLP([n_atom_basis, n_atom_basis], activation=activation, last_activation=activation,
+            two = info["mlp"] or info["mlpa"]       # gotennet.py:238-250
+            self.gamma_t = MLP([n_atom_basis] * (3 if two else 2), activation=activation,
+                               last_activation=None if info["mlp"] else activation,
                                weight_init=weight_init, bias_init=bias_init, norm=edge_ln)
             self.W_vq = D_(n_atom_basis, n_atom_basis, activation=None, bias=False)
             if sep_htr:
@@ -120,7 +121,19 @@ class GATA(nn.Module):
                                            for _ in range(lmax)])
             else:
                 self.W_vk = D_(n_atom_basis, n_atom_basis, activation=None, bias=False)
-            self.gamma_w = nn.Sequential()            # parameter-free (Sigmoid / Tanh / SiLU): applied by gn_htr_edge
+            modules = []                               # gotennet.py:270-291 (same module order => same state_dict keys)
+            if info["lin_w"] > 0:
+                if info["lin_ln"] == 1:
+                    modules.append(nn.LayerNorm(n_atom_basis))
+                if info["lin_w"] == 2:
+                    modules.append(nn.SiLU())
+                self.W_edp = D_(n_atom_basis, n_atom_basis, activation=None,
+                                norm="layer" if info["lin_ln"] == 2 else "")
+                modules.append(self.W_edp)
+            gate = {"gatedt": nn.Tanh, "gated": nn.Sigmoid, "act": nn.SiLU}.get(info["gated"])
+            if gate is not None:
+                modules.append(gate())
+            self.gamma_w = nn.Sequential(*modules)
         self.W_rs = D_(n_atom_basis, n_atom_basis * multiplier, activation=None)
         # gotennet.py:305-315
         self.layernorm = nn.LayerNorm(n_atom_basis) if layer_norm != "" else nn.Identity()
@@ -130,8 +143,19 @@ class GATA(nn.Module):
     @property
     def htr_mode(self) -> int:
         """``mode`` argument of gn_htr_edge / gn_htr_backward (include/gotennet_hip.h)."""
-        gate = {False: 0, "gated": 1, "gatedt": 2, "act": 3}[self.update_info["gated"]]
+        gate = 0 if self.composed_update else self.gate_kind
         return (0 if self.sep_htr else 1) | (0 if self.update_info["rej"] else 2) | (gate << 2)
+
+    @property
+    def gate_kind(self) -> int:
+        return {False: 0, "gated": 1, "gatedt": 2, "act": 3}[self.update_info["gated"]]
+
+    @property
+    def composed_update(self) -> bool:
+        """gamma_t is a 2-layer MLP and/or gamma_w has the W_edp projection: the edge update is sequenced from
+        GEMM / LayerNorm / gate launches by engine._edge_update_composed instead of the fused default."""
+        i = self.update_info
+        return bool(i["mlp"] or i["mlpa"] or i["lin_w"])
 
     def reset_parameters(self):
         for m in self.modules():
@@ -272,7 +296,10 @@ class GotenNet(nn.Module):
                              lmax=self.lmax, M=g0.multiplier, cutoff=float(self.cutoff), eps=float(self.epsilon),
                              scale_edge=bool(self.scale_edge), sep_dir=bool(self.sep_dir),
                              sep_tensor=bool(self.sep_tensor), basis=BASIS_CODE[type(self.radial_basis)][0],
-                             htr_mode=g0.htr_mode, layernorm=bool(g0.layernorm_), steerable_norm=bool(g0.steerable_norm_))
+                             htr_mode=g0.htr_mode, layernorm=bool(g0.layernorm_), steerable_norm=bool(g0.steerable_norm_),
+                             composed_update=g0.composed_update, gate_kind=g0.gate_kind,
+                             t_last_act=0 if g0.update_info["mlp"] else 3,
+                             lin_w=g0.update_info["lin_w"], lin_ln=g0.update_info["lin_ln"])
 
     def packed_weights(self) -> engine.PackedWeights:
         """Concatenate the projections that share an input into single GEMM operands
@@ -304,7 +331,18 @@ class GotenNet(nn.Module):
                 Wm0=d(eq.gamma_m[0].weight), bm0=d(eq.gamma_m[0].bias),
                 Wm1=d(eq.gamma_m[1].weight), bm1=d(eq.gamma_m[1].bias))
             if not gata.last_layer and gata.edge_updates:
-                lw.Wt, lw.bt = d(gata.gamma_t.dense_layers[0].weight), d(gata.gamma_t.dense_layers[0].bias)
+                dl = gata.gamma_t.dense_layers
+                lw.Wt, lw.bt = d(dl[-1].weight), d(dl[-1].bias)
+                if len(dl) == 2:                   # "mlp"/"mlpa": hidden layer (+ optional LayerNorm "edge_ln")
+                    lw.Wt0, lw.bt0 = d(dl[0].weight), d(dl[0].bias)
+                    if dl[0].norm is not None:
+                        lw.t_ln_w, lw.t_ln_b = d(dl[0].norm.weight), d(dl[0].norm.bias)
+                if gata.update_info["lin_w"]:
+                    lw.Wedp, lw.bedp = d(gata.W_edp.weight), d(gata.W_edp.bias)
+                    if gata.update_info["lin_ln"] == 1:
+                        lw.w_ln_w, lw.w_ln_b = d(gata.gamma_w[0].weight), d(gata.gamma_w[0].bias)
+                    elif gata.update_info["lin_ln"] == 2:
+                        lw.w_ln_w, lw.w_ln_b = d(gata.W_edp.norm.weight), d(gata.W_edp.norm.bias)
                 lw.Wvq = d(gata.W_vq.weight)
                 lw.Wvk = [d(wk.weight) for wk in gata.W_vk] if gata.sep_htr else [d(gata.W_vk.weight)]
             if gata.layernorm_:

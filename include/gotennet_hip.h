@@ -163,6 +163,7 @@ int gn_message_aggregate(const float* x, const float* v, int ldxv, const float* 
 #define GN_HTR_GATE_SIGMOID (1 << 2)
 #define GN_HTR_GATE_TANH (2 << 2)
 #define GN_HTR_GATE_SILU (3 << 2)
+#define GN_HTR_DIRECT 16 /* gn_htr_backward only: g_t_out already is dL/dw [E,F]; pre_t, w, w_raw, g_pre_t unused */
 int gn_htr_edge(const float* EQ, const float* EK, const float* rl, const int* rowptr, const int* src,
                 int N, int F, int lmax, int mode, float* w_raw, float* w, void* stream);
 
@@ -226,6 +227,15 @@ int gn_layernorm_backward(const float* x, const float* gamma, float eps,
                           const float* g_out, int N, int F, float* g_x, void* stream);
 int gn_tensor_norm_backward(const float* X, const float* weight, const float* g_Y, float eps, int N, int F,
                             int lmax, float* g_X, void* stream);
+
+/* ---- element-wise pieces of the composed edge update (gotennet.py:236-291: gamma_t as a 2-layer MLP "mlp"/"mlpa",
+ *      gamma_w = [LayerNorm "ln"] [act "linwa"] W_edp "linw" [LayerNorm "postln"] [gate]); n = element count, n % 4 = 0.
+ *      kind: 0 identity, 1 sigmoid, 2 tanh, 3 SiLU. */
+int gn_gate(const float* x, int kind, long n, float* y, void* stream);
+int gn_gate_backward(const float* g, const float* x, int kind, long n, float* g_x, void* stream);
+/* t' = t + act(pre) * wg  ->  g_pre = g act'(pre) wg,  g_wg = g act(pre);  act in {0, 3}. */
+int gn_edge_gate_backward(const float* g, const float* pre, int act, const float* wg, long n,
+                          float* g_pre, float* g_wg, void* stream);
 
 /* Edge geometry (K1) backward: (sum of the n_rl slices g_rl [n_rl,E,D], sum of the n_cut slices g_cut [n_cut,E],
  * g_phi [E,R]) -> g_vec [E,3] through the unit vector and harmonics, g_diff [E] through cutoff and radial

@@ -46,16 +46,12 @@ def default_config(**kw) -> dict:
 
 
 def edge_update_info(edge_updates) -> dict:
-    """gotennet.py:139-190: the '_'-separated string form of ``edge_updates``.  Only the parts the HIP path
-    carries are restated: rejection on/off and the element-wise gate on w_ij."""
-    info = dict(enabled=bool(edge_updates), rej=True, gate="")
+    """gotennet.py:139-190: the '_'-separated string form of ``edge_updates``."""
+    info = dict(enabled=bool(edge_updates), rej=True, gate="", mlp=False, mlpa=False, lin_w=0, lin_ln=0)
     parts = edge_updates.split("_") if isinstance(edge_updates, str) else []
     allowed = ["gated", "gatedt", "norej", "norm", "mlp", "mlpa", "act", "linw", "linwa", "ln", "postln"]
     if not all(part in allowed for part in parts):
         raise ValueError(f"Invalid edge update parts. Allowed parts are {allowed}")
-    for part in ("mlp", "mlpa", "linw", "linwa", "ln", "postln"):
-        if part in parts:
-            raise NotImplementedError(f"edge_updates part {part!r} is not restated")
     if "gated" in parts:
         info["gate"] = "sigmoid"
     if "gatedt" in parts:
@@ -64,6 +60,15 @@ def edge_update_info(edge_updates) -> dict:
         info["gate"] = "silu"
     if "norej" in parts:
         info["rej"] = False
+    info["mlp"], info["mlpa"] = "mlp" in parts, "mlpa" in parts
+    if "linw" in parts:
+        info["lin_w"] = 1
+    if "linwa" in parts:
+        info["lin_w"] = 2
+    if "ln" in parts:
+        info["lin_ln"] = 1
+    if "postln" in parts:
+        info["lin_ln"] = 2
     return info
 
 
@@ -310,8 +315,8 @@ def _rejection(rep: Tensor, rl: Tensor) -> Tensor:
 
 
 def gata_htr(sd, cfg, p, edge_index, X, rl, t):
-    """gotennet.py:429-445 + edge_update 561-611: gamma_t = SiLU(Dense); rejection on/off, per-degree or joint
-    (sep_htr), gamma_w = identity | sigmoid | tanh | SiLU (gotennet.py:285-291)."""
+    """gotennet.py:429-445 + edge_update 561-611: rejection on/off, per-degree or joint (sep_htr);
+    t' = t + gamma_t(t) * gamma_w(w)."""
     lmax = cfg["lmax"]
     info = edge_update_info(cfg.get("edge_updates", True))
     sizes = degree_sizes(lmax)
@@ -335,13 +340,43 @@ def gata_htr(sd, cfg, p, edge_index, X, rl, t):
             ek = _rejection(ek, -rl_s[a])
         wl = (eq * ek).sum(dim=1)
         w = wl if w is None else w + wl
+    return t + gamma_t(sd, cfg, p, info, t) * gamma_w(sd, p, info, w)
+
+
+def _layer_norm(x, sd, key):
+    return F.layer_norm(x, (x.shape[-1],), sd[key + ".weight"], sd[key + ".bias"], 1e-5)
+
+
+def gamma_t(sd, cfg, p, info, t):
+    """gotennet.py:236-251: MLP([F, F]) with SiLU, or with "mlp"/"mlpa" MLP([F, emlp, F]) whose hidden Dense
+    carries the optional ``edge_ln`` LayerNorm (layers.py:518-529) and whose last activation is None for "mlp"."""
+    k = p + "gamma_t.dense_layers."
+    if info["mlp"] or info["mlpa"]:
+        u = linear(t, sd, k + "0")
+        if (k + "0.norm.weight") in sd:
+            u = _layer_norm(u, sd, k + "0.norm")
+        y = linear(F.silu(u), sd, k + "1")
+        return y if info["mlp"] else F.silu(y)
+    return F.silu(linear(t, sd, k + "0"))
+
+
+def gamma_w(sd, p, info, w):
+    """gotennet.py:270-291: nn.Sequential([LayerNorm "ln"], [act "linwa"], W_edp [with norm "postln"], [gate])."""
+    if info["lin_w"] > 0:
+        if info["lin_ln"] == 1:
+            w = _layer_norm(w, sd, p + "gamma_w.0")
+        if info["lin_w"] == 2:
+            w = F.silu(w)
+        w = linear(w, sd, p + "W_edp")
+        if info["lin_ln"] == 2:
+            w = _layer_norm(w, sd, p + "W_edp.norm")
     if info["gate"] == "sigmoid":
         w = torch.sigmoid(w)
     elif info["gate"] == "tanh":
         w = torch.tanh(w)
     elif info["gate"] == "silu":
         w = F.silu(w)
-    return t + F.silu(linear(t, sd, p + "gamma_t.dense_layers.0")) * w
+    return w
 
 
 def eqff(sd, cfg, p, h, X):

@@ -19,7 +19,8 @@ def _net_from_case(cfg, sd):
         # non-default flags carried by the opt_* fixtures
         sep_htr=cfg.get("sep_htr", True), radial_basis=cfg.get("radial_basis", "expnorm"),
         edge_updates=cfg.get("edge_updates", True), layernorm=cfg.get("layernorm", ""),
-        steerable_norm=cfg.get("steerable_norm", ""))
+        steerable_norm=cfg.get("steerable_norm", ""), edge_ln=cfg.get("edge_ln", ""),
+            activation=cfg.get("activation", "silu"))
     net.load_state_dict(sd, strict=True)
     return net.cuda().eval()
 
@@ -99,7 +100,8 @@ def test_wrapper_matches_golden():
         # non-default flags carried by the opt_* fixtures
         sep_htr=cfg.get("sep_htr", True), radial_basis=cfg.get("radial_basis", "expnorm"),
         edge_updates=cfg.get("edge_updates", True), layernorm=cfg.get("layernorm", ""),
-        steerable_norm=cfg.get("steerable_norm", ""))
+        steerable_norm=cfg.get("steerable_norm", ""), edge_ln=cfg.get("edge_ln", ""),
+            activation=cfg.get("activation", "silu"))
     net.load_state_dict(sd, strict=True)
     net = net.cuda().eval()
     inp = types.SimpleNamespace(z=t["z"].cuda(), pos=t["pos"].cuda(), batch=t["batch"].cuda())

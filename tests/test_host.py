@@ -37,7 +37,8 @@ def test_state_dict_layout_matches_golden_checkpoint():
             scale_edge=cfg["scale_edge"], lmax=cfg["lmax"], sep_dir=cfg["sep_dir"], sep_tensor=cfg["sep_tensor"],
             sep_htr=cfg.get("sep_htr", True), radial_basis=cfg.get("radial_basis", "expnorm"),
             edge_updates=cfg.get("edge_updates", True), layernorm=cfg.get("layernorm", ""),
-            steerable_norm=cfg.get("steerable_norm", ""))
+            steerable_norm=cfg.get("steerable_norm", ""), edge_ln=cfg.get("edge_ln", ""),
+            activation=cfg.get("activation", "silu"))
         assert sorted(net.state_dict().keys()) == sorted(sd.keys()), name
         net.load_state_dict(sd, strict=True)
         assert net.hidden_dim == cfg["n_atom_basis"] and net.cutoff == cfg["cutoff"]
@@ -60,9 +61,11 @@ def test_unsupported_flags_raise_before_launch():
     with pytest.raises(NotImplementedError):
         gotennet_amd.GotenNet(cutoff_fn=cut, lmax=5)
     with pytest.raises(NotImplementedError):
-        gotennet_amd.GotenNet(cutoff_fn=cut, edge_ln="layer")
+        gotennet_amd.GotenNet(cutoff_fn=cut, edge_ln="batch")
     with pytest.raises(NotImplementedError):
-        gotennet_amd.GotenNet(cutoff_fn=cut, edge_updates="gated_mlp")
+        gotennet_amd.GotenNet(cutoff_fn=cut, evec_dim=64)
+    with pytest.raises(NotImplementedError):
+        gotennet_amd.GotenNet(cutoff_fn=cut, aggr="mean")
     with pytest.raises(ValueError):
         gotennet_amd.GotenNet(cutoff_fn=cut, edge_updates="bogus")
     with pytest.raises(ValueError):

@@ -73,6 +73,18 @@ CASES = {
     "opt_tln_l4": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=4, num_heads=8, scale_edge=True,
                         sep_dir=True, sep_tensor=True, max_z=10, steerable_norm="tensor"),
                    dict(mols=[5], box=2.6, seed=17)),
+    # composed edge updates; activation passed as a string so that "linwa" can put it into nn.Sequential
+    "opt_mlp_linwa_ln_gated": (dict(n_atom_basis=32, n_interactions=3, n_rbf=8, lmax=2, num_heads=8, scale_edge=False,
+                                    sep_dir=True, sep_tensor=True, max_z=10, activation="silu",
+                                    edge_updates="mlp_linwa_ln_gated", edge_ln="layer"),
+                               dict(mols=[6, 5], box=3.0, seed=21)),
+    "opt_mlpa_linw_postln": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=1, num_heads=4, scale_edge=True,
+                                  sep_dir=False, sep_tensor=False, max_z=10, activation="silu",
+                                  edge_updates="mlpa_linw_postln_norej", sep_htr=False),
+                             dict(mols=[7, 4], box=3.0, seed=22)),
+    "opt_linw_act_l3": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=3, num_heads=8, scale_edge=False,
+                             sep_dir=True, sep_tensor=True, max_z=10, activation="silu", edge_updates="linw_act"),
+                        dict(mols=[5, 4], box=2.8, seed=23)),
 }
 
 CUTOFF = 5.0
