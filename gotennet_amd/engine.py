@@ -80,6 +80,16 @@ class Config:
     t_last_act: int = 3       # activation of gamma_t's last layer: 3 SiLU, 0 none ("mlp")
     lin_w: int = 0            # 0 no W_edp, 1 "linw", 2 "linwa" (SiLU before W_edp)
     lin_ln: int = 0           # 0 none, 1 "ln" (LayerNorm before W_edp), 2 "postln" (inside the W_edp Dense)
+    evec: int = 0             # evec_dim: width of EQ / EK / w (0 = F; != F needs W_edp to map back to F)
+    emlp: int = 0             # emlp_dim: hidden width of the 2-layer gamma_t (0 = F)
+
+    @property
+    def Fe(self) -> int:
+        return self.evec or self.F
+
+    @property
+    def Fm(self) -> int:
+        return self.emlp or self.F
 
     @property
     def D(self) -> int:
@@ -226,6 +236,7 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
     """-> (h [N,F], X [N,D,F], tape or None).  ``save`` keeps what ``backward`` needs;
     ``trace`` (tests only) collects per-layer clones of (h, X, t)."""
     F_, R, H, D, M, lmax = cfg.F, cfg.R, cfg.H, cfg.D, cfg.M, cfg.lmax
+    Fe = cfg.Fe
     N, E = g.N, g.E
     dev = z32.device
     f32 = dict(dtype=torch.float32, device=dev)
@@ -255,7 +266,7 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
         h2, X2, t2 = new(N, F_), new(N, D, F_), new(E, F_)
         nproj, xs, vs = new(N, 4 * F_), new(N, M * F_), new(N, M * F_)
         eproj, attn = new(E, lde), new(E, H)
-        EQ, EK, Xp, w = new(N, D, F_), new(N, D, F_), new(N, D, F_), new(E, F_)
+        EQ, EK, Xp, w = new(N, D, Fe), new(N, D, Fe), new(N, D, F_), new(E, Fe)
         ctx, pre_g1, mm = new(N, 2 * F_), new(N, F_), new(N, 2 * F_)
 
     for li, lw in enumerate(pw.layers):
@@ -278,10 +289,10 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
             eproj, attn = new(E, lde), new(E, H)
             Xp, ctx, pre_g1, mm = new(N, D, F_), new(N, 2 * F_), new(N, F_), new(N, 2 * F_)
             if not last:
-                EQ, EK, w = new(N, D, F_), new(N, D, F_), new(E, F_)
+                EQ, EK, w = new(N, D, Fe), new(N, D, Fe), new(E, Fe)
                 lt.pre_t = new(E, F_)
                 lt.EQ, lt.EK, lt.w = EQ, EK, w
-                lt.w_raw = new(E, F_) if (cfg.htr_mode >> 2) else None
+                lt.w_raw = new(E, Fe) if (cfg.htr_mode >> 2) else None
             lt.nproj, lt.xs, lt.vs, lt.eproj, lt.attn = nproj, xs, vs, eproj, attn
             lt.Xp, lt.ctx, lt.pre_g1, lt.mm = Xp, ctx, pre_g1, mm
         # ---- GATA projections (gotennet.py:400-407); SiLU applied by the consumers
@@ -307,16 +318,16 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
             gemm(pre_g1, F_, lw.Wm1, lw.bm1, mm, 2 * F_, N, 2 * F_, F_, pro=(1, 0, F_))
         # ---- HTR (429-445, 561-611)
         if not last:
-            gemm(X, F_, lw.Wvq, None, EQ, F_, N * D, F_, F_)
+            gemm(X, F_, lw.Wvq, None, EQ, Fe, N * D, Fe, F_)
             if cfg.htr_mode & 1:                   # sep_htr=False: one W_vk for every row
-                gemm(X, F_, lw.Wvk[0], None, EK, F_, N * D, F_, F_)
+                gemm(X, F_, lw.Wvk[0], None, EK, Fe, N * D, Fe, F_)
             else:
                 off = 0
                 for l in range(1, lmax + 1):
                     cnt = 2 * l + 1
-                    gemm(X, F_, lw.Wvk[l - 1], None, EK, F_, N * cnt, F_, F_, rowmap=(cnt, D, off))
+                    gemm(X, F_, lw.Wvk[l - 1], None, EK, Fe, N * cnt, Fe, F_, rowmap=(cnt, D, off))
                     off += cnt
-            call("gn_htr_edge", ptr(EQ), ptr(EK), ptr(g.rl), ptr(g.rowptr), ptr(g.src), N, F_, lmax, cfg.htr_mode,
+            call("gn_htr_edge", ptr(EQ), ptr(EK), ptr(g.rl), ptr(g.rowptr), ptr(g.src), N, Fe, lmax, cfg.htr_mode,
                  ptr(lt.w_raw) if save else None, ptr(w), _stream())
             if cfg.composed_update:
                 upd = _edge_update_composed(cfg, lw, t, w, t2, E, lt.pre_t if save else None)
@@ -338,18 +349,18 @@ def _edge_update_composed(cfg: Config, lw: LayerWeights, t, w_raw, t2, E: int, p
     gamma_w = [LayerNorm "ln"] -> [SiLU "linwa"] -> W_edp "linw"/"linwa" [-> LayerNorm "postln"] -> [gate];
     gamma_t = Dense -> [LayerNorm edge_ln] -> SiLU -> Dense [-> SiLU unless "mlp"]  ("mlp"/"mlpa"), or the
     default SiLU(Dense).  Returns the intermediates the backward needs."""
-    F_ = cfg.F
-    new = lambda: torch.empty((E, F_), dtype=torch.float32, device=t.device)
+    F_, Fe, Fm = cfg.F, cfg.Fe, cfg.Fm
+    new = lambda width=F_: torch.empty((E, width), dtype=torch.float32, device=t.device)
     st = _stream()
     u = dict(w_raw=w_raw)
     x = w_raw
     if cfg.lin_w:
         a_in = x
         if cfg.lin_ln == 1:
-            a_in = new()
-            call("gn_layernorm", ptr(x), ptr(lw.w_ln_w), ptr(lw.w_ln_b), 1e-5, E, F_, ptr(a_in), st)
+            a_in = new(Fe)
+            call("gn_layernorm", ptr(x), ptr(lw.w_ln_w), ptr(lw.w_ln_b), 1e-5, E, Fe, ptr(a_in), st)
         lin = new()
-        gemm(a_in, F_, lw.Wedp, lw.bedp, lin, F_, E, F_, F_, pro=(1, 0, F_) if cfg.lin_w == 2 else (0, 0, 0))
+        gemm(a_in, Fe, lw.Wedp, lw.bedp, lin, F_, E, F_, Fe, pro=(1, 0, Fe) if cfg.lin_w == 2 else (0, 0, 0))
         x = lin
         if cfg.lin_ln == 2:
             x = new()
@@ -364,13 +375,13 @@ def _edge_update_composed(cfg: Config, lw: LayerWeights, t, w_raw, t2, E: int, p
     u["wg"] = wg
     act = (0, F_) if cfg.t_last_act == 3 else (0, 0)
     if lw.Wt0 is not None:
-        hid = new()
-        gemm(t, F_, lw.Wt0, lw.bt0, hid, F_, E, F_, F_)
+        hid = new(Fm)
+        gemm(t, F_, lw.Wt0, lw.bt0, hid, Fm, E, Fm, F_)
         u_in = hid
         if lw.t_ln_w is not None:
-            u_in = new()
-            call("gn_layernorm", ptr(hid), ptr(lw.t_ln_w), ptr(lw.t_ln_b), 1e-5, E, F_, ptr(u_in), st)
-        gemm(u_in, F_, lw.Wt, lw.bt, t2, F_, E, F_, F_, act=act, res=t, gate=wg, pre_out=pre_t, pro=(1, 0, F_))
+            u_in = new(Fm)
+            call("gn_layernorm", ptr(hid), ptr(lw.t_ln_w), ptr(lw.t_ln_b), 1e-5, E, Fm, ptr(u_in), st)
+        gemm(u_in, Fm, lw.Wt, lw.bt, t2, F_, E, F_, Fm, act=act, res=t, gate=wg, pre_out=pre_t, pro=(1, 0, Fm))
         u.update(hid=hid, u_in=u_in)
     else:
         gemm(t, F_, lw.Wt, lw.bt, t2, F_, E, F_, F_, act=act, res=t, gate=wg, pre_out=pre_t)
@@ -379,20 +390,20 @@ def _edge_update_composed(cfg: Config, lw: LayerWeights, t, w_raw, t2, E: int, p
 
 def _edge_update_composed_backward(cfg: Config, lw: LayerWeights, lt, gt, gt_a, E: int):
     """Input-gradients of _edge_update_composed: writes gt_a = gt + (d/dt through gamma_t) and returns dL/dw [E,F]."""
-    F_ = cfg.F
-    new = lambda: torch.empty((E, F_), dtype=torch.float32, device=gt.device)
+    F_, Fe, Fm = cfg.F, cfg.Fe, cfg.Fm
+    new = lambda width=F_: torch.empty((E, width), dtype=torch.float32, device=gt.device)
     st = _stream()
     u = lt.upd
     g_pre, g_wg = new(), new()
     call("gn_edge_gate_backward", ptr(gt), ptr(lt.pre_t), cfg.t_last_act, ptr(u["wg"]), E * F_, ptr(g_pre), ptr(g_wg), st)
     if lw.Wt0 is not None:
-        g_u = new()
-        gemm(g_pre, F_, _T(lw, "Wt"), None, g_u, F_, E, F_, F_, dgate=u["u_in"])
+        g_u = new(Fm)
+        gemm(g_pre, F_, _T(lw, "Wt"), None, g_u, Fm, E, Fm, F_, dgate=u["u_in"])
         if lw.t_ln_w is not None:
-            g_h = new()
-            call("gn_layernorm_backward", ptr(u["hid"]), ptr(lw.t_ln_w), 1e-5, ptr(g_u), E, F_, ptr(g_h), st)
+            g_h = new(Fm)
+            call("gn_layernorm_backward", ptr(u["hid"]), ptr(lw.t_ln_w), 1e-5, ptr(g_u), E, Fm, ptr(g_h), st)
             g_u = g_h
-        gemm(g_u, F_, _T(lw, "Wt0"), None, gt_a, F_, E, F_, F_, res=gt)
+        gemm(g_u, Fm, _T(lw, "Wt0"), None, gt_a, F_, E, F_, Fm, res=gt)
     else:
         gemm(g_pre, F_, _T(lw, "Wt"), None, gt_a, F_, E, F_, F_, res=gt)
     gq = g_wg
@@ -405,12 +416,12 @@ def _edge_update_composed_backward(cfg: Config, lw: LayerWeights, lt, gt, gt_a, 
             g2 = new()
             call("gn_layernorm_backward", ptr(u["lin"]), ptr(lw.w_ln_w), 1e-5, ptr(gq), E, F_, ptr(g2), st)
             gq = g2
-        g3 = new()
-        gemm(gq, F_, _T(lw, "Wedp"), None, g3, F_, E, F_, F_, dgate=u["a_in"] if cfg.lin_w == 2 else None)
+        g3 = new(Fe)
+        gemm(gq, F_, _T(lw, "Wedp"), None, g3, Fe, E, Fe, F_, dgate=u["a_in"] if cfg.lin_w == 2 else None)
         gq = g3
         if cfg.lin_ln == 1:
-            g4 = new()
-            call("gn_layernorm_backward", ptr(u["w_raw"]), ptr(lw.w_ln_w), 1e-5, ptr(gq), E, F_, ptr(g4), st)
+            g4 = new(Fe)
+            call("gn_layernorm_backward", ptr(u["w_raw"]), ptr(lw.w_ln_w), 1e-5, ptr(gq), E, Fe, ptr(g4), st)
             gq = g4
     return gq
 
@@ -420,6 +431,7 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
     """Input-gradients of ``forward``: given dL/dh [N,F] and dL/dX [N,D,F] (or None = 0)
     returns (g_edge_vec [E,3], g_edge_diff [E]) in the CSR edge order of ``g``."""
     F_, R, H, D, M, lmax = cfg.F, cfg.R, cfg.H, cfg.D, cfg.M, cfg.lmax
+    Fe = cfg.Fe
     N, E = g.N, g.E
     f32 = dict(dtype=torch.float32, device=z32.device)
     new = lambda *shape: torch.empty(shape, **f32)
@@ -441,7 +453,7 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
 
     gm, gXp, g_g1, g_ctx = new(N, 2 * F_), new(N, D, F_), new(N, F_), new(N, 2 * F_)
     gh1, gX1, gX2, gh2 = new(N, F_), new(N, D, F_), new(N, D, F_), new(N, F_)
-    gEQ, gEK = new(N, D, F_), new(N, D, F_)
+    gEQ, gEK = new(N, D, Fe), new(N, D, Fe)
     g_eproj, g_s = new(E, lde), new(E, H)
     g_nproj, g_x, g_v = new(N, 4 * F_), new(N, M * F_), new(N, M * F_)
     gt_a, gt_b, g_pre_t = new(E, F_), new(E, F_), new(E, F_)
@@ -462,13 +474,13 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
             if cfg.composed_update:                # gt_a = gt + gamma_t backward; g_w = gamma_w backward
                 g_w = _edge_update_composed_backward(cfg, lw, lt, gt, gt_a, E)
                 call("gn_htr_backward", ptr(g_w), None, None, None, ptr(lt.EQ), ptr(lt.EK), ptr(g.rl),
-                     ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm), N, F_, lmax, cfg.htr_mode | 16,
+                     ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm), N, Fe, lmax, cfg.htr_mode | 16,
                      ptr(gEQ), ptr(gEK), rl_slice(L + li), None, _stream())
             else:
                 call("gn_htr_backward", ptr(gt), ptr(lt.pre_t), ptr(lt.w), ptr(lt.w_raw), ptr(lt.EQ), ptr(lt.EK),
-                     ptr(g.rl), ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm), N, F_, lmax,
+                     ptr(g.rl), ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm), N, Fe, lmax,
                      cfg.htr_mode, ptr(gEQ), ptr(gEK), rl_slice(L + li), ptr(g_pre_t), _stream())
-            gemm(gEQ, F_, _T(lw, "Wvq"), None, gX1, F_, N * D, F_, F_, res=gX1)
+            gemm(gEQ, Fe, _T(lw, "Wvq"), None, gX1, F_, N * D, F_, Fe, res=gX1)
             off = 0
             for l in range(1, lmax + 1):
                 joint = bool(cfg.htr_mode & 1)
@@ -477,7 +489,7 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
                 if wkT is None:
                     wkT = lw.Wvk[l - 1].t().contiguous()
                     lw.T[("Wvk", l)] = wkT
-                gemm(gEK, F_, wkT, None, gX1, F_, N * cnt, F_, F_, rowmap=(cnt, D, off), res=gX1)
+                gemm(gEK, Fe, wkT, None, gX1, F_, N * cnt, F_, Fe, rowmap=(cnt, D, off), res=gX1)
                 off += cnt
                 if joint:
                     break

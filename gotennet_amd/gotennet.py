@@ -93,8 +93,15 @@ class GATA(nn.Module):
             raise NotImplementedError("aggr must be 'add'")
         if edge_ln not in ("", None, "layer"):
             raise NotImplementedError(f"edge_ln={edge_ln!r}: only '' and 'layer' are on the accelerated path")
-        if evec_dim not in (None, n_atom_basis) or emlp_dim not in (None, n_atom_basis):
-            raise NotImplementedError("evec_dim / emlp_dim must equal n_atom_basis")
+        self.edge_vec_dim = n_atom_basis if evec_dim is None else evec_dim
+        self.edge_mlp_dim = n_atom_basis if emlp_dim is None else emlp_dim
+        if self.edge_vec_dim != n_atom_basis and not info["lin_w"] and edge_updates:
+            raise ValueError("evec_dim != n_atom_basis needs a 'linw'/'linwa' edge update (W_edp maps w_ij back to "
+                             "n_atom_basis; the reference fails with a shape error otherwise)")
+        if self.edge_vec_dim < 16 or self.edge_vec_dim > 1024 or self.edge_vec_dim & (self.edge_vec_dim - 1):
+            raise NotImplementedError("evec_dim must be a power of two in [16, 1024] on the HIP path (<= 256 for forces)")
+        if self.edge_mlp_dim % 4:
+            raise NotImplementedError("emlp_dim must be a multiple of 4 on the HIP path")
         self.layernorm_, self.steerable_norm_ = layer_norm, steerable_norm
         self.n_atom_basis, self.lmax, self.num_heads = n_atom_basis, lmax, num_heads
         self.last_layer, self.edge_updates, self.scale_edge = last_layer, edge_updates, scale_edge
@@ -112,22 +119,23 @@ class GATA(nn.Module):
         self.W_re = D_(n_atom_basis, n_atom_basis, activation=activation)
         if not last_layer and edge_updates:
             two = info["mlp"] or info["mlpa"]       # gotennet.py:238-250
-            self.gamma_t = MLP([n_atom_basis] * (3 if two else 2), activation=activation,
+            self.gamma_t = MLP([n_atom_basis, self.edge_mlp_dim, n_atom_basis] if two else [n_atom_basis] * 2,
+                               activation=activation,
                                last_activation=None if info["mlp"] else activation,
                                weight_init=weight_init, bias_init=bias_init, norm=edge_ln)
-            self.W_vq = D_(n_atom_basis, n_atom_basis, activation=None, bias=False)
+            ev = self.edge_vec_dim
+            self.W_vq = D_(n_atom_basis, ev, activation=None, bias=False)
             if sep_htr:
-                self.W_vk = nn.ModuleList([D_(n_atom_basis, n_atom_basis, activation=None, bias=False)
-                                           for _ in range(lmax)])
+                self.W_vk = nn.ModuleList([D_(n_atom_basis, ev, activation=None, bias=False) for _ in range(lmax)])
             else:
-                self.W_vk = D_(n_atom_basis, n_atom_basis, activation=None, bias=False)
+                self.W_vk = D_(n_atom_basis, ev, activation=None, bias=False)
             modules = []                               # gotennet.py:270-291 (same module order => same state_dict keys)
             if info["lin_w"] > 0:
                 if info["lin_ln"] == 1:
-                    modules.append(nn.LayerNorm(n_atom_basis))
+                    modules.append(nn.LayerNorm(ev))
                 if info["lin_w"] == 2:
                     modules.append(nn.SiLU())
-                self.W_edp = D_(n_atom_basis, n_atom_basis, activation=None,
+                self.W_edp = D_(ev, n_atom_basis, activation=None,
                                 norm="layer" if info["lin_ln"] == 2 else "")
                 modules.append(self.W_edp)
             gate = {"gatedt": nn.Tanh, "gated": nn.Sigmoid, "act": nn.SiLU}.get(info["gated"])
@@ -299,7 +307,8 @@ class GotenNet(nn.Module):
                              htr_mode=g0.htr_mode, layernorm=bool(g0.layernorm_), steerable_norm=bool(g0.steerable_norm_),
                              composed_update=g0.composed_update, gate_kind=g0.gate_kind,
                              t_last_act=0 if g0.update_info["mlp"] else 3,
-                             lin_w=g0.update_info["lin_w"], lin_ln=g0.update_info["lin_ln"])
+                             lin_w=g0.update_info["lin_w"], lin_ln=g0.update_info["lin_ln"],
+                             evec=g0.edge_vec_dim, emlp=g0.edge_mlp_dim)
 
     def packed_weights(self) -> engine.PackedWeights:
         """Concatenate the projections that share an input into single GEMM operands

@@ -20,7 +20,7 @@ def _net_from_case(cfg, sd):
         sep_htr=cfg.get("sep_htr", True), radial_basis=cfg.get("radial_basis", "expnorm"),
         edge_updates=cfg.get("edge_updates", True), layernorm=cfg.get("layernorm", ""),
         steerable_norm=cfg.get("steerable_norm", ""), edge_ln=cfg.get("edge_ln", ""),
-            activation=cfg.get("activation", "silu"))
+            activation=cfg.get("activation", "silu"), evec_dim=cfg.get("evec_dim"), emlp_dim=cfg.get("emlp_dim"))
     net.load_state_dict(sd, strict=True)
     return net.cuda().eval()
 
@@ -101,7 +101,7 @@ def test_wrapper_matches_golden():
         sep_htr=cfg.get("sep_htr", True), radial_basis=cfg.get("radial_basis", "expnorm"),
         edge_updates=cfg.get("edge_updates", True), layernorm=cfg.get("layernorm", ""),
         steerable_norm=cfg.get("steerable_norm", ""), edge_ln=cfg.get("edge_ln", ""),
-            activation=cfg.get("activation", "silu"))
+            activation=cfg.get("activation", "silu"), evec_dim=cfg.get("evec_dim"), emlp_dim=cfg.get("emlp_dim"))
     net.load_state_dict(sd, strict=True)
     net = net.cuda().eval()
     inp = types.SimpleNamespace(z=t["z"].cuda(), pos=t["pos"].cuda(), batch=t["batch"].cuda())

@@ -85,6 +85,10 @@ CASES = {
     "opt_linw_act_l3": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=3, num_heads=8, scale_edge=False,
                              sep_dir=True, sep_tensor=True, max_z=10, activation="silu", edge_updates="linw_act"),
                         dict(mols=[5, 4], box=2.8, seed=23)),
+    "opt_evec16_emlp48": (dict(n_atom_basis=32, n_interactions=3, n_rbf=8, lmax=2, num_heads=8, scale_edge=False,
+                               sep_dir=True, sep_tensor=True, max_z=10, activation="silu",
+                               edge_updates="mlpa_linwa_postln_gatedt", edge_ln="layer", evec_dim=16, emlp_dim=48),
+                          dict(mols=[6, 5], box=3.0, seed=24)),
 }
 
 CUTOFF = 5.0
