@@ -56,28 +56,29 @@ __device__ __forceinline__ float group_sum(float v, int width) {
 // Sum K values (K a power of two, K <= width) over aligned groups of `width` lanes with a
 // value-halving butterfly: ~K + log2(width) shuffles instead of K log2(width).  On return the lane
 // whose in-group index lp satisfies lp % (width / K) == 0 holds the total of value lp / (width / K) in v[0].
-template <int K>
-__device__ __forceinline__ void multi_group_sum(float (&v)[K], int width, int lp) {
+// (every register index below is a compile-time constant: a formulation with a run-time trip count made the
+//  compiler index v[] dynamically -- a 16-way v_cmp/v_cndmask chain per element, ~900 VALU instructions per edge.)
+template <int LIVE, int K>
+__device__ __forceinline__ void mgs_halve(float (&v)[K], int off, int lp) {   // LIVE live values -> LIVE / 2
+    const bool up = (lp & off) != 0;
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const int off = width >> (s + 1);
-        if (off == 0) break;
-        constexpr int dummy = 0; (void)dummy;
-        const int k = (K >> s) > 1 ? (K >> s) : 1;       // live values before this step (compile-time after unroll)
-        if (k > 1) {
-            const int half = k >> 1;
-            const bool up = (lp & off) != 0;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                if (i >= half) break;
-                const float keep = up ? v[i + half] : v[i];
-                const float send = up ? v[i] : v[i + half];
-                v[i] = keep + __shfl_xor(send, off, GN_WAVE);
-            }
-        } else {
-            v[0] += __shfl_xor(v[0], off, GN_WAVE);
-        }
+    for (int i = 0; i < LIVE / 2; ++i) {
+        const float a = v[i], b = v[i + LIVE / 2];
+        const float keep = up ? b : a;
+        const float send = up ? a : b;
+        v[i] = keep + __shfl_xor(send, off, GN_WAVE);
     }
+}
+template <int K>
+__device__ __forceinline__ void multi_group_sum(float (&v)[K], int width, int lp) {   // requires width >= K
+    static_assert(K == 2 || K == 4 || K == 8 || K == 16 || K == 32, "K must be a power of two <= 32");
+    int off = width >> 1;
+    if constexpr (K >= 32) { mgs_halve<32>(v, off, lp); off >>= 1; }
+    if constexpr (K >= 16) { mgs_halve<16>(v, off, lp); off >>= 1; }
+    if constexpr (K >= 8) { mgs_halve<8>(v, off, lp); off >>= 1; }
+    if constexpr (K >= 4) { mgs_halve<4>(v, off, lp); off >>= 1; }
+    mgs_halve<2>(v, off, lp);
+    for (off >>= 1; off > 0; off >>= 1) v[0] += __shfl_xor(v[0], off, GN_WAVE);
 }
 
 __device__ __forceinline__ float wave_max(float v) {
