@@ -196,8 +196,9 @@ template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
 __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p) {
     using S = MsgShape<LMAX, SEP_DIR, SEP_TENSOR>;
     constexpr int D = S::D, M = S::M;
-    constexpr int KP = (D + 8) <= 16 ? 16 : 32;      // D rl sums + 8 head sums, padded to a power of two
+    constexpr int KP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));      // D rl sums, padded to a power of two
     __shared__ __attribute__((aligned(16))) float red[1024];
+    __shared__ float hsum[256 * M];
     const int N = p.N, F = p.F, H = p.H;
     const int i = xcd_item(blockIdx.x, N);
     if (i < 0) return;
@@ -255,38 +256,34 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
         }
         cutp = group_sum(cutp, lps);
         if (lp == 0) p.g_cut[e] = cutp;
-        if (H <= 8 && lps >= KP) {                   // D rl sums + up to 8 head sums in one butterfly
+        // head sums: head h owns the flattened float4 positions [h PH, (h+1) PH) of the (block, lane) grid,
+        // PH = M lps / H.  Stage the M per-lane partials in LDS (a slot never spans waves: wave-ordered LDS
+        // accesses, no barrier), lps / H reader lanes per head add M consecutive entries each, then a short
+        // butterfly.  (Per-head selects cost 8 M compare/select pairs per edge and 77 spilled mask SGPRs.)
+        {
+            float* hrow = hsum + slot * (M * lps);
+#pragma unroll
+            for (int b = 0; b < M; ++b) hrow[b * lps + lp] = pa_h[b];
+            const int rpl = lps / H, hh = lp / rpl, part = lp - hh * rpl;
+            const float* hp = hrow + hh * (M * rpl) + part * M;
+            float hv = hp[0];
+#pragma unroll
+            for (int k = 1; k < M; ++k) hv += hp[k];
+            hv = group_sum(hv, rpl);
+            if (part == 0) p.g_s[(size_t)e * H + hh] = hv;
+        }
+        if (lps >= KP) {                             // D rl sums in one butterfly
             float vals[KP];
 #pragma unroll
-            for (int m = 0; m < D; ++m) vals[m] = rlp[m];
-#pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                float val = 0.f;
-#pragma unroll
-                for (int b = 0; b < M; ++b) val += (hb[b] == h) ? pa_h[b] : 0.f;
-                vals[D + h] = val;
-            }
-#pragma unroll
-            for (int m = D + 8; m < KP; ++m) vals[m] = 0.f;
+            for (int m = 0; m < KP; ++m) vals[m] = m < D ? rlp[m] : 0.f;
             multi_group_sum<KP>(vals, lps, lp);
             const int stride = lps / KP;
-            if ((lp & (stride - 1)) == 0) {
-                const int idx = lp / stride;
-                if (idx < D) p.g_rl[(size_t)e * D + idx] = vals[0];
-                else if (idx - D < H) p.g_s[(size_t)e * H + idx - D] = vals[0];
-            }
+            if ((lp & (stride - 1)) == 0 && lp / stride < D) p.g_rl[(size_t)e * D + lp / stride] = vals[0];
         } else {
 #pragma unroll
             for (int m = 0; m < D; ++m) {
                 const float s = group_sum(rlp[m], lps);
                 if (lp == 0) p.g_rl[(size_t)e * D + m] = s;
-            }
-            for (int h = 0; h < H; ++h) {
-                float val = 0.f;
-#pragma unroll
-                for (int b = 0; b < M; ++b) val += (hb[b] == h) ? pa_h[b] : 0.f;
-                val = group_sum(val, lps);
-                if (lp == 0) p.g_s[(size_t)e * H + h] = val;
             }
         }
     }
