@@ -14,6 +14,7 @@
 // 351-364 + 561-611 (HTR), 716-748 (EQFF), layers.py:1658-1714 (init),
 // layers.py:133-152, 744-746, 805-902 (cutoff, RBF, harmonics).
 #include "gn_common.h"
+#include "gn_tune.h"
 #include "gn_sh.h"
 
 namespace gn {
@@ -40,7 +41,7 @@ __device__ __forceinline__ void reduce_rows(float4 (&acc)[ROWS], float* red, int
 // =========================================================================== HTR backward
 // w = sum_l [ A.B - (2 - r.r)(A.r)(B.r) ],  A = EQ_i block, B = EK_j block, r = rl block
 template <int LMAX>
-__global__ __launch_bounds__(256) void htr_bwd_target_kernel(
+__global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT) void htr_bwd_target_kernel(
     const float* __restrict__ gtp, const float* __restrict__ pre_t, const float* __restrict__ w,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
     const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F,
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void htr_bwd_target_kernel(
 }
 
 template <int LMAX>
-__global__ __launch_bounds__(256) void htr_bwd_source_kernel(
+__global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_SRC) void htr_bwd_source_kernel(
     const float* __restrict__ gtp, const float* __restrict__ pre_t,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
     const int* __restrict__ colptr, const int* __restrict__ perm, const int* __restrict__ dst, int N, int F,
@@ -192,8 +193,10 @@ struct MsgBwdArgs {
 };
 
 // by-target pass: g_tf, g_cut, g_rl, attention backward (g_a -> g_s), g_ta, g_q
+// (body in a forceinline function with __restrict__ parameters: with the pointers read from the argument struct the
+//  compiler had to assume that the g_eproj stores alias every later load and issued the row loads one at a time)
 template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
-__global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p) {
+__device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, const float* __restrict__ x_, const float* __restrict__ v_, const float* __restrict__ eproj_, const float* __restrict__ a_, const float* __restrict__ qk_, const float* __restrict__ X_in_, const float* __restrict__ rl_, const float* __restrict__ cut_, const int* __restrict__ outdeg_, const float* __restrict__ g_h1_, const float* __restrict__ g_X1_, const int* __restrict__ rowptr_, const int* __restrict__ src_, float* __restrict__ g_eproj_, float* __restrict__ g_s_, float* __restrict__ g_nproj_, float* __restrict__ g_rl_, float* __restrict__ g_cut_) {
     using S = MsgShape<LMAX, SEP_DIR, SEP_TENSOR>;
     constexpr int D = S::D, M = S::M;
     constexpr int KP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));      // D rl sums, padded to a power of two
@@ -204,28 +207,28 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
     if (i < 0) return;
     const int lps = F >> 2, ns = 256 / lps;
     const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
-    const int e0 = p.rowptr[i], e1 = p.rowptr[i + 1];
+    const int e0 = rowptr_[i], e1 = rowptr_[i + 1];
     const int per_head = (M * F) / H;
     int hb[M];
 #pragma unroll
     for (int b = 0; b < M; ++b) hb[b] = (b * F + c0) / per_head;
 
-    const float4 gdh = ld4(p.g_h1 + (size_t)i * F + c0);
+    const float4 gdh = ld4(g_h1_ + (size_t)i * F + c0);
     float4 gdX[D];
 #pragma unroll
-    for (int m = 0; m < D; ++m) gdX[m] = ld4(p.g_X1 + ((size_t)i * D + m) * F + c0);
+    for (int m = 0; m < D; ++m) gdX[m] = ld4(g_X1_ + ((size_t)i * D + m) * F + c0);
 
     // ---- phase 1: per-edge gate gradients
     for (int e = e0 + slot; e < e1; e += ns) {
-        const int j = p.src[e];
-        const float ce = p.cut[e];
-        const float* xr = p.x + (size_t)j * p.ldxv + c0;
-        const float* vr = p.v + (size_t)j * p.ldxv + c0;
-        const float* tr = p.eproj + (size_t)e * p.lde + F + c0;
-        float* gtr = p.g_eproj + (size_t)e * p.lde + F + c0;
-        const float* ar = p.a + (size_t)e * H;
-        const float* Xj = p.X_in + (size_t)j * D * F + c0;
-        const float* re = p.rl + (size_t)e * D;
+        const int j = src_[e];
+        const float ce = cut_[e];
+        const float* xr = x_ + (size_t)j * p.ldxv + c0;
+        const float* vr = v_ + (size_t)j * p.ldxv + c0;
+        const float* tr = eproj_ + (size_t)e * p.lde + F + c0;
+        float* gtr = g_eproj_ + (size_t)e * p.lde + F + c0;
+        const float* ar = a_ + (size_t)e * H;
+        const float* Xj = X_in_ + (size_t)j * D * F + c0;
+        const float* re = rl_ + (size_t)e * D;
         float pa_h[M];
         float cutp = 0.f;
         float rlp[D];
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
             }
         }
         cutp = group_sum(cutp, lps);
-        if (lp == 0) p.g_cut[e] = cutp;
+        if (lp == 0) g_cut_[e] = cutp;
         // head sums: head h owns the flattened float4 positions [h PH, (h+1) PH) of the (block, lane) grid,
         // PH = M lps / H.  Stage the M per-lane partials in LDS (a slot never spans waves: wave-ordered LDS
         // accesses, no barrier), lps / H reader lanes per head add M consecutive entries each, then a short
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
 #pragma unroll
             for (int k = 1; k < M; ++k) hv += hp[k];
             hv = group_sum(hv, rpl);
-            if (part == 0) p.g_s[(size_t)e * H + hh] = hv;
+            if (part == 0) g_s_[(size_t)e * H + hh] = hv;
         }
         if (lps >= KP) {                             // D rl sums in one butterfly
             float vals[KP];
@@ -278,12 +281,12 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
             for (int m = 0; m < KP; ++m) vals[m] = m < D ? rlp[m] : 0.f;
             multi_group_sum<KP>(vals, lps, lp);
             const int stride = lps / KP;
-            if ((lp & (stride - 1)) == 0 && lp / stride < D) p.g_rl[(size_t)e * D + lp / stride] = vals[0];
+            if ((lp & (stride - 1)) == 0 && lp / stride < D) g_rl_[(size_t)e * D + lp / stride] = vals[0];
         } else {
 #pragma unroll
             for (int m = 0; m < D; ++m) {
                 const float s = group_sum(rlp[m], lps);
-                if (lp == 0) p.g_rl[(size_t)e * D + m] = s;
+                if (lp == 0) g_rl_[(size_t)e * D + m] = s;
             }
         }
     }
@@ -293,35 +296,40 @@ __global__ __launch_bounds__(256) void msg_bwd_target_kernel(const MsgBwdArgs p)
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         for (int h = wave; h < H; h += 4) {
             float dot = 0.f;
-            for (int e = e0 + lane; e < e1; e += 64) dot += p.a[(size_t)e * H + h] * p.g_s[(size_t)e * H + h];
+            for (int e = e0 + lane; e < e1; e += 64) dot += a_[(size_t)e * H + h] * g_s_[(size_t)e * H + h];
             dot = wave_sum(dot);
             for (int e = e0 + lane; e < e1; e += 64) {
-                const float nrm = p.outdeg ? sqrtf((float)p.outdeg[p.src[e]]) * p.inv_sqrt_f : p.inv_sqrt_f;
-                const float av = p.a[(size_t)e * H + h];
-                p.g_s[(size_t)e * H + h] = av * p.g_s[(size_t)e * H + h] - (av / nrm) * dot;
+                const float nrm = outdeg_ ? sqrtf((float)outdeg_[src_[e]]) * p.inv_sqrt_f : p.inv_sqrt_f;
+                const float av = a_[(size_t)e * H + h];
+                g_s_[(size_t)e * H + h] = av * g_s_[(size_t)e * H + h] - (av / nrm) * dot;
             }
         }
     }
     __syncthreads();
     // ---- phase 3: scores backward: g_ta (pre-SiLU' factor), g_q
     const int hq = c0 / (F / H);
-    const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
+    const float4 qi = ld4(qk_ + (size_t)i * p.ldqk + c0);
     float4 gq = zero4();
     for (int e = e0 + slot; e < e1; e += ns) {
-        const float gs = p.g_s[(size_t)e * H + hq];
-        const float4 kj = ld4(p.qk + (size_t)p.src[e] * p.ldqk + F + c0);
-        const float4 pta = ld4(p.eproj + (size_t)e * p.lde + c0);
+        const float gs = g_s_[(size_t)e * H + hq];
+        const float4 kj = ld4(qk_ + (size_t)src_[e] * p.ldqk + F + c0);
+        const float4 pta = ld4(eproj_ + (size_t)e * p.lde + c0);
         gq = fma4(gs, kj * silu4(pta), gq);
-        st4(p.g_eproj + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dsilu4(pta));   // d/d(pre-activation of t_attn)
+        st4(g_eproj_ + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dsilu4(pta));   // d/d(pre-activation of t_attn)
     }
     st4(&red[slot * F + c0], gq);
     __syncthreads();
-    if (slot == 0) st4(p.g_nproj + (size_t)i * p.ldn + c0, red4(red, c0, F, ns));
+    if (slot == 0) st4(g_nproj_ + (size_t)i * p.ldn + c0, red4(red, c0, F, ns));
+}
+
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
+__global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_TGT) void msg_bwd_target_kernel(const MsgBwdArgs p) {
+    msg_bwd_target_body<LMAX, SEP_DIR, SEP_TENSOR>(p, p.x, p.v, p.eproj, p.a, p.qk, p.X_in, p.rl, p.cut, p.outdeg, p.g_h1, p.g_X1, p.rowptr, p.src, p.g_eproj, p.g_s, p.g_nproj, p.g_rl, p.g_cut);
 }
 
 // by-source pass: g_x, g_v, g_k, and g_X (tensor-gate path) of the gathered source rows
 template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
-__global__ __launch_bounds__(256) void msg_bwd_source_kernel(const MsgBwdArgs p) {
+__global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kernel(const MsgBwdArgs p) {
     using S = MsgShape<LMAX, SEP_DIR, SEP_TENSOR>;
     constexpr int D = S::D, M = S::M;
     constexpr int ROWS = 2 * M + D + 1;
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(256) void msg_bwd_source_kernel(const MsgBwdArgs p)
 // source-pass launch per group, plus one attention-backward launch (softmax backward needs the head
 // sums of ALL groups).  Value blocks: 0 scalar, l direction gate, LMAX + l tensor gate.
 template <int LMAX, int LLO, int LHI, bool SCALAR>
-__global__ __launch_bounds__(256) void msg_bwd_target_group_kernel(const MsgBwdArgs p, float* __restrict__ ga_slice,
+__global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_TGT_G) void msg_bwd_target_group_kernel(const MsgBwdArgs p, float* __restrict__ ga_slice,
                                                                   float* __restrict__ cut_slice) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int M = 1 + 2 * LMAX;
@@ -533,7 +541,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const MsgBwdArgs p, const
 }
 
 template <int LMAX, int LLO, int LHI, bool SCALAR>
-__global__ __launch_bounds__(256) void msg_bwd_source_group_kernel(const MsgBwdArgs p) {
+__global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC_G) void msg_bwd_source_group_kernel(const MsgBwdArgs p) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int M = 1 + 2 * LMAX;
     constexpr int NL = LHI - LLO + 1;
@@ -614,7 +622,7 @@ __global__ __launch_bounds__(256) void msg_bwd_source_group_kernel(const MsgBwdA
 
 // HTR backward per degree group (w = sum_l w_l: the degrees are independent)
 template <int LMAX, int LLO, int LHI, bool FIRST>
-__global__ __launch_bounds__(256) void htr_bwd_target_group_kernel(
+__global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT_G) void htr_bwd_target_group_kernel(
     const float* __restrict__ gtp, const float* __restrict__ pre_t, const float* __restrict__ w,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
     const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F,
@@ -679,7 +687,7 @@ __global__ __launch_bounds__(256) void htr_bwd_target_group_kernel(
 }
 
 template <int LMAX, int LLO, int LHI>
-__global__ __launch_bounds__(256) void htr_bwd_source_group_kernel(
+__global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_SRC_G) void htr_bwd_source_group_kernel(
     const float* __restrict__ gtp, const float* __restrict__ pre_t,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
     const int* __restrict__ colptr, const int* __restrict__ perm, const int* __restrict__ dst, int N, int F,

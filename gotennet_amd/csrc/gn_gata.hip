@@ -8,12 +8,13 @@
 // Workgroup -> target mapping is XCD-aware (gn::xcd_item) so the source rows of one
 // molecule are re-read through a single XCD's L2.
 #include "gn_common.h"
+#include "gn_tune.h"
 
 namespace gn {
 
 // ------------------------------------------------------------------ attention weights
 // reference gotennet.py:497-511 + PyG softmax.  a[e,h] holds raw scores between the two phases.
-__global__ __launch_bounds__(256) void attn_softmax_kernel(
+__global__ __launch_bounds__(256) GN_WPE(GN_W_ATTN) void attn_softmax_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int ldqk,
     const float* __restrict__ ta, int ldt,
     const int* __restrict__ rowptr, const int* __restrict__ src, const int* __restrict__ outdeg,
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(
 // M F-wide blocks of the value vector: 0 = scalar; direction gate of degree l: block
 // (SEP_DIR ? l : 1); tensor gate: block TB0 + (SEP_TENSOR ? l-1 : 0), TB0 = 1 + (SEP_DIR ? LMAX : 1).
 template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
-__global__ __launch_bounds__(256) void message_aggregate_kernel(
+__global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
     const float* __restrict__ x, const float* __restrict__ v, int ldxv,
     const float* __restrict__ tf, int ldt, const float* __restrict__ a,
     const float* __restrict__ rl, const float* __restrict__ cut,
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void message_aggregate_kernel(
 // keeps <= 9 float4 accumulators per lane (3+ waves/SIMD instead of 2 at 246 VGPRs).  Gates are
 // per degree, so the groups re-read nothing but the per-edge scalars.
 template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR>
-__global__ __launch_bounds__(256) void message_aggregate_group_kernel(
+__global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G) void message_aggregate_group_kernel(
     const float* __restrict__ x, const float* __restrict__ v, int ldxv,
     const float* __restrict__ tf, int ldt, const float* __restrict__ a,
     const float* __restrict__ rl, const float* __restrict__ cut,
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void message_aggregate_group_kernel(
 // ------------------------------------------------------------------ K7 HTR edge weights
 // gotennet.py:351-364, 580-609 (sep_htr, rejection on): literal two-rejection form.
 template <int LMAX>
-__global__ __launch_bounds__(256) void htr_edge_kernel(
+__global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_EDGE) void htr_edge_kernel(
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
     const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F, float* __restrict__ w) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;

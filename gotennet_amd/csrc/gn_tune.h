@@ -1,0 +1,57 @@
+// gn_tune.h -- per-kernel occupancy targets (waves per SIMD) for the gather kernels.
+// The AMDGPU scheduler sizes its load batches by the occupancy it believes it must keep: told "2 waves/SIMD"
+// it keeps up to ~23 row loads of an edge in flight (184 VGPRs) instead of ~6 (136 VGPRs), which is what a
+// latency-bound gather wants; other kernels are best left alone or run better with MORE, thinner waves.
+// Values measured on MI355X with tools/tune_sweep.sh (0 = no hint); -DGN_W_<KERNEL>=n overrides for a sweep.
+#pragma once
+
+#define GN_WPE_ATTR(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+
+#ifndef GN_W_K6
+#define GN_W_K6 2          // message_aggregate_kernel: 117.5 -> 105.1 us (lmax=2)
+#endif
+#ifndef GN_W_K6_G
+#define GN_W_K6_G 3        // message_aggregate_group_kernel: 290 -> 250 (2) -> 234 us (3) per layer (lmax=4, three launches)
+#endif
+#ifndef GN_W_MSG_TGT
+#define GN_W_MSG_TGT 0     // 2: 333 -> 348 us (message backward, both passes)
+#endif
+#ifndef GN_W_MSG_SRC
+#define GN_W_MSG_SRC 0     // 1: +37 us, 2: within noise, 3: +47 us, 4: +200 us
+#endif
+#ifndef GN_W_MSG_TGT_G
+#define GN_W_MSG_TGT_G 0
+#endif
+#ifndef GN_W_MSG_SRC_G
+#define GN_W_MSG_SRC_G 2   // message backward (lmax=4, all passes): 856 -> 711 us per layer (3: 740)
+#endif
+#ifndef GN_W_HTR_TGT
+#define GN_W_HTR_TGT 0     // 2, 3: within noise; 4: 140 -> 268 us
+#endif
+#ifndef GN_W_HTR_SRC
+#define GN_W_HTR_SRC 0
+#endif
+#ifndef GN_W_HTR_TGT_G
+#define GN_W_HTR_TGT_G 0
+#endif
+#ifndef GN_W_HTR_SRC_G
+#define GN_W_HTR_SRC_G 0
+#endif
+#ifndef GN_W_HTR_EDGE
+#define GN_W_HTR_EDGE 0    // 2: +4 us; 4: lmax=4 104 -> 192 us
+#endif
+#ifndef GN_W_ATTN
+#define GN_W_ATTN 0        // 2: 29 -> 55 us; 4: 37 us
+#endif
+
+#define GN_TUNE_CAT_(a, b) a##b
+#define GN_TUNE_CAT(a, b) GN_TUNE_CAT_(a, b)
+#define GN_WPE_SEL_0
+#define GN_WPE_SEL_1 GN_WPE_ATTR(1)
+#define GN_WPE_SEL_2 GN_WPE_ATTR(2)
+#define GN_WPE_SEL_3 GN_WPE_ATTR(3)
+#define GN_WPE_SEL_4 GN_WPE_ATTR(4)
+#define GN_WPE_SEL_5 GN_WPE_ATTR(5)
+#define GN_WPE_SEL_6 GN_WPE_ATTR(6)
+#define GN_WPE_SEL_8 GN_WPE_ATTR(8)
+#define GN_WPE(n) GN_TUNE_CAT(GN_WPE_SEL_, n)
