@@ -192,18 +192,47 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
         if (gn < p.N) {
             const float4 bias4 = p.bias ? ld4(p.bias + gn) : zero4();
             const bool act = gn >= p.act_lo && gn < p.act_hi;          // act ranges are multiples of 4
+            if (p.res || p.gate) {
+                // four rows per pass, all residual / gate loads of the pass issued BEFORE its first store: the
+                // stores may alias them as far as the compiler knows (res == C is allowed), and a load behind
+                // a store was one exposed round trip per row
+                constexpr int ITS = (BM * C4) / 256, UN = ITS < 4 ? ITS : 4;
+                for (int it0 = 0; it0 < ITS; it0 += UN) {
+                    size_t off[UN];
+                    bool ok[UN];
+                    float4 rv[UN], gv[UN];
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        const int gm = m0 + (it0 + u) * (256 / C4) + tid / C4;
+                        ok[u] = gm < p.M;
+                        off[u] = (size_t)phys_row(p, ok[u] ? gm : 0) * p.ldc + gn;
+                        rv[u] = (ok[u] && p.res) ? ld4(p.res + off[u]) : zero4();
+                        gv[u] = (ok[u] && p.gate) ? ld4(p.gate + off[u]) : zero4();
+                    }
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        if (!ok[u]) continue;
+                        const int row = (it0 + u) * (256 / C4) + tid / C4;
+                        float4 v = ld4(&smem[row * CP + cc]) + bias4;
+                        if (p.pre_out) st4(p.pre_out + off[u], v);
+                        if (act) v = silu4(v);
+                        if (p.gate) v = v * (p.gate_mode ? dsilu4(gv[u]) : gv[u]);
+                        if (p.res) v = rv[u] + v;
+                        st4(p.C + off[u], v);
+                    }
+                }
+            } else {
 #pragma unroll 4
-            for (int it = 0; it < (BM * C4) / 256; ++it) {
-                const int row = it * (256 / C4) + tid / C4;
-                const int gm = m0 + row;
-                if (gm >= p.M) continue;
-                float4 v = ld4(&smem[row * CP + cc]) + bias4;
-                const size_t off = (size_t)phys_row(p, gm) * p.ldc + gn;
-                if (p.pre_out) st4(p.pre_out + off, v);
-                if (act) v = silu4(v);
-                if (p.gate) v = v * (p.gate_mode ? dsilu4(ld4(p.gate + off)) : ld4(p.gate + off));
-                if (p.res) v = ld4(p.res + off) + v;
-                st4(p.C + off, v);
+                for (int it = 0; it < (BM * C4) / 256; ++it) {
+                    const int row = it * (256 / C4) + tid / C4;
+                    const int gm = m0 + row;
+                    if (gm >= p.M) continue;
+                    float4 v = ld4(&smem[row * CP + cc]) + bias4;
+                    const size_t off = (size_t)phys_row(p, gm) * p.ldc + gn;
+                    if (p.pre_out) st4(p.pre_out + off, v);
+                    if (act) v = silu4(v);
+                    st4(p.C + off, v);
+                }
             }
         }
     }
