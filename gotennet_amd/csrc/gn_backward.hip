@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_SRC) void htr_bwd_source_kerne
     for (int pp = p0 + slot; pp < p1; pp += ns) {
         const int e = perm[pp];
         const float4 gw = ld4(gtp + (size_t)e * F + c0) * silu4(ld4(pre_t + (size_t)e * F + c0));
-        const float* qi = EQ + (size_t)dst[e] * D * F + c0;
+        const float* qi = EQ + (size_t)dst[pp] * D * F + c0;
         const float* re = rl + (size_t)e * D;
         int m0 = 0;
 #pragma unroll
@@ -180,7 +180,8 @@ struct MsgBwdArgs {
     // upstream gradients
     const float* g_h1; const float* g_X1;              // [N,F], [N,D,F]
     // graph
-    const int* rowptr; const int* src; const int* dst; const int* colptr; const int* perm;
+    const int* rowptr; const int* src; const int* dst;   // dst: target of the pp-th BY-SOURCE entry (= CSR dst[perm[pp]])
+    const int* colptr; const int* perm;
     // outputs
     float* g_eproj;                                    // [E, (1+M) F]: d/d(W_re t + b) | d/d t_filter
     float* g_s;                                        // [E, H] scratch: g_a then g_s
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kerne
 
     for (int pp = p0 + slot; pp < p1; pp += ns) {
         const int e = p.perm[pp];
-        const int i = p.dst[e];
+        const int i = p.dst[pp];
         const float ce = p.cut[e];
         // own rows re-read per edge (L1-resident) instead of pinned in registers
         const float* xr = p.x + (size_t)j * p.ldxv + c0;
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC_G) void msg_bwd_source_gro
 
     for (int pp = p0 + slot; pp < p1; pp += ns) {
         const int e = p.perm[pp];
-        const int i = p.dst[e];
+        const int i = p.dst[pp];
         const float ce = p.cut[e];
         const float* xr = p.x + (size_t)j * p.ldxv + c0;
         const float* vr = p.v + (size_t)j * p.ldxv + c0;
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_SRC_G) void htr_bwd_source_gro
     for (int pp = colptr[j] + slot; pp < colptr[j + 1]; pp += ns) {
         const int e = perm[pp];
         const float4 gw = ld4(gtp + (size_t)e * F + c0) * silu4(ld4(pre_t + (size_t)e * F + c0));
-        const float* qi = EQ + (size_t)dst[e] * D * F + c0;
+        const float* qi = EQ + (size_t)dst[pp] * D * F + c0;
         const float* re = rl + (size_t)e * D;
 #pragma unroll
         for (int l = LLO; l <= LHI; ++l) {

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void htr_bwd_source_general_kernel(
             gw = gw * silu4o(ld4(pre_t + (size_t)e * F + c0));
             if (gate) gw = gw * dgate4(ld4(w_raw + (size_t)e * F + c0), gate);
         }
-        const float* qi = EQ + (size_t)dst[e] * D * F + c0;
+        const float* qi = EQ + (size_t)dst[pp] * D * F + c0;
         const float* re = rl + (size_t)e * D;
         float4 pa[LMAX];
         float rr[LMAX];

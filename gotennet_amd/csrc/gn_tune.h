@@ -17,7 +17,7 @@
 #define GN_W_MSG_TGT 0     // 2: 333 -> 348 us (message backward, both passes)
 #endif
 #ifndef GN_W_MSG_SRC
-#define GN_W_MSG_SRC 0     // 1: +37 us, 2: within noise, 3: +47 us, 4: +200 us
+#define GN_W_MSG_SRC 2     // without it the scheduler serialises every row load to reach 3 waves/SIMD: 393 -> 327 us (both passes)
 #endif
 #ifndef GN_W_MSG_TGT_G
 #define GN_W_MSG_TGT_G 0

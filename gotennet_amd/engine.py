@@ -202,7 +202,7 @@ class Graph:
         call("gn_edge_geometry", ptr(edge_vec), ptr(edge_diff), ptr(self.src), ptr(self.dst), E,
              cfg.lmax, cfg.R, cfg.basis, ptr(pw.rb0), ptr(pw.rb1), float(cfg.cutoff),
              ptr(self.rl), ptr(self.phi), ptr(self.cut), _stream())
-        self.perm = self.colptr = None
+        self.perm = self.colptr = self.tgt_by_src = None
 
     def csc(self):
         """Edges grouped by source (stable): integer index plumbing, no host sync."""
@@ -211,6 +211,7 @@ class Graph:
             cnt = torch.bincount(self.src, minlength=self.N)
             self.colptr = torch.zeros(self.N + 1, dtype=torch.int32, device=self.src.device)
             self.colptr[1:] = torch.cumsum(cnt, 0)
+            self.tgt_by_src = self.dst[self.perm.long()].contiguous()   # target of each by-source entry
         return self.colptr, self.perm
 
 
@@ -474,11 +475,11 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
             if cfg.composed_update:                # gt_a = gt + gamma_t backward; g_w = gamma_w backward
                 g_w = _edge_update_composed_backward(cfg, lw, lt, gt, gt_a, E)
                 call("gn_htr_backward", ptr(g_w), None, None, None, ptr(lt.EQ), ptr(lt.EK), ptr(g.rl),
-                     ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm), N, Fe, lmax, cfg.htr_mode | 16,
+                     ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm), N, Fe, lmax, cfg.htr_mode | 16,
                      ptr(gEQ), ptr(gEK), rl_slice(L + li), None, _stream())
             else:
                 call("gn_htr_backward", ptr(gt), ptr(lt.pre_t), ptr(lt.w), ptr(lt.w_raw), ptr(lt.EQ), ptr(lt.EK),
-                     ptr(g.rl), ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm), N, Fe, lmax,
+                     ptr(g.rl), ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm), N, Fe, lmax,
                      cfg.htr_mode, ptr(gEQ), ptr(gEK), rl_slice(L + li), ptr(g_pre_t), _stream())
             gemm(gEQ, Fe, _T(lw, "Wvq"), None, gX1, F_, N * D, F_, Fe, res=gX1)
             off = 0
@@ -502,7 +503,7 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
         # ---- message backward
         call("gn_message_backward", ptr(lt.xs), ptr(lt.vs), M * F_, ptr(lt.eproj), lde, ptr(lt.attn),
              ptr(lt.nproj), 4 * F_, ptr(lt.X_in), ptr(g.rl), ptr(g.cut), ptr(g.outdeg),
-             ptr(gh1), ptr(gX1), ptr(g.rowptr), ptr(g.src), ptr(g.dst), ptr(colptr), ptr(perm),
+             ptr(gh1), ptr(gX1), ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm),
              ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), ptr(gX2), rl_slice(li), cut_slice(G * li),
              ptr(ga_parts), E,
              N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())

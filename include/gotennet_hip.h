@@ -174,7 +174,9 @@ int gn_eqff_context(const float* h, const float* Xp, float eps, int N, int F, in
 int gn_eqff_update(const float* m, const float* Xp, int N, int F, int D, float* h, float* X, void* stream);
 
 /* ---- K10 force backward (input gradients only; what torch.autograd.grad does for the reference at
- *      outputs.py:365-375).  Needs the by-source (CSC) view: perm[colptr[j] .. colptr[j+1]) lists the CSR
+ *      outputs.py:365-375).  Needs the by-source (CSC) view: tgt_by_src[pp] is the TARGET of by-source entry pp
+ *      (= dst[perm[pp]], stored so that the source passes chase one index less per edge) and
+ *      perm[colptr[j] .. colptr[j+1]) lists the CSR
  *      edge ids whose source is j.  F <= 256.  Every kernel WRITES its g_rl [E,D] / g_cut [E] contribution to
  *      the slice it is given (plain stores, no read-modify-write); gn_edge_geometry_backward sums the slices. */
 
@@ -182,7 +184,7 @@ int gn_eqff_update(const float* m, const float* Xp, int N, int F, int D, float* 
  * rl, and g_pre_t = g_t_out * w * SiLU'(pre_t) [E,F] (the operand of the W_t^T product). */
 int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* w, const float* w_raw,
                     const float* EQ, const float* EK,
-                    const float* rl, const int* rowptr, const int* src, const int* dst,
+                    const float* rl, const int* rowptr, const int* src, const int* tgt_by_src,
                     const int* colptr, const int* perm, int N, int F, int lmax, int mode,
                     float* gEQ, float* gEK, float* g_rl, float* g_pre_t, void* stream);
 
@@ -194,7 +196,7 @@ int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* w, co
 int gn_message_backward(const float* x, const float* v, int ldxv, const float* eproj, int lde, const float* a,
                         const float* qk, int ldqk, const float* X_in, const float* rl, const float* cut,
                         const int* outdeg, const float* g_h1, const float* g_X1,
-                        const int* rowptr, const int* src, const int* dst, const int* colptr, const int* perm,
+                        const int* rowptr, const int* src, const int* tgt_by_src, const int* colptr, const int* perm,
                         float* g_eproj, float* g_s, float* g_nproj, int ldn, float* g_x, float* g_v,
                         float* g_X_out, float* g_rl, float* g_cut, float* ga_parts, long E,
                         int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream);
