@@ -263,6 +263,7 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
 
     X = torch.zeros((N, D, F_), **f32)            # gotennet.py:992
     lde = (1 + M) * F_
+    nact, g1act = new(N, 4 * F_), new(N, F_)       # activated copies (scratch, shared by all layers)
     if not save:                                   # inference: ping-pong work buffers, reused by every layer
         h2, X2, t2 = new(N, F_), new(N, D, F_), new(E, F_)
         nproj, xs, vs = new(N, 4 * F_), new(N, M * F_), new(N, M * F_)
@@ -298,13 +299,15 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
             lt.Xp, lt.ctx, lt.pre_g1, lt.mm = Xp, ctx, pre_g1, mm
         # ---- GATA projections (gotennet.py:400-407); SiLU applied by the consumers
         with _Side(dev) as fork:                   # atom-sized projections || edge projection
-            gemm(h, F_, lw.Wn1, lw.bn1, nproj, 4 * F_, N, 4 * F_, F_)
-            gemm(nproj, 4 * F_, lw.Ws2, lw.bs2, xs, M * F_, N, M * F_, F_, a_off=2 * F_, pro=(1, 0, F_))
-            gemm(nproj, 4 * F_, lw.Wv2, lw.bv2, vs, M * F_, N, M * F_, F_, a_off=3 * F_, pro=(1, 0, F_))
+            # SiLU of the two hidden blocks is applied ONCE by this epilogue (a SiLU prologue in the two products
+            # below would redo it for each of their 4M column tiles); the pre-activation copy is what backward needs
+            gemm(h, F_, lw.Wn1, lw.bn1, nact, 4 * F_, N, 4 * F_, F_, act=(2 * F_, 4 * F_), pre_out=nproj if save else None)
+            gemm(nact, 4 * F_, lw.Ws2, lw.bs2, xs, M * F_, N, M * F_, F_, a_off=2 * F_)
+            gemm(nact, 4 * F_, lw.Wv2, lw.bv2, vs, M * F_, N, M * F_, F_, a_off=3 * F_)
         gemm(t, F_, lw.We, lw.be, eproj, lde, E, lde, F_)
         fork.join()
         # ---- message / softmax / aggregate / residual (452-559, 613-640, 426-427)
-        call("gn_attn_softmax", ptr(nproj), nproj.data_ptr() + 4 * F_, 4 * F_, ptr(eproj), lde,
+        call("gn_attn_softmax", ptr(nact), nact.data_ptr() + 4 * F_, 4 * F_, ptr(eproj), lde,
              ptr(g.rowptr), ptr(g.src), ptr(g.outdeg), N, F_, H, ptr(attn), _stream())
         call("gn_message_aggregate", ptr(xs), ptr(vs), M * F_, eproj.data_ptr() + 4 * F_, lde,
              ptr(attn), ptr(g.rl), ptr(g.cut), ptr(g.rowptr), ptr(g.src),
@@ -315,8 +318,8 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
         with _Side(dev) as fork:
             gemm(X, F_, lw.Wvu, None, Xp, F_, N * D, F_, F_)
             call("gn_eqff_context", ptr(h), ptr(Xp), float(cfg.eps), N, F_, D, ptr(ctx), _stream())
-            gemm(ctx, 2 * F_, lw.Wm0, lw.bm0, pre_g1, F_, N, F_, 2 * F_)
-            gemm(pre_g1, F_, lw.Wm1, lw.bm1, mm, 2 * F_, N, 2 * F_, F_, pro=(1, 0, F_))
+            gemm(ctx, 2 * F_, lw.Wm0, lw.bm0, g1act, F_, N, F_, 2 * F_, act=(0, F_), pre_out=pre_g1 if save else None)
+            gemm(g1act, F_, lw.Wm1, lw.bm1, mm, 2 * F_, N, 2 * F_, F_)
         # ---- HTR (429-445, 561-611)
         if not last:
             gemm(X, F_, lw.Wvq, None, EQ, Fe, N * D, Fe, F_)
