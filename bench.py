@@ -46,6 +46,8 @@ class KernelTimer:
     def tag_of(name, args):
         if name in ("gn_gemm_ex", "gn_gemm_split"):
             return f"gn_gemm[{args[6]}x{args[7]}x{args[8]}]"
+        if name == "gn_gemm_group":            # several independent problems in one launch
+            return "gn_gemm[" + "+".join(f"{args[0][i].M}x{args[0][i].N}x{args[0][i].K}" for i in range(args[1])) + "]"
         return name
 
     def want(self, name, args):
@@ -236,13 +238,14 @@ def measure(a, lmax, steps, warmup, rank, world, dev, dist):
         for tag in tot:
             if family(tag) != "gn_gemm":
                 continue
-            m_, n_, k_ = (int(v) for v in tag[8:-1].split("x"))
-            flops += 2.0 * m_ * n_ * k_ * cnt[tag]
+            fl = sum(2.0 * m_ * n_ * k_ for m_, n_, k_ in
+                     (tuple(int(v) for v in part.split("x")) for part in tag[8:-1].split("+")))
+            flops += fl * cnt[tag]
             t_ms += tot[tag]
             n += cnt[tag]
             us = 1e3 * tot[tag] / cnt[tag]
             if big is None or tot[tag] > big[1]:
-                big = (tag, tot[tag], us, 2.0 * m_ * n_ * k_ / (us * 1e-6) / 1e12)
+                big = (tag, tot[tag], us, fl / (us * 1e-6) / 1e12)
         ach = flops / (t_ms * 1e-3) / 1e12
         from gotennet_amd import engine as _eng
         exact = _eng.GEMM_MODE == "f32"

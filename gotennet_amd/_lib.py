@@ -18,6 +18,16 @@ ABI_VERSION = 1
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 
 # symbol -> argtypes (mirrors include/gotennet_hip.h one for one)
+class GemmDesc(C.Structure):
+    """gn_gemm_desc of include/gotennet_hip.h (one problem of gn_gemm_group)."""
+    _fields_ = [("A", _P), ("lda", _I), ("W", _P), ("bias", _P), ("C", _P), ("ldc", _I),
+                ("M", _I), ("N", _I), ("K", _I), ("act_lo", _I), ("act_hi", _I),
+                ("row_cnt", _I), ("row_gstride", _I), ("row_goff", _I),
+                ("res", _P), ("gate", _P), ("gate_mode", _I), ("pre_out", _P),
+                ("pro_mode", _I), ("pro_lo", _I), ("pro_hi", _I), ("a_pre", _P), ("ldp", _I),
+                ("a_gate", _P), ("ldg", _I)]
+
+
 SIGNATURES = {
     "gn_abi_version": [C.POINTER(C.c_char_p)],
     "gn_build_csr": [_P, _I, _I, _P, _P, _P, _P],
@@ -35,6 +45,7 @@ SIGNATURES = {
     "gn_eqff_context": [_P, _P, _F, _I, _I, _I, _P, _P],
     "gn_eqff_update": [_P, _P, _I, _I, _I, _P, _P, _P],
     "gn_gemm_ex": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],
+    "gn_gemm_group": [_P, _I, _P],
     "gn_gemm_split": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],
     "gn_split_bf16x3": [_P, C.c_long, _P, _P],
     "gn_htr_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],

@@ -18,6 +18,13 @@ struct GemmArgs {
     int gate_mode;                  // 0: value * gate; 1: value * SiLU'(gate)
 };
 
+constexpr int GN_MAX_GROUP = 4;
+struct GroupArgs {
+    GemmArgs g[GN_MAX_GROUP];       // entries >= n repeat the last problem (never selected)
+    int tile_end[GN_MAX_GROUP];     // running tile count: problem i owns the global tile ids [tile_end[i-1], tile_end[i])
+    int n;
+};
+
 constexpr int BK = 32, PITCH = 36;
 
 __device__ __forceinline__ int phys_row(const GemmArgs& p, int r) {
@@ -29,6 +36,9 @@ __device__ __forceinline__ float4 dsilu4(float4 v) { return make_float4(dsilu(v.
 
 
 }  // namespace gn
+
+// exact-fp32 launcher for a group of n <= GN_MAX_GROUP problems (gn_gemm.hip)
+int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st);
 
 // split kernel launcher (gn_gemm_split.hip); W3 = [3][N][K] bf16 (hi, mid, lo planes)
 int gn_gemm_split_launch(gn::GemmArgs p, const unsigned short* W3, void* stream);

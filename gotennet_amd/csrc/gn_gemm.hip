@@ -27,7 +27,7 @@
 namespace gn {
 
 template <int TM, int TN, bool PRO, int PF>
-__global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
+__global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;       // staged float4 rows per thread
     constexpr int STAGE = (BM + BN) * PITCH;        // floats per K-slab buffer (A rows then W rows)
@@ -35,14 +35,32 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
     constexpr int LDS_FLOATS = (2 * STAGE > BM * CP) ? 2 * STAGE : BM * CP;
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
 
-    // XCD-aware tile order (block b runs on XCD b % 8, speed only): every XCD owns a contiguous range
-    // of row tiles and walks all column tiles of a row tile back to back, so an A row tile is pulled
-    // through ONE L2 instead of all eight.  grid = 8 * ceil(tiles_m / 8) * tiles_n; the excess exits.
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles_m = (p.M + BM - 1) / BM;
-    const int xq = tiles_m >> 3, xr = tiles_m & 7, xcd = blockIdx.x & 7;
-    const int rows_here = xq + (xcd < xr ? 1 : 0);
-    const int row_base = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+    // One launch walks the tiles of up to GN_MAX_GROUP independent problems (a "group": the atom-sized products of
+    // a layer are too small to fill 256 CUs one at a time).  Global tile ids: problem 0's tiles, then problem 1's, ...;
+    // inside a problem row-tile major, so consecutive ids share their A rows.
+    // XCD-aware order (block b runs on XCD b % 8, speed only): every XCD owns a contiguous range of tile ids, so an
+    // A row tile is pulled through ONE L2 instead of all eight.  grid = 8 * ceil(tiles / 8) capped; the excess exits.
+    int tiles_all = ga.tile_end[0];
+#pragma unroll
+    for (int gi = 1; gi < GN_MAX_GROUP; ++gi)
+        if (gi < ga.n) tiles_all = ga.tile_end[gi];
+    const int xq = tiles_all >> 3, xr = tiles_all & 7, xcd = blockIdx.x & 7;
+    const int tiles_here = xq + (xcd < xr ? 1 : 0);
+    const int tile_base = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+    const int tile_stop = tile_base + tiles_here;
+    // the problem a tile id belongs to (ids only grow, so the scan never goes back)
+    GemmArgs p = ga.g[0];
+    int g_begin = 0, g_end = ga.tile_end[0], tiles_n = (p.N + BN - 1) / BN;
+    auto select = [&](int t) {
+#pragma unroll
+        for (int gi = 1; gi < GN_MAX_GROUP; ++gi)
+            if (gi < ga.n && t >= ga.tile_end[gi - 1] && g_end <= ga.tile_end[gi - 1]) {
+                p = ga.g[gi];
+                g_begin = ga.tile_end[gi - 1];
+                g_end = ga.tile_end[gi];
+            }
+        tiles_n = (p.N + BN - 1) / BN;
+    };
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -57,7 +75,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
     const float* brow[RB];
     bool aok[RA], bok[RB];
     auto set_tile = [&](int t_idx) {
-        const int m0f = (row_base + t_idx / tiles_n) * BM, n0f = (t_idx % tiles_n) * BN;
+        const int m0f = ((t_idx - g_begin) / tiles_n) * BM, n0f = ((t_idx - g_begin) % tiles_n) * BN;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int gm = m0f + sr + 32 * i;
@@ -105,15 +123,16 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
 
     // double-buffered LDS K loop, one barrier per slab; register set s holds slab kt+1 when slab kt is
     // multiplied and is refilled with slab kt+1+PF right after it has been written to LDS
-    const int nk = (p.K + BK - 1) / BK;
-    int idx = blockIdx.x >> 3;
-    if (idx / tiles_n >= rows_here) return;
+    int idx = tile_base + (blockIdx.x >> 3);
+    if (idx >= tile_stop) return;
+    select(idx);
     set_tile(idx);
     fetch(0, pa[0], pb[0]);
-  // persistent over tiles: workgroup b walks the tiles b/8, b/8 + gridDim/8, ... of ITS XCD's range
+  // persistent over tiles: workgroup b walks the tiles base + b/8, base + b/8 + gridDim/8, ... of ITS XCD's range
   for (;;) {
-    const int m0 = (row_base + idx / tiles_n) * BM;
-    const int n0 = (idx % tiles_n) * BN;
+    const int nk = (p.K + BK - 1) / BK;
+    const int m0 = ((idx - g_begin) / tiles_n) * BM;
+    const int n0 = ((idx - g_begin) % tiles_n) * BN;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -166,10 +185,12 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
       }
     }
 
-    // next tile's first slab goes in flight now and lands during the epilogue
+    // next tile's first slab goes in flight now and lands during the epilogue (same problem only: the epilogue
+    // below still needs this problem's arguments)
     const int next = idx + stride;
-    const bool has_next = next / tiles_n < rows_here;
-    if (has_next) {
+    const bool has_next = next < tile_stop;
+    const bool same = has_next && next < g_end;
+    if (same) {
         set_tile(next);
         fetch(0, pa[0], pb[0]);
     }
@@ -238,6 +259,11 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
     }
     __syncthreads();                                // LDS is reused by the next tile's first slab
     if (!has_next) break;
+    if (!same) {                                    // first tile of the next problem
+        select(next);
+        set_tile(next);
+        fetch(0, pa[0], pb[0]);
+    }
     idx = next;
   }
 }
@@ -260,20 +286,70 @@ extern "C" int gn_gemm_ex(const float* A, int lda, const float* W, const float* 
     if (Mrows == 0) return GN_OK;
     gn::GemmArgs p{A, W, bias, C, res, gate, pre_out, a_pre, a_gate, lda, ldc, ldp, ldg, Mrows, Nout, K,
                    act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, gate_mode};
-    const long big = (long)((Mrows + 127) / 128) * ((Nout + 127) / 128);
-    long grid_big = 8L * (((Mrows + 127) / 128 + 7) / 8) * ((Nout + 127) / 128);
-    long grid_small = 8L * (((Mrows + 63) / 64 + 7) / 8) * ((Nout + 63) / 64);
-    const bool pro = pro_mode != 0 || a_gate != nullptr;
-    hipStream_t st = (hipStream_t)stream;
+    return gn_gemm_launch(&p, 1, (hipStream_t)stream);
+}
+
+static int gemm_args_ok(int Mrows, int Nout, int K, int lda, int ldc, int act_lo, int act_hi, int row_cnt,
+                        const float* res, const float* gate, int gate_mode, int pro_mode, int pro_lo, int pro_hi,
+                        const float* a_pre, int ldp, const float* a_gate, int ldg) {
+    if (Mrows < 0 || Nout <= 0 || K <= 0 || (K & 3) || (lda & 3) || (Nout & 3) || (ldc & 3) || (act_lo & 3) ||
+        (act_hi & 3) || row_cnt <= 0)
+        return 0;
+    if (gate != nullptr && res == nullptr && gate_mode == 0) return 0;
+    if (pro_mode < 0 || pro_mode > 2 || (pro_mode == 2 && (!a_pre || (ldp & 3))) || (a_gate && (ldg & 3)) ||
+        (pro_mode && ((pro_lo & 3) || (pro_hi & 3))))
+        return 0;
+    return 1;
+}
+
+extern "C" int gn_gemm_group(const gn_gemm_desc* d, int n, void* stream) {
+    if (n < 0 || n > gn::GN_MAX_GROUP || (n > 0 && !d)) return GN_ERR_BAD_ARG;
+    gn::GemmArgs g[gn::GN_MAX_GROUP];
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const gn_gemm_desc& q = d[i];
+        if (!gemm_args_ok(q.M, q.N, q.K, q.lda, q.ldc, q.act_lo, q.act_hi, q.row_cnt, q.res, q.gate, q.gate_mode,
+                          q.pro_mode, q.pro_lo, q.pro_hi, q.a_pre, q.ldp, q.a_gate, q.ldg))
+            return GN_ERR_BAD_ARG;
+        if (q.M == 0) continue;
+        g[m++] = gn::GemmArgs{q.A, q.W, q.bias, q.C, q.res, q.gate, q.pre_out, q.a_pre, q.a_gate, q.lda, q.ldc, q.ldp,
+                              q.ldg, q.M, q.N, q.K, q.act_lo, q.act_hi, q.pro_mode, q.pro_lo, q.pro_hi, q.row_cnt,
+                              q.row_gstride, q.row_goff, q.gate_mode};
+    }
+    if (m == 0) return GN_OK;
+    return gn_gemm_launch(g, m, (hipStream_t)stream);
+}
+
+// one launch for n <= GN_MAX_GROUP problems (validated by the callers)
+int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st) {
+    gn::GroupArgs ga;
+    long big = 0, small = 0;
+    bool pro = false;
+    for (int i = 0; i < n; ++i) {
+        big += (long)((g[i].M + 127) / 128) * ((g[i].N + 127) / 128);
+        small += (long)((g[i].M + 63) / 64) * ((g[i].N + 63) / 64);
+        pro = pro || g[i].pro_mode != 0 || g[i].a_gate != nullptr;
+    }
+    const bool use_big = big >= 384;           // measured best switch-over (tools/gemm_bench.py sweep)
+    long end = 0;
+    for (int i = 0; i < gn::GN_MAX_GROUP; ++i) {
+        ga.g[i] = g[i < n ? i : n - 1];
+        if (i < n) end += use_big ? (long)((g[i].M + 127) / 128) * ((g[i].N + 127) / 128)
+                                  : (long)((g[i].M + 63) / 64) * ((g[i].N + 63) / 64);
+        ga.tile_end[i] = (int)end;
+    }
+    ga.n = n;
+    if (end == 0) return GN_OK;
     // persistent launch: at most 2 (big tiles) / 4 (small tiles) workgroups per CU walk the tile list (+2 %)
-    if (grid_big > 512) grid_big = 512;
-    if (grid_small > 1024) grid_small = 1024;
-    if (big >= 384) {                          // measured best switch-over (tools/gemm_bench.py sweep)
-        if (pro) hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, true, 1>), dim3((unsigned)grid_big), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, false, 1>), dim3((unsigned)grid_big), dim3(256), 0, st, p);
+    long grid = 8L * ((end + 7) / 8);
+    const long cap = use_big ? 512 : 1024;
+    if (grid > cap) grid = cap;
+    if (use_big) {
+        if (pro) hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, true, 1>), dim3((unsigned)grid), dim3(256), 0, st, ga);
+        else hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, ga);
     } else {
-        if (pro) hipLaunchKernelGGL((gn::gemm_f32_mfma<1, 1, true, 1>), dim3((unsigned)grid_small), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gn::gemm_f32_mfma<1, 1, false, 1>), dim3((unsigned)grid_small), dim3(256), 0, st, p);
+        if (pro) hipLaunchKernelGGL((gn::gemm_f32_mfma<1, 1, true, 1>), dim3((unsigned)grid), dim3(256), 0, st, ga);
+        else hipLaunchKernelGGL((gn::gemm_f32_mfma<1, 1, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, ga);
     }
     GN_LAUNCH_CHECK();
     return GN_OK;

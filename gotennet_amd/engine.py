@@ -176,6 +176,39 @@ def gemm(A, lda, W, bias, C, ldc, rows, nout, K, act=(0, 0), rowmap=(1, 1, 0), r
          ptr(a_gate), ldg, _stream())
 
 
+def gemm_group(problems):
+    """Several INDEPENDENT ``gemm(...)`` calls (a list of argument dicts) as ONE launch (gn_gemm_group); the
+    3xbf16-split mode has no grouped kernel and issues them one by one."""
+    problems = [q for q in problems if q is not None]
+    if GEMM_MODE == "split" or len(problems) == 1:
+        for q in problems:
+            gemm(**{"bias": None, **q})
+        return
+    for i0 in range(0, len(problems), 4):
+        chunk = problems[i0:i0 + 4]
+        arr = (_lib.GemmDesc * len(chunk))()
+        for d, q in zip(arr, chunk):
+            g = lambda k, dflt=None: q.get(k, dflt)
+            act, rowmap, pro = g("act", (0, 0)), g("rowmap", (1, 1, 0)), g("pro", (0, 0, 0))
+            dgate = g("dgate")
+            d.A = q["A"].data_ptr() + 4 * g("a_off", 0); d.lda = q["lda"]
+            d.W = ptr(q["W"]); d.bias = ptr(g("bias"))
+            d.C = q["C"].data_ptr() + 4 * g("c_off", 0); d.ldc = q["ldc"]
+            d.M, d.N, d.K = q["rows"], q["nout"], q["K"]
+            d.act_lo, d.act_hi = act
+            d.row_cnt, d.row_gstride, d.row_goff = rowmap
+            d.res = ptr(g("res"))
+            d.gate = (dgate.data_ptr() + 4 * g("g_off", 0)) if dgate is not None else ptr(g("gate"))
+            d.gate_mode = 1 if dgate is not None else 0
+            d.pre_out = ptr(g("pre_out"))
+            d.pro_mode, d.pro_lo, d.pro_hi = pro
+            a_pre = g("a_pre")
+            d.a_pre = (a_pre.data_ptr() + 4 * g("p_off", 0)) if a_pre is not None else None
+            d.ldp = g("ldp", 0)
+            d.a_gate = ptr(g("a_gate")); d.ldg = g("ldg", 0)
+        call("gn_gemm_group", arr, len(chunk), _stream())
+
+
 class Graph:
     """CSR-by-target view of a target-sorted edge list + per-edge geometry (K1);
     ``csc()`` adds the by-source view the backward needs."""
@@ -302,8 +335,8 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
             # SiLU of the two hidden blocks is applied ONCE by this epilogue (a SiLU prologue in the two products
             # below would redo it for each of their 4M column tiles); the pre-activation copy is what backward needs
             gemm(h, F_, lw.Wn1, lw.bn1, nact, 4 * F_, N, 4 * F_, F_, act=(2 * F_, 4 * F_), pre_out=nproj if save else None)
-            gemm(nact, 4 * F_, lw.Ws2, lw.bs2, xs, M * F_, N, M * F_, F_, a_off=2 * F_)
-            gemm(nact, 4 * F_, lw.Wv2, lw.bv2, vs, M * F_, N, M * F_, F_, a_off=3 * F_)
+            gemm_group([dict(A=nact, lda=4 * F_, W=lw.Ws2, bias=lw.bs2, C=xs, ldc=M * F_, rows=N, nout=M * F_, K=F_, a_off=2 * F_),
+                        dict(A=nact, lda=4 * F_, W=lw.Wv2, bias=lw.bv2, C=vs, ldc=M * F_, rows=N, nout=M * F_, K=F_, a_off=3 * F_)])
         gemm(t, F_, lw.We, lw.be, eproj, lde, E, lde, F_)
         fork.join()
         # ---- message / softmax / aggregate / residual (452-559, 613-640, 426-427)
@@ -315,22 +348,26 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
         h, h2 = h2, h
         X, X2 = X2, X
         # ---- EQFF (716-748): node-local chain on the side stream while HTR walks the edges
+        # every product of the updated X (X W_vu^T for EQFF; EQ and the per-degree EK_l for HTR) in one launch
+        xprods = [dict(A=X, lda=F_, W=lw.Wvu, C=Xp, ldc=F_, rows=N * D, nout=F_, K=F_)]
+        if not last:
+            xprods.append(dict(A=X, lda=F_, W=lw.Wvq, C=EQ, ldc=Fe, rows=N * D, nout=Fe, K=F_))
+            if cfg.htr_mode & 1:                   # sep_htr=False: one W_vk for every row
+                xprods.append(dict(A=X, lda=F_, W=lw.Wvk[0], C=EK, ldc=Fe, rows=N * D, nout=Fe, K=F_))
+            else:
+                off = 0
+                for l in range(1, lmax + 1):
+                    cnt = 2 * l + 1
+                    xprods.append(dict(A=X, lda=F_, W=lw.Wvk[l - 1], C=EK, ldc=Fe, rows=N * cnt, nout=Fe, K=F_,
+                                       rowmap=(cnt, D, off)))
+                    off += cnt
+        gemm_group(xprods)
         with _Side(dev) as fork:
-            gemm(X, F_, lw.Wvu, None, Xp, F_, N * D, F_, F_)
             call("gn_eqff_context", ptr(h), ptr(Xp), float(cfg.eps), N, F_, D, ptr(ctx), _stream())
             gemm(ctx, 2 * F_, lw.Wm0, lw.bm0, g1act, F_, N, F_, 2 * F_, act=(0, F_), pre_out=pre_g1 if save else None)
             gemm(g1act, F_, lw.Wm1, lw.bm1, mm, 2 * F_, N, 2 * F_, F_)
         # ---- HTR (429-445, 561-611)
         if not last:
-            gemm(X, F_, lw.Wvq, None, EQ, Fe, N * D, Fe, F_)
-            if cfg.htr_mode & 1:                   # sep_htr=False: one W_vk for every row
-                gemm(X, F_, lw.Wvk[0], None, EK, Fe, N * D, Fe, F_)
-            else:
-                off = 0
-                for l in range(1, lmax + 1):
-                    cnt = 2 * l + 1
-                    gemm(X, F_, lw.Wvk[l - 1], None, EK, Fe, N * cnt, Fe, F_, rowmap=(cnt, D, off))
-                    off += cnt
             call("gn_htr_edge", ptr(EQ), ptr(EK), ptr(g.rl), ptr(g.rowptr), ptr(g.src), N, Fe, lmax, cfg.htr_mode,
                  ptr(lt.w_raw) if save else None, ptr(w), _stream())
             if cfg.composed_update:
@@ -510,10 +547,10 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
              ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), ptr(gX2), rl_slice(li), cut_slice(G * li),
              ptr(ga_parts), E,
              N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
-        gemm(g_x, M * F_, _T(lw, "Ws2"), None, g_nproj, 4 * F_, N, F_, M * F_, c_off=2 * F_,
-             dgate=lt.nproj, g_off=2 * F_)
-        gemm(g_v, M * F_, _T(lw, "Wv2"), None, g_nproj, 4 * F_, N, F_, M * F_, c_off=3 * F_,
-             dgate=lt.nproj, g_off=3 * F_)
+        gemm_group([dict(A=g_x, lda=M * F_, W=_T(lw, "Ws2"), C=g_nproj, ldc=4 * F_, rows=N, nout=F_, K=M * F_,
+                         c_off=2 * F_, dgate=lt.nproj, g_off=2 * F_),
+                    dict(A=g_v, lda=M * F_, W=_T(lw, "Wv2"), C=g_nproj, ldc=4 * F_, rows=N, nout=F_, K=M * F_,
+                         c_off=3 * F_, dgate=lt.nproj, g_off=3 * F_)])
         gemm(g_nproj, 4 * F_, _T(lw, "Wn1"), None, gh2, F_, N, F_, 4 * F_, res=gh1)
         gemm(g_eproj, lde, _T(lw, "We"), None, gt_b, F_, E, F_, lde, res=gt_in)
         gh, gh2 = gh2, gh

@@ -115,6 +115,25 @@ int gn_gemm_ex(const float* A, int lda, const float* W, const float* bias, float
                int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
                const float* a_gate, int ldg, void* stream);
 
+/* Several INDEPENDENT gn_gemm_ex problems in one launch (no problem may read what another writes).  The atom-sized
+ * products of a layer (x / v, EQ / EK_l / X W_vu^T, and the matching input-gradient products) fill a fraction of the
+ * 256 CUs one at a time; a group walks all their tiles with one persistent grid.  n <= 4; every field has the meaning
+ * of the gn_gemm_ex argument of the same name. */
+typedef struct gn_gemm_desc {
+    const float* A; int lda;
+    const float* W; const float* bias;
+    float* C; int ldc;
+    int M, N, K;
+    int act_lo, act_hi;
+    int row_cnt, row_gstride, row_goff;
+    const float* res; const float* gate; int gate_mode;
+    float* pre_out;
+    int pro_mode, pro_lo, pro_hi;
+    const float* a_pre; int ldp;
+    const float* a_gate; int ldg;
+} gn_gemm_desc;
+int gn_gemm_group(const gn_gemm_desc* problems, int n, void* stream);
+
 /* 3 x bf16 split variant: same contract as gn_gemm_ex, but the weight is passed as three
  * bf16 planes W3[3][Nout][K] (hi, mid, lo with W = hi + mid + lo to 2^-25; made once by gn_split_bf16x3) and the
  * product is accumulated in fp32 from the six plane pairs of order <= 2 on the bf16 matrix cores: fp32-class
