@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
                 ("row_cnt", _I), ("row_gstride", _I), ("row_goff", _I),
                 ("res", _P), ("gate", _P), ("gate_mode", _I), ("pre_out", _P),
                 ("pro_mode", _I), ("pro_lo", _I), ("pro_hi", _I), ("a_pre", _P), ("ldp", _I),
-                ("a_gate", _P), ("ldg", _I)]
+                ("a_gate", _P), ("ldg", _I), ("A2", _P), ("A3", _P), ("a_seg", _I)]
 
 
 SIGNATURES = {

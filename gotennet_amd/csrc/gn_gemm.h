@@ -16,6 +16,9 @@ struct GemmArgs {
     int pro_mode, pro_lo, pro_hi;
     int row_cnt, row_gstride, row_goff;
     int gate_mode;                  // 0: value * gate; 1: value * SiLU'(gate)
+    // K-segmented A operand: columns [s * a_seg, (s+1) * a_seg) of the logical A come from A / A2 / A3 (same lda,
+    // same row addressing): sums up to three products that share their output rows.  a_seg = 0: plain A.
+    const float* A2; const float* A3; int a_seg;
 };
 
 constexpr int GN_MAX_GROUP = 4;

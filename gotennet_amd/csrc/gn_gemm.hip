@@ -99,11 +99,18 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
         const int kc = k0 + 4 * c4;
         const bool kok = kc < p.K;
         const bool pro = PRO && p.pro_mode && kc >= p.pro_lo && kc < p.pro_hi;
+        // K-segmented A (a slab never straddles a segment: a_seg % BK == 0, checked by the launcher)
+        const float* Ab = p.A;
+        int ka = kc;
+        if (p.a_seg) {
+            if (k0 >= 2 * p.a_seg) { Ab = p.A3; ka = kc - 2 * p.a_seg; }
+            else if (k0 >= p.a_seg) { Ab = p.A2; ka = kc - p.a_seg; }
+        }
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             float4 v = zero4();
             if (aok[i] && kok) {
-                v = ld4(p.A + (size_t)prow[i] * p.lda + kc);
+                v = ld4(Ab + (size_t)prow[i] * p.lda + ka);
                 if constexpr (PRO) {
                     if (pro) v = (p.pro_mode == 1) ? silu4(v) : v * dsilu4(ld4(p.a_pre + (size_t)prow[i] * p.ldp + kc));
                     if (p.a_gate) v = v * ld4(p.a_gate + (size_t)prow[i] * p.ldg + kc);
@@ -285,7 +292,8 @@ extern "C" int gn_gemm_ex(const float* A, int lda, const float* W, const float* 
         return GN_ERR_BAD_ARG;
     if (Mrows == 0) return GN_OK;
     gn::GemmArgs p{A, W, bias, C, res, gate, pre_out, a_pre, a_gate, lda, ldc, ldp, ldg, Mrows, Nout, K,
-                   act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, gate_mode};
+                   act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, gate_mode,
+                   nullptr, nullptr, 0};
     return gn_gemm_launch(&p, 1, (hipStream_t)stream);
 }
 
@@ -311,10 +319,13 @@ extern "C" int gn_gemm_group(const gn_gemm_desc* d, int n, void* stream) {
         if (!gemm_args_ok(q.M, q.N, q.K, q.lda, q.ldc, q.act_lo, q.act_hi, q.row_cnt, q.res, q.gate, q.gate_mode,
                           q.pro_mode, q.pro_lo, q.pro_hi, q.a_pre, q.ldp, q.a_gate, q.ldg))
             return GN_ERR_BAD_ARG;
+        if (q.a_seg < 0 || (q.a_seg && ((q.a_seg % gn::BK) || q.pro_mode || q.a_gate || q.K > 3 * q.a_seg ||
+                                        !q.A2 || (q.K > 2 * q.a_seg && !q.A3))))
+            return GN_ERR_BAD_ARG;
         if (q.M == 0) continue;
         g[m++] = gn::GemmArgs{q.A, q.W, q.bias, q.C, q.res, q.gate, q.pre_out, q.a_pre, q.a_gate, q.lda, q.ldc, q.ldp,
                               q.ldg, q.M, q.N, q.K, q.act_lo, q.act_hi, q.pro_mode, q.pro_lo, q.pro_hi, q.row_cnt,
-                              q.row_gstride, q.row_goff, q.gate_mode};
+                              q.row_gstride, q.row_goff, q.gate_mode, q.A2, q.A3, q.a_seg};
     }
     if (m == 0) return GN_OK;
     return gn_gemm_launch(g, m, (hipStream_t)stream);

@@ -180,9 +180,18 @@ def gemm_group(problems):
     """Several INDEPENDENT ``gemm(...)`` calls (a list of argument dicts) as ONE launch (gn_gemm_group); the
     3xbf16-split mode has no grouped kernel and issues them one by one."""
     problems = [q for q in problems if q is not None]
-    if GEMM_MODE == "split" or len(problems) == 1:
+    if GEMM_MODE == "split" or (len(problems) == 1 and not problems[0].get("a_seg")):
         for q in problems:
-            gemm(**{"bias": None, **q})
+            if q.get("a_seg"):                       # K-segmented A: chained products through `res`
+                segs = [q["A"], q["A2"]] + ([q["A3"]] if q.get("A3") is not None else [])
+                res = q.get("res")
+                for si, a in enumerate(segs):
+                    Wseg = q["W"][:, si * q["a_seg"]:(si + 1) * q["a_seg"]].contiguous()
+                    gemm(a, q["lda"], Wseg, q.get("bias") if si == 0 else None, q["C"], q["ldc"], q["rows"], q["nout"],
+                         q["a_seg"], rowmap=q.get("rowmap", (1, 1, 0)), res=res)
+                    res = q["C"]
+            else:
+                gemm(**{"bias": None, **q})
         return
     for i0 in range(0, len(problems), 4):
         chunk = problems[i0:i0 + 4]
@@ -206,6 +215,7 @@ def gemm_group(problems):
             d.a_pre = (a_pre.data_ptr() + 4 * g("p_off", 0)) if a_pre is not None else None
             d.ldp = g("ldp", 0)
             d.a_gate = ptr(g("a_gate")); d.ldg = g("ldg", 0)
+            d.A2, d.A3, d.a_seg = ptr(g("A2")), ptr(g("A3")), g("a_seg", 0)
         call("gn_gemm_group", arr, len(chunk), _stream())
 
 
@@ -507,7 +517,9 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
         gemm(gm, 2 * F_, _T(lw, "Wm1"), None, g_g1, F_, N, F_, 2 * F_, dgate=lt.pre_g1)   # * SiLU'(pre) in the epilogue
         gemm(g_g1, F_, _T(lw, "Wm0"), None, g_ctx, 2 * F_, N, 2 * F_, F_)
         call("gn_eqff_backward_b", ptr(g_ctx), ptr(lt.ctx), ptr(lt.Xp), ptr(gh), N, F_, D, ptr(gXp), ptr(gh1), _stream())
-        gemm(gXp, F_, _T(lw, "Wvu"), None, gX1, F_, N * D, F_, F_, res=gX)
+        fuse_x = (not last) and Fe == F_           # gX1 = gX + gXp W_vu + gEQ W_vq + gEK_l W_vk_l in one launch below
+        if not fuse_x:
+            gemm(gXp, F_, _T(lw, "Wvu"), None, gX1, F_, N * D, F_, F_, res=gX)
         # ---- HTR backward
         if not last:
             if gt is None:
@@ -521,19 +533,35 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
                 call("gn_htr_backward", ptr(gt), ptr(lt.pre_t), ptr(lt.w), ptr(lt.w_raw), ptr(lt.EQ), ptr(lt.EK),
                      ptr(g.rl), ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm), N, Fe, lmax,
                      cfg.htr_mode, ptr(gEQ), ptr(gEK), rl_slice(L + li), ptr(g_pre_t), _stream())
-            gemm(gEQ, Fe, _T(lw, "Wvq"), None, gX1, F_, N * D, F_, Fe, res=gX1)
-            off = 0
-            for l in range(1, lmax + 1):
-                joint = bool(cfg.htr_mode & 1)
-                cnt = D if joint else 2 * l + 1
-                wkT = lw.T.get(("Wvk", l))
-                if wkT is None:
-                    wkT = lw.Wvk[l - 1].t().contiguous()
-                    lw.T[("Wvk", l)] = wkT
-                gemm(gEK, Fe, wkT, None, gX1, F_, N * cnt, F_, Fe, rowmap=(cnt, D, off), res=gX1)
-                off += cnt
-                if joint:
-                    break
+            joint = bool(cfg.htr_mode & 1)
+            if fuse_x:
+                # per degree block: A = [gXp | gEQ | gEK] (K-segmented), W = [W_vu^T | W_vq^T | W_vk_l^T] along K
+                probs, off = [], 0
+                for l in range(1, lmax + 1):
+                    cnt = D if joint else 2 * l + 1
+                    wcat = lw.T.get(("Xcat", l))
+                    if wcat is None:
+                        wcat = torch.cat([_T(lw, "Wvu"), _T(lw, "Wvq"), lw.Wvk[l - 1].t()], dim=1).contiguous()
+                        lw.T[("Xcat", l)] = wcat
+                    probs.append(dict(A=gXp, A2=gEQ, A3=gEK, a_seg=F_, lda=F_, W=wcat, C=gX1, ldc=F_, rows=N * cnt,
+                                      nout=F_, K=3 * F_, rowmap=(cnt, D, off), res=gX))
+                    off += cnt
+                    if joint:
+                        break
+                gemm_group(probs)
+            else:
+                gemm(gEQ, Fe, _T(lw, "Wvq"), None, gX1, F_, N * D, F_, Fe, res=gX1)
+                off = 0
+                for l in range(1, lmax + 1):
+                    cnt = D if joint else 2 * l + 1
+                    wkT = lw.T.get(("Wvk", l))
+                    if wkT is None:
+                        wkT = lw.Wvk[l - 1].t().contiguous()
+                        lw.T[("Wvk", l)] = wkT
+                    gemm(gEK, Fe, wkT, None, gX1, F_, N * cnt, F_, Fe, rowmap=(cnt, D, off), res=gX1)
+                    off += cnt
+                    if joint:
+                        break
             # gt_a = gt + ((gt * w) * SiLU'(pre_t)) Wt
             if not cfg.composed_update:
                 gemm(g_pre_t, F_, _T(lw, "Wt"), None, gt_a, F_, E, F_, F_, res=gt)

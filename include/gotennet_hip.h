@@ -131,6 +131,10 @@ typedef struct gn_gemm_desc {
     int pro_mode, pro_lo, pro_hi;
     const float* a_pre; int ldp;
     const float* a_gate; int ldg;
+    /* K-segmented A: when a_seg != 0 the logical A columns [s a_seg, (s+1) a_seg) come from A, A2, A3 (s = 0, 1, 2;
+     * same lda and row addressing; a_seg % 32 == 0; no prologue): C = res + A W_0^T + A2 W_1^T + A3 W_2^T with the
+     * three weights concatenated along K.  Used for gX = gX + gXp W_vu + gEQ W_vq + gEK_l W_vk_l. */
+    const float* A2; const float* A3; int a_seg;
 } gn_gemm_desc;
 int gn_gemm_group(const gn_gemm_desc* problems, int n, void* stream);
 
