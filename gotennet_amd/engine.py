@@ -100,50 +100,6 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-#: GN_OVERLAP=1 runs the atom-sized (node-level) kernel chains of a layer on a second HIP stream, concurrently
-#: with the edge-sized GEMMs they do not depend on.  Measured on MI355X (round 1): 14.89 -> 14.77 ms/step only --
-#: the edge GEMM's two 73.7 KB-LDS workgroups per CU leave no LDS for a co-resident kernel -- so it is OFF by default.
-OVERLAP = os.environ.get("GN_OVERLAP", "0") != "0"
-_SIDE: dict = {}
-
-
-class _Side:
-    """``with _Side(dev) as s:`` forks a side stream off the current one; ``s.join()`` makes the
-    current stream wait for it.  No-op (same stream) when OVERLAP is off."""
-
-    def __init__(self, device):
-        self.main = torch.cuda.current_stream(device)
-        if OVERLAP:
-            key = (device.index if device.index is not None else torch.cuda.current_device())
-            if key not in _SIDE:
-                _SIDE[key] = torch.cuda.Stream(device=device)
-            self.side = _SIDE[key]
-        else:
-            self.side = self.main
-        self.ctx = None
-
-    def __enter__(self):
-        if self.side is not self.main:
-            self.side.wait_stream(self.main)
-            self.ctx = torch.cuda.stream(self.side)
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False
-
-    def wait_main(self):
-        """inside the block: make the side stream wait for what the main stream has queued so far."""
-        if self.side is not self.main:
-            self.side.wait_stream(self.main)
-
-    def join(self):
-        if self.side is not self.main:
-            self.main.wait_stream(self.side)
-
-
 #: projection arithmetic: "split" = 3 x bf16 split on the bf16 matrix cores (fp32-class error, 2.67x the
 #: fp32 MFMA rate); "f32" = exact fp32 MFMA.  Env GN_GEMM_MODE overrides.
 GEMM_MODE = os.environ.get("GN_GEMM_MODE", "f32")
@@ -340,15 +296,15 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
                 lt.w_raw = new(E, Fe) if (cfg.htr_mode >> 2) else None
             lt.nproj, lt.xs, lt.vs, lt.eproj, lt.attn = nproj, xs, vs, eproj, attn
             lt.Xp, lt.ctx, lt.pre_g1, lt.mm = Xp, ctx, pre_g1, mm
-        # ---- GATA projections (gotennet.py:400-407); SiLU applied by the consumers
-        with _Side(dev) as fork:                   # atom-sized projections || edge projection
-            # SiLU of the two hidden blocks is applied ONCE by this epilogue (a SiLU prologue in the two products
-            # below would redo it for each of their 4M column tiles); the pre-activation copy is what backward needs
-            gemm(h, F_, lw.Wn1, lw.bn1, nact, 4 * F_, N, 4 * F_, F_, act=(2 * F_, 4 * F_), pre_out=nproj if save else None)
-            gemm_group([dict(A=nact, lda=4 * F_, W=lw.Ws2, bias=lw.bs2, C=xs, ldc=M * F_, rows=N, nout=M * F_, K=F_, a_off=2 * F_),
-                        dict(A=nact, lda=4 * F_, W=lw.Wv2, bias=lw.bv2, C=vs, ldc=M * F_, rows=N, nout=M * F_, K=F_, a_off=3 * F_)])
-        gemm(t, F_, lw.We, lw.be, eproj, lde, E, lde, F_)
-        fork.join()
+        # ---- GATA projections (gotennet.py:400-407).  The atom-sized node projection rides in the edge projection's
+        # launch (its 168 tiles fill the tail of the 5100-tile grid).  SiLU of the two hidden blocks is applied ONCE by
+        # the epilogue (a SiLU prologue in the two products below would redo it for each of their 4M column tiles); the
+        # pre-activation copy is what the backward needs.
+        gemm_group([dict(A=t, lda=F_, W=lw.We, bias=lw.be, C=eproj, ldc=lde, rows=E, nout=lde, K=F_),
+                    dict(A=h, lda=F_, W=lw.Wn1, bias=lw.bn1, C=nact, ldc=4 * F_, rows=N, nout=4 * F_, K=F_,
+                         act=(2 * F_, 4 * F_), pre_out=nproj if save else None)])
+        gemm_group([dict(A=nact, lda=4 * F_, W=lw.Ws2, bias=lw.bs2, C=xs, ldc=M * F_, rows=N, nout=M * F_, K=F_, a_off=2 * F_),
+                    dict(A=nact, lda=4 * F_, W=lw.Wv2, bias=lw.bv2, C=vs, ldc=M * F_, rows=N, nout=M * F_, K=F_, a_off=3 * F_)])
         # ---- message / softmax / aggregate / residual (452-559, 613-640, 426-427)
         call("gn_attn_softmax", ptr(nact), nact.data_ptr() + 4 * F_, 4 * F_, ptr(eproj), lde,
              ptr(g.rowptr), ptr(g.src), ptr(g.outdeg), N, F_, H, ptr(attn), _stream())
@@ -372,11 +328,11 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
                                        rowmap=(cnt, D, off)))
                     off += cnt
         gemm_group(xprods)
-        with _Side(dev) as fork:
-            call("gn_eqff_context", ptr(h), ptr(Xp), float(cfg.eps), N, F_, D, ptr(ctx), _stream())
-            gemm(ctx, 2 * F_, lw.Wm0, lw.bm0, g1act, F_, N, F_, 2 * F_, act=(0, F_), pre_out=pre_g1 if save else None)
-            gemm(g1act, F_, lw.Wm1, lw.bm1, mm, 2 * F_, N, 2 * F_, F_)
-        # ---- HTR (429-445, 561-611)
+        # ---- EQFF context (731-735) and HTR edge weights (561-611); then the first gamma_m layer rides in the
+        # launch of the edge-sized gamma_t product
+        call("gn_eqff_context", ptr(h), ptr(Xp), float(cfg.eps), N, F_, D, ptr(ctx), _stream())
+        m0 = dict(A=ctx, lda=2 * F_, W=lw.Wm0, bias=lw.bm0, C=g1act, ldc=F_, rows=N, nout=F_, K=2 * F_, act=(0, F_),
+                  pre_out=pre_g1 if save else None)
         if not last:
             call("gn_htr_edge", ptr(EQ), ptr(EK), ptr(g.rl), ptr(g.rowptr), ptr(g.src), N, Fe, lmax, cfg.htr_mode,
                  ptr(lt.w_raw) if save else None, ptr(w), _stream())
@@ -384,11 +340,14 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
                 upd = _edge_update_composed(cfg, lw, t, w, t2, E, lt.pre_t if save else None)
                 if save:
                     lt.upd = upd
+                gemm_group([m0])
             else:
-                gemm(t, F_, lw.Wt, lw.bt, t2, F_, E, F_, F_, act=(0, F_), res=t, gate=w,
-                     pre_out=lt.pre_t if save else None)
+                gemm_group([dict(A=t, lda=F_, W=lw.Wt, bias=lw.bt, C=t2, ldc=F_, rows=E, nout=F_, K=F_, act=(0, F_), res=t,
+                                 gate=w, pre_out=lt.pre_t if save else None), m0])
             t, t2 = t2, t
-        fork.join()                                # X is updated in place only after HTR has read it
+        else:
+            gemm_group([m0])
+        gemm(g1act, F_, lw.Wm1, lw.bm1, mm, 2 * F_, N, 2 * F_, F_)
         call("gn_eqff_update", ptr(mm), ptr(Xp), N, F_, D, ptr(h), ptr(X), _stream())
         if trace is not None:
             trace.append((h.clone(), X.clone(), t.clone()))
@@ -512,15 +471,10 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
     for li in reversed(range(len(pw.layers))):
         lw, lt = pw.layers[li], tape.layers[li]
         last = lw.Wt is None
-        # ---- EQFF backward
+        # ---- EQFF backward, first half; HTR backward kernels (independent of it)
         call("gn_eqff_backward_a", ptr(gh), ptr(gX), ptr(lt.mm), ptr(lt.Xp), N, F_, D, ptr(gm), ptr(gXp), _stream())
-        gemm(gm, 2 * F_, _T(lw, "Wm1"), None, g_g1, F_, N, F_, 2 * F_, dgate=lt.pre_g1)   # * SiLU'(pre) in the epilogue
-        gemm(g_g1, F_, _T(lw, "Wm0"), None, g_ctx, 2 * F_, N, 2 * F_, F_)
-        call("gn_eqff_backward_b", ptr(g_ctx), ptr(lt.ctx), ptr(lt.Xp), ptr(gh), N, F_, D, ptr(gXp), ptr(gh1), _stream())
-        fuse_x = (not last) and Fe == F_           # gX1 = gX + gXp W_vu + gEQ W_vq + gEK_l W_vk_l in one launch below
-        if not fuse_x:
-            gemm(gXp, F_, _T(lw, "Wvu"), None, gX1, F_, N * D, F_, F_, res=gX)
-        # ---- HTR backward
+        m1 = dict(A=gm, lda=2 * F_, W=_T(lw, "Wm1"), C=g_g1, ldc=F_, rows=N, nout=F_, K=2 * F_,
+                  dgate=lt.pre_g1)                 # * SiLU'(pre) in the epilogue
         if not last:
             if gt is None:
                 raise RuntimeError("internal: missing edge gradient")
@@ -529,45 +483,53 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
                 call("gn_htr_backward", ptr(g_w), None, None, None, ptr(lt.EQ), ptr(lt.EK), ptr(g.rl),
                      ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm), N, Fe, lmax, cfg.htr_mode | 16,
                      ptr(gEQ), ptr(gEK), rl_slice(L + li), None, _stream())
+                gemm_group([m1])
             else:
                 call("gn_htr_backward", ptr(gt), ptr(lt.pre_t), ptr(lt.w), ptr(lt.w_raw), ptr(lt.EQ), ptr(lt.EK),
                      ptr(g.rl), ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm), N, Fe, lmax,
                      cfg.htr_mode, ptr(gEQ), ptr(gEK), rl_slice(L + li), ptr(g_pre_t), _stream())
-            joint = bool(cfg.htr_mode & 1)
-            if fuse_x:
-                # per degree block: A = [gXp | gEQ | gEK] (K-segmented), W = [W_vu^T | W_vq^T | W_vk_l^T] along K
-                probs, off = [], 0
-                for l in range(1, lmax + 1):
-                    cnt = D if joint else 2 * l + 1
-                    wcat = lw.T.get(("Xcat", l))
-                    if wcat is None:
-                        wcat = torch.cat([_T(lw, "Wvu"), _T(lw, "Wvq"), lw.Wvk[l - 1].t()], dim=1).contiguous()
-                        lw.T[("Xcat", l)] = wcat
-                    probs.append(dict(A=gXp, A2=gEQ, A3=gEK, a_seg=F_, lda=F_, W=wcat, C=gX1, ldc=F_, rows=N * cnt,
-                                      nout=F_, K=3 * F_, rowmap=(cnt, D, off), res=gX))
-                    off += cnt
-                    if joint:
-                        break
-                gemm_group(probs)
-            else:
-                gemm(gEQ, Fe, _T(lw, "Wvq"), None, gX1, F_, N * D, F_, Fe, res=gX1)
-                off = 0
-                for l in range(1, lmax + 1):
-                    cnt = D if joint else 2 * l + 1
-                    wkT = lw.T.get(("Wvk", l))
-                    if wkT is None:
-                        wkT = lw.Wvk[l - 1].t().contiguous()
-                        lw.T[("Wvk", l)] = wkT
-                    gemm(gEK, Fe, wkT, None, gX1, F_, N * cnt, F_, Fe, rowmap=(cnt, D, off), res=gX1)
-                    off += cnt
-                    if joint:
-                        break
-            # gt_a = gt + ((gt * w) * SiLU'(pre_t)) Wt
-            if not cfg.composed_update:
-                gemm(g_pre_t, F_, _T(lw, "Wt"), None, gt_a, F_, E, F_, F_, res=gt)
+                # gt_a = gt + ((gt * w) * SiLU'(pre_t)) Wt; the atom-sized gamma_m product rides in its launch
+                gemm_group([dict(A=g_pre_t, lda=F_, W=_T(lw, "Wt"), C=gt_a, ldc=F_, rows=E, nout=F_, K=F_, res=gt), m1])
             gt_in = gt_a
         else:
+            gemm_group([m1])
             gt_in = gt                             # no edge update in this layer: t passes through unchanged
+        # ---- EQFF backward, second half
+        gemm(g_g1, F_, _T(lw, "Wm0"), None, g_ctx, 2 * F_, N, 2 * F_, F_)
+        call("gn_eqff_backward_b", ptr(g_ctx), ptr(lt.ctx), ptr(lt.Xp), ptr(gh), N, F_, D, ptr(gXp), ptr(gh1), _stream())
+        # ---- gX1 = gX + gXp W_vu (+ gEQ W_vq + gEK_l W_vk_l)
+        joint = bool(cfg.htr_mode & 1)
+        if last:
+            gemm(gXp, F_, _T(lw, "Wvu"), None, gX1, F_, N * D, F_, F_, res=gX)
+        elif Fe == F_:
+            # one launch; per degree block: A = [gXp | gEQ | gEK] (K-segmented), W = [W_vu^T | W_vq^T | W_vk_l^T] along K
+            probs, off = [], 0
+            for l in range(1, lmax + 1):
+                cnt = D if joint else 2 * l + 1
+                wcat = lw.T.get(("Xcat", l))
+                if wcat is None:
+                    wcat = torch.cat([_T(lw, "Wvu"), _T(lw, "Wvq"), lw.Wvk[l - 1].t()], dim=1).contiguous()
+                    lw.T[("Xcat", l)] = wcat
+                probs.append(dict(A=gXp, A2=gEQ, A3=gEK, a_seg=F_, lda=F_, W=wcat, C=gX1, ldc=F_, rows=N * cnt,
+                                  nout=F_, K=3 * F_, rowmap=(cnt, D, off), res=gX))
+                off += cnt
+                if joint:
+                    break
+            gemm_group(probs)
+        else:                                      # evec_dim != F: three chained products
+            gemm(gXp, F_, _T(lw, "Wvu"), None, gX1, F_, N * D, F_, F_, res=gX)
+            gemm(gEQ, Fe, _T(lw, "Wvq"), None, gX1, F_, N * D, F_, Fe, res=gX1)
+            off = 0
+            for l in range(1, lmax + 1):
+                cnt = D if joint else 2 * l + 1
+                wkT = lw.T.get(("Wvk", l))
+                if wkT is None:
+                    wkT = lw.Wvk[l - 1].t().contiguous()
+                    lw.T[("Wvk", l)] = wkT
+                gemm(gEK, Fe, wkT, None, gX1, F_, N * cnt, F_, Fe, rowmap=(cnt, D, off), res=gX1)
+                off += cnt
+                if joint:
+                    break
         # ---- message backward
         call("gn_message_backward", ptr(lt.xs), ptr(lt.vs), M * F_, ptr(lt.eproj), lde, ptr(lt.attn),
              ptr(lt.nproj), 4 * F_, ptr(lt.X_in), ptr(g.rl), ptr(g.cut), ptr(g.outdeg),
@@ -579,8 +541,8 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
                          c_off=2 * F_, dgate=lt.nproj, g_off=2 * F_),
                     dict(A=g_v, lda=M * F_, W=_T(lw, "Wv2"), C=g_nproj, ldc=4 * F_, rows=N, nout=F_, K=M * F_,
                          c_off=3 * F_, dgate=lt.nproj, g_off=3 * F_)])
-        gemm(g_nproj, 4 * F_, _T(lw, "Wn1"), None, gh2, F_, N, F_, 4 * F_, res=gh1)
-        gemm(g_eproj, lde, _T(lw, "We"), None, gt_b, F_, E, F_, lde, res=gt_in)
+        gemm_group([dict(A=g_eproj, lda=lde, W=_T(lw, "We"), C=gt_b, ldc=F_, rows=E, nout=F_, K=lde, res=gt_in),
+                    dict(A=g_nproj, lda=4 * F_, W=_T(lw, "Wn1"), C=gh2, ldc=F_, rows=N, nout=F_, K=4 * F_, res=gh1)])
         gh, gh2 = gh2, gh
         gX, gX2 = gX2, gX
         if gh2 is gh_caller:
