@@ -26,6 +26,7 @@ struct GroupArgs {
     GemmArgs g[GN_MAX_GROUP];       // entries >= n repeat the last problem (never selected)
     int tile_end[GN_MAX_GROUP];     // running tile count: problem i owns the global tile ids [tile_end[i-1], tile_end[i])
     int n;
+    int spread;                     // 1: every problem's tiles are cut into 8 XCD ranges; 0: one cut of the whole list
 };
 
 constexpr int BK = 32, PITCH = 36;
