@@ -22,6 +22,7 @@
 //   1: A <- SiLU(A)                 (activations are stored pre-activation, consumers apply SiLU)
 //   2: A <- A * SiLU'(P)            (backward through an activation; P = stored pre-activation)
 //   and, for every column, A <- A * G when a_gate != NULL.
+#include <cstdlib>
 #include "gn_gemm.h"
 
 namespace gn {
@@ -370,7 +371,11 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st) {
         small += (long)((g[i].M + 63) / 64) * ((g[i].N + 63) / 64);
         pro = pro || g[i].pro_mode != 0 || g[i].a_gate != nullptr;
     }
-    const bool use_big = big >= 384;           // measured best switch-over (tools/gemm_bench.py sweep)
+    // 128x128 tiles from 900 tiles up (measured switch-over, GN_GEMM_BIG_MIN overrides for a sweep): the [E x 256 x K]
+    // products (850 tiles = 1.66 rounds on 512 resident workgroups) run 4-20 % faster as 3400 64x64 tiles, the
+    // [E x 1536 x 256] product (5100 tiles) and the four-problem X group (1008) want the big tile
+    static const long big_min = getenv("GN_GEMM_BIG_MIN") ? atol(getenv("GN_GEMM_BIG_MIN")) : 900;
+    const bool use_big = big >= big_min;
     long end = 0;
     for (int i = 0; i < gn::GN_MAX_GROUP; ++i) {
         ga.g[i] = g[i < n ? i : n - 1];
