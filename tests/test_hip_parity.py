@@ -191,6 +191,51 @@ def test_gemm_row_map_and_epilogues():
     assert float(out[:, :3].abs().max()) == 0.0
 
 
+def test_gemm_group_and_segmented_k():
+    """gn_gemm_group: unlike problems in one launch (different M/N/K, epilogues, row maps), equal problems (one XCD
+    cut), more than four problems (chunked), and the K-segmented A operand -- against fp64 matmuls."""
+    from gotennet_amd import engine
+    if engine.GEMM_MODE != "f32":
+        pytest.skip("the 3xbf16-split mode issues grouped problems one by one")
+    torch.manual_seed(1)
+    dev = "cuda"
+    r = lambda *s: torch.randn(*s, device=dev)
+    # four unlike problems (spread mode): big rows, a rider with a different K, an activated one, a row-mapped one
+    A0, W0, b0, C0 = r(3000, 64), r(256, 64), r(256), torch.empty(3000, 256, device=dev)
+    A1, W1, C1, R1 = r(130, 512), r(96, 512), torch.empty(130, 96, device=dev), r(130, 96)
+    A2, W2, b2, C2, P2 = r(257, 32), r(128, 32), r(128), torch.empty(257, 128, device=dev), torch.empty(257, 128, device=dev)
+    n, D, Fd = 29, 8, 64
+    X, W3, C3 = r(n, D, Fd), r(Fd, Fd), torch.zeros(n, D, Fd, device=dev)
+    engine.gemm_group([
+        dict(A=A0, lda=64, W=W0, bias=b0, C=C0, ldc=256, rows=3000, nout=256, K=64),
+        dict(A=A1, lda=512, W=W1, C=C1, ldc=96, rows=130, nout=96, K=512, res=R1),
+        dict(A=A2, lda=32, W=W2, bias=b2, C=C2, ldc=128, rows=257, nout=128, K=32, act=(0, 64), pre_out=P2),
+        dict(A=X, lda=Fd, W=W3, C=C3, ldc=Fd, rows=n * 3, nout=Fd, K=Fd, rowmap=(3, D, 0))])
+    dd = lambda t: t.double().cpu()
+    assert rel_err(C0.cpu(), dd(A0) @ dd(W0).T + dd(b0)) < 1e-5
+    assert rel_err(C1.cpu(), dd(R1) + dd(A1) @ dd(W1).T) < 1e-5
+    pre = dd(A2) @ dd(W2).T + dd(b2)
+    assert rel_err(P2.cpu(), pre) < 1e-5
+    ref2 = pre.clone(); ref2[:, :64] = torch.nn.functional.silu(ref2[:, :64])
+    assert rel_err(C2.cpu(), ref2) < 1e-5
+    ref3 = torch.zeros(n, D, Fd, dtype=torch.double); ref3[:, :3] = dd(X)[:, :3] @ dd(W3).T
+    assert rel_err(C3.cpu(), ref3) < 1e-5 and float(C3[:, 3:].abs().max()) == 0.0
+    # six equal problems (one cut of the concatenated tile list; chunks of four)
+    As = [r(500, 64) for _ in range(6)]; Ws = [r(192, 64) for _ in range(6)]
+    Cs = [torch.empty(500, 192, device=dev) for _ in range(6)]
+    engine.gemm_group([dict(A=a, lda=64, W=w, C=c, ldc=192, rows=500, nout=192, K=64) for a, w, c in zip(As, Ws, Cs)])
+    for a, w, c in zip(As, Ws, Cs):
+        assert rel_err(c.cpu(), dd(a) @ dd(w).T) < 1e-5
+    # K-segmented A: C = res + A W_0^T + A2 W_1^T + A3 W_2^T with the weights concatenated along K, row-mapped
+    G0, G1, G2 = r(n, D, Fd), r(n, D, Fd), r(n, D, Fd)
+    Wc, Rr, Cc = r(Fd, 3 * Fd), r(n, D, Fd), torch.zeros(n, D, Fd, device=dev)
+    engine.gemm_group([dict(A=G0, A2=G1, A3=G2, a_seg=Fd, lda=Fd, W=Wc, C=Cc, ldc=Fd, rows=n * 5, nout=Fd, K=3 * Fd,
+                            rowmap=(5, D, 3), res=Rr)])
+    refc = torch.zeros(n, D, Fd, dtype=torch.double)
+    refc[:, 3:] = (dd(Rr) + dd(G0) @ dd(Wc)[:, :Fd].T + dd(G1) @ dd(Wc)[:, Fd:2 * Fd].T + dd(G2) @ dd(Wc)[:, 2 * Fd:].T)[:, 3:]
+    assert rel_err(Cc.cpu(), refc) < 1e-5
+
+
 @pytest.mark.parametrize("F,H", [(512, 8), (1024, 16), (16, 4)])
 def test_forward_feature_width_extremes(F, H):
     """Slot layout corner cases: F = 512/1024 (a slot spans 2/4 waves), F = 16 (64 slots per workgroup)."""
