@@ -537,12 +537,14 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
              ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), ptr(gX2), rl_slice(li), cut_slice(G * li),
              ptr(ga_parts), E,
              N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
-        gemm_group([dict(A=g_x, lda=M * F_, W=_T(lw, "Ws2"), C=g_nproj, ldc=4 * F_, rows=N, nout=F_, K=M * F_,
+        # the edge-sized W_e^T product leaves 0.7 of its last tile round idle: the two K-heavy atom-sized products
+        # (g_x W_s2, g_v W_v2; 60 us as a launch of their own) ride there; W_n1^T needs their output and follows alone
+        gemm_group([dict(A=g_eproj, lda=lde, W=_T(lw, "We"), C=gt_b, ldc=F_, rows=E, nout=F_, K=lde, res=gt_in),
+                    dict(A=g_x, lda=M * F_, W=_T(lw, "Ws2"), C=g_nproj, ldc=4 * F_, rows=N, nout=F_, K=M * F_,
                          c_off=2 * F_, dgate=lt.nproj, g_off=2 * F_),
                     dict(A=g_v, lda=M * F_, W=_T(lw, "Wv2"), C=g_nproj, ldc=4 * F_, rows=N, nout=F_, K=M * F_,
                          c_off=3 * F_, dgate=lt.nproj, g_off=3 * F_)])
-        gemm_group([dict(A=g_eproj, lda=lde, W=_T(lw, "We"), C=gt_b, ldc=F_, rows=E, nout=F_, K=lde, res=gt_in),
-                    dict(A=g_nproj, lda=4 * F_, W=_T(lw, "Wn1"), C=gh2, ldc=F_, rows=N, nout=F_, K=4 * F_, res=gh1)])
+        gemm(g_nproj, 4 * F_, _T(lw, "Wn1"), None, gh2, F_, N, F_, 4 * F_, res=gh1)
         gh, gh2 = gh2, gh
         gX, gX2 = gX2, gX
         if gh2 is gh_caller:
