@@ -113,6 +113,79 @@ def test_forces_match_oracle_wide(F, L, lmax):
     assert float(f.cpu().reshape(3, 14, 3).sum(1).abs().max()) < 1e-3 * float(f.abs().max())
 
 
+def _random_flag_cases(n=16):
+    """Seeded random flag combinations across every constructor switch the HIP path implements."""
+    import random
+    rng = random.Random(1234)
+    cases = []
+    for i in range(n):
+        lmax = rng.choice([1, 2, 2, 3, 4])
+        parts = []
+        if rng.random() < 0.4:
+            parts.append(rng.choice(["gated", "gatedt", "act"]))
+        if rng.random() < 0.3:
+            parts.append("norej")
+        if rng.random() < 0.35:
+            parts.append(rng.choice(["mlp", "mlpa"]))
+        lin = rng.random() < 0.35
+        if lin:
+            parts.append(rng.choice(["linw", "linwa"]))
+            if rng.random() < 0.5:
+                parts.append(rng.choice(["ln", "postln"]))
+        eu = "_".join(parts) if parts else rng.choice([True, True, False])
+        cases.append(dict(
+            n_atom_basis=rng.choice([32, 64]), n_interactions=rng.choice([1, 2, 3]), n_rbf=rng.choice([8, 16]), lmax=lmax,
+            num_heads=rng.choice([4, 8]), scale_edge=rng.random() < 0.5, sep_dir=rng.random() < 0.6,
+            sep_tensor=rng.random() < 0.6, sep_htr=rng.random() < 0.6,
+            radial_basis=rng.choice(["expnorm", "expnorm", "BesselBasis", "GaussianRBF"]), edge_updates=eu,
+            layernorm=rng.choice(["", "", "layer"]), steerable_norm=rng.choice(["", "", "tensor"]),
+            edge_ln=rng.choice(["", "layer"]), evec_dim=(16 if lin and rng.random() < 0.4 else None),
+            emlp_dim=rng.choice([None, 48]), seed=100 + i))
+    return cases
+
+
+@pytest.mark.parametrize("hp", _random_flag_cases(), ids=lambda hp: f"s{hp['seed']}")
+def test_random_flag_combinations_match_oracle(hp):
+    """Forward (h, X) and energy/forces against the oracle for random combinations of the constructor flags (the
+    golden fixtures pin each flag against the reference; this crosses them)."""
+    import gotennet_amd
+    from gotennet_amd.graph import distance
+    from gotennet_amd.outputs import Atomwise
+    from gotennet_amd.pipeline import EnergyForces
+    from oracle import gotennet_oracle as orc
+    hp = dict(hp)
+    seed = hp.pop("seed")
+    torch.manual_seed(seed)
+    F = hp["n_atom_basis"]
+    net = gotennet_amd.GotenNet(cutoff_fn=gotennet_amd.CosineCutoff(5.0), activation="silu", max_z=10, **hp)
+    head = Atomwise(n_in=F, n_hidden=32, derivative="forces")
+    with torch.no_grad():
+        for m in (net, head):
+            for n, p in m.named_parameters():
+                if p.dim() == 1:
+                    p.uniform_(-0.05, 0.05) if not n.endswith("norm.weight") else p.uniform_(0.9, 1.1)
+        for n, b in net.named_buffers():
+            if n.endswith("tensor_layernorm.weight"):
+                b.uniform_(0.9, 1.1)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    hsd = {k: v.clone() for k, v in head.state_dict().items()}
+    cfg = orc.default_config(cutoff=5.0, **{k: v for k, v in hp.items() if k not in ("evec_dim", "emlp_dim", "edge_ln")})
+    pos, batch, z = _synthetic(2, 9, 3.2, seed=seed)
+    z = z.clamp(max=9)
+    ei, w, vec = orc.distance(pos, batch, 5.0)
+    h_ref, X_ref = orc.gotennet_forward({k: v.double() for k, v in sd.items()}, cfg, z, ei, w.double(), vec.double())
+    e_ref, f_ref, _ = orc.energy_and_forces({k: v.double() for k, v in sd.items()}, cfg,
+                                            {k: v.double() for k, v in hsd.items()}, z, pos.double(), batch, 2)
+    net, head = net.cuda().eval(), head.cuda().eval()
+    eic, wc, vecc = distance(pos.cuda(), batch.cuda(), 5.0, 32)
+    assert torch.equal(eic.cpu(), ei)
+    h, X = net(z.cuda(), eic, wc, vecc)
+    assert rel_err(h.cpu(), h_ref) < TOL and rel_err(X.cpu(), X_ref) < TOL
+    e, f = EnergyForces(net, head)(z.cuda(), eic, wc, vecc, batch.cuda(), 2)
+    assert rel_err(e.cpu(), e_ref) < TOL
+    assert rel_err(f.cpu(), f_ref) < TOL
+
+
 def test_forces_asymmetric_graph_neighbor_cap():
     """A dense molecule with max_num_neighbors far below the neighbour count: the capped radius graph is NOT
     symmetric (j->i present, i->j absent), so the by-source (CSC) backward pass sees different rows than the
