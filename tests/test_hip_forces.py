@@ -186,6 +186,53 @@ def test_random_flag_combinations_match_oracle(hp):
     assert rel_err(f.cpu(), f_ref) < TOL
 
 
+def test_full_size_properties():
+    """BASELINE configs[1] at full size (128 aspirin-like molecules, F=256, L=6, lmax=2, the bench model): properties that
+    need no reference -- bit-reproducibility, zero net force per molecule, rotation/translation behaviour of E and F,
+    per-molecule results independent of what else is in the batch."""
+    import gotennet_amd
+    from gotennet_amd import synthetic
+    from gotennet_amd.graph import distance
+    from gotennet_amd.outputs import Atomwise
+    from gotennet_amd.pipeline import EnergyForces
+    dev = "cuda"
+    torch.manual_seed(0)
+    rep = gotennet_amd.GotenNet(n_atom_basis=256, n_interactions=6, n_rbf=32, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
+                                num_heads=8, scale_edge=False, lmax=2, sep_dir=True, sep_tensor=True).to(dev).eval()
+    head = Atomwise(n_in=256, n_hidden=256, derivative="forces").to(dev).eval()
+    run = EnergyForces(rep, head)
+    B, na = 128, 21
+    pos, batch, z = synthetic.make_batch("rmd17_aspirin", B, seed=0)
+    pos, batch, z = pos.to(dev), batch.to(dev), z.to(dev)
+
+    def ef(p, zz=z, bb=batch, nb=B):
+        ei, ed, ev = distance(p, bb, 5.0, 32)
+        e, f = run(zz, ei, ed, ev, bb, nb)
+        return e.clone(), f.clone()
+
+    e0, f0 = ef(pos)
+    assert torch.isfinite(e0).all() and torch.isfinite(f0).all()
+    e1, f1 = ef(pos)
+    assert torch.equal(e0, e1) and torch.equal(f0, f1)                       # no atomics anywhere: bit-reproducible
+    fmax = float(f0.abs().max())
+    assert float(f0.reshape(B, na, 3).sum(1).abs().max()) < 2e-4 * fmax       # translation invariance: zero net force
+    # rotation + translation of every molecule: E invariant, F co-rotates
+    g = torch.Generator().manual_seed(5)
+    Q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))
+    Q = (Q * torch.sign(torch.linalg.det(Q))).float().to(dev)
+    e2, f2 = ef(pos @ Q.T + torch.tensor([1.5, -2.0, 0.25], device=dev))
+    assert rel_err(e2.cpu(), e0.cpu()) < 1e-5
+    assert rel_err(f2.cpu(), (f0 @ Q.T).cpu()) < TOL
+    # a molecule's energy / forces do not depend on its batch mates: reversed molecule order, and a 5-molecule sub-batch
+    perm = torch.arange(B - 1, -1, -1, device=dev)
+    idx = (perm[:, None] * na + torch.arange(na, device=dev)[None]).reshape(-1)
+    e3, f3 = ef(pos[idx], z[idx], batch)
+    assert rel_err(e3.cpu(), e0[perm].cpu()) < 1e-6 and rel_err(f3.cpu(), f0[idx].cpu()) < 1e-5
+    sub = slice(7 * na, 12 * na)
+    e4, f4 = ef(pos[sub], z[sub], batch[: 5 * na], 5)
+    assert rel_err(e4.cpu(), e0[7:12].cpu()) < 1e-6 and rel_err(f4.cpu(), f0[sub].cpu()) < 1e-5
+
+
 def test_forces_asymmetric_graph_neighbor_cap():
     """A dense molecule with max_num_neighbors far below the neighbour count: the capped radius graph is NOT
     symmetric (j->i present, i->j absent), so the by-source (CSC) backward pass sees different rows than the
