@@ -246,8 +246,8 @@ __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, const f
                     for (int m = S::first_row(l); m < S::first_row(l) + 2 * l + 1; ++m)
                         go = S::is_dir(b) ? fma4(re[m], gdX[m], go) : fma4(gdX[m], ld4(Xj + (size_t)m * F), go);
             }
-            const float4 tfb = ld4(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
-            st4(gtr + b * F, (go * xb) * ce);
+            const float4 tfb = ld4_nt(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
+            st4_nt(gtr + b * F, (go * xb) * ce);
             cutp += hsum4(go * tfb * xb);
             pa_h[b] = hsum4(go * vb);
             if (S::is_dir(b)) {
@@ -314,9 +314,9 @@ __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, const f
     for (int e = e0 + slot; e < e1; e += ns) {
         const float gs = g_s_[(size_t)e * H + hq];
         const float4 kj = ld4(qk_ + (size_t)src_[e] * p.ldqk + F + c0);
-        const float4 pta = ld4(eproj_ + (size_t)e * p.lde + c0);
+        const float4 pta = ld4_nt(eproj_ + (size_t)e * p.lde + c0);
         gq = fma4(gs, kj * silu4(pta), gq);
-        st4(g_eproj_ + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dsilu4(pta));   // d/d(pre-activation of t_attn)
+        st4_nt(g_eproj_ + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dsilu4(pta));   // d/d(pre-activation of t_attn)
     }
     st4(&red[slot * F + c0], gq);
     __syncthreads();
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kerne
         const float* gXi = p.g_X1 + (size_t)i * D * F + c0;
 #pragma unroll
         for (int b = 0; b < M; ++b) {
-            const float4 tfb = ld4(tr + b * F);
+            const float4 tfb = ld4_nt(tr + b * F);
             const float ab = ar[hb[b]];
             float4 go;
             if (b == 0) {
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kerne
         }
         const float gs = p.g_s[(size_t)e * H + hq];
         const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
-        const float4 ta = silu4(ld4(p.eproj + (size_t)e * p.lde + c0));
+        const float4 ta = silu4(ld4_nt(p.eproj + (size_t)e * p.lde + c0));
         acc[2 * M + D] = fma4(gs, qi * ta, acc[2 * M + D]);
     }
     reduce_rows<ROWS>(acc, red, slot, c0, F, ns, [&](int row, float4 s) {
@@ -448,8 +448,8 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_TGT_G) void msg_bwd_target_gro
         for (int k = 0; k < KP; ++k) vals[k] = 0.f;
         // one value block: gradient `go` of its gate -> g_tf, cut partial, head partial; returns tf*x*cut + a*v
         auto block = [&](int b, float4 go, bool need_fwd) {
-            const float4 tfb = ld4(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
-            st4(gtr + b * F, (go * xb) * ce);
+            const float4 tfb = ld4_nt(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
+            st4_nt(gtr + b * F, (go * xb) * ce);
             cutp += hsum4(go * tfb * xb);
             const int hb = (b * F + c0) / per_head;
             const float pa = hsum4(go * vb);
@@ -532,9 +532,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const MsgBwdArgs p, const
     for (int e = e0 + slot; e < e1; e += ns) {
         const float gs = p.g_s[(size_t)e * H + hq];
         const float4 kj = ld4(p.qk + (size_t)p.src[e] * p.ldqk + F + c0);
-        const float4 pta = ld4(p.eproj + (size_t)e * p.lde + c0);
+        const float4 pta = ld4_nt(p.eproj + (size_t)e * p.lde + c0);
         gq = fma4(gs, kj * silu4(pta), gq);
-        st4(p.g_eproj + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dsilu4(pta));
+        st4_nt(p.g_eproj + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dsilu4(pta));
     }
     st4(&red[slot * F + c0], gq);
     __syncthreads();
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC_G) void msg_bwd_source_gro
         for (int l = LLO; l <= LHI; ++l) {
             const int kd = (SCALAR ? 1 : 0) + (l - LLO), kt = kd + NL;
             const int bd = l, bt = LMAX + l;
-            const float4 tfd = ld4(tr + bd * F), tft = ld4(tr + bt * F);
+            const float4 tfd = ld4_nt(tr + bd * F), tft = ld4_nt(tr + bt * F);
             const float ad = ar[(bd * F + c0) / per_head], at = ar[(bt * F + c0) / per_head];
             const float4 ot = fma4(at, ld4(vr + bt * F), (tft * ld4(xr + bt * F)) * ce);   // forward tensor gate
             float4 god = zero4(), got = zero4();
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC_G) void msg_bwd_source_gro
         if (SCALAR) {
             const float gs = p.g_s[(size_t)e * H + hq];
             const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
-            const float4 ta = silu4(ld4(p.eproj + (size_t)e * p.lde + c0));
+            const float4 ta = silu4(ld4_nt(p.eproj + (size_t)e * p.lde + c0));
             acc[2 * NB + XR] = fma4(gs, qi * ta, acc[2 * NB + XR]);
         }
     }

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
 #pragma unroll
         for (int b = 0; b < M; ++b) {
             // gotennet.py:516-529: (t_filter * x_j) * cutoff + attn * v_j
-            const float4 sp = (ld4(tr + b * F) * ld4(xr + b * F)) * ce;
+            const float4 sp = (ld4_nt(tr + b * F) * ld4(xr + b * F)) * ce;
             o[b] = fma4(ar[hb[b]], ld4(vr + b * F), sp);
         }
         acc[0] = acc[0] + o[0];
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G) void message_aggregate_group
         const float* re = rl + (size_t)e * D;
         // gotennet.py:516-529: (t_filter * x_j) * cutoff + attn * v_j, block b of the value vector
         auto gate = [&](int b) {
-            const float4 sp = (ld4(tr + b * F) * ld4(xr + b * F)) * ce;
+            const float4 sp = (ld4_nt(tr + b * F) * ld4(xr + b * F)) * ce;
             return fma4(ar[hb[b]], ld4(vr + b * F), sp);
         };
         // all gate loads first (independent, issued back to back), then the X_j rows
