@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_EDGE) void htr_edge_kernel(
             }
             m0 += 2 * l + 1;
         }
-        st4(w + (size_t)e * F + c0, wsum);
+        st4_nt(w + (size_t)e * F + c0, wsum);
     }
 }
 

@@ -19,6 +19,7 @@ struct GemmArgs {
     // K-segmented A operand: columns [s * a_seg, (s+1) * a_seg) of the logical A come from A / A2 / A3 (same lda,
     // same row addressing): sums up to three products that share their output rows.  a_seg = 0: plain A.
     const float* A2; const float* A3; int a_seg;
+    int nt_store;                   // outputs far larger than the L2s are written with non-temporal stores
 };
 
 constexpr int GN_MAX_GROUP = 4;

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
                     const size_t off = (size_t)phys_row(p, gm) * p.ldc + gn;
                     if (p.pre_out) st4(p.pre_out + off, v);
                     if (act) v = silu4(v);
-                    st4(p.C + off, v);
+                    if (p.nt_store) st4_nt(p.C + off, v); else st4(p.C + off, v);
                 }
             }
         }
@@ -377,8 +377,12 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st) {
     static const long big_min = getenv("GN_GEMM_BIG_MIN") ? atol(getenv("GN_GEMM_BIG_MIN")) : 900;
     const bool use_big = big >= big_min;
     long end = 0;
+    // outputs of 100 MB and more (the [E, (1+M)F] edge projection) are stored non-temporally: they are consumed by
+    // later kernels from HBM anyway and would only evict the node tables (K6 +5 %); GN_GEMM_NT_MB overrides
+    static const double nt_min = (getenv("GN_GEMM_NT_MB") ? atof(getenv("GN_GEMM_NT_MB")) : 100.0) * 1048576.0;
     for (int i = 0; i < gn::GN_MAX_GROUP; ++i) {
         ga.g[i] = g[i < n ? i : n - 1];
+        ga.g[i].nt_store = (double)ga.g[i].M * ga.g[i].N * 4.0 >= nt_min;
         if (i < n) end += use_big ? (long)((g[i].M + 127) / 128) * ((g[i].N + 127) / 128)
                                   : (long)((g[i].M + 63) / 64) * ((g[i].N + 63) / 64);
         ga.tile_end[i] = (int)end;
