@@ -10,7 +10,8 @@ host, so a step can be captured in a hipGraph (torch.cuda.CUDAGraph).
 Call order = the reference's op order in GotenNet.forward (gotennet.py:956-1010),
 GATA.forward (366-450) and EQFF.forward (716-748); ``backward`` walks it in
 reverse (what torch.autograd.grad does for the reference at outputs.py:365-375).
-Activations are stored PRE-activation; consumers apply SiLU while loading.
+The backward's copies of activations are PRE-activation (SiLU' needs them); the forward applies SiLU once, in the
+producing GEMM's epilogue.  Independent projections are issued as grouped launches (gn_gemm_group).
 """
 from __future__ import annotations
 
@@ -313,7 +314,6 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
              ptr(h), ptr(X), ptr(h2), ptr(X2), N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
         h, h2 = h2, h
         X, X2 = X2, X
-        # ---- EQFF (716-748): node-local chain on the side stream while HTR walks the edges
         # every product of the updated X (X W_vu^T for EQFF; EQ and the per-degree EK_l for HTR) in one launch
         xprods = [dict(A=X, lda=F_, W=lw.Wvu, C=Xp, ldc=F_, rows=N * D, nout=F_, K=F_)]
         if not last:
