@@ -44,6 +44,31 @@ def test_state_dict_layout_matches_golden_checkpoint():
         assert net.hidden_dim == cfg["n_atom_basis"] and net.cutoff == cfg["cutoff"]
 
 
+def test_load_from_lightning_style_checkpoint(tmp_path):
+    """GotenNet.load_from_checkpoint (reference gotennet.py:904-946): Lightning layout with the ``representation.``
+    prefix, head weights to skip, hyper-parameters incl. a cutoff_fn mapping and the Hydra target key."""
+    import gotennet_amd
+    from tests.golden_util import load_case
+    cfg, sd, head, _ = load_case("opt_mlp_linwa_ln_gated")
+    hp = dict(n_atom_basis=cfg["n_atom_basis"], n_interactions=cfg["n_interactions"], n_rbf=cfg["n_rbf"],
+              cutoff_fn={"cutoff": cfg["cutoff"]}, max_z=cfg["max_z"], num_heads=cfg["num_heads"],
+              scale_edge=cfg["scale_edge"], lmax=cfg["lmax"], sep_dir=cfg["sep_dir"], sep_tensor=cfg["sep_tensor"],
+              edge_updates=cfg["edge_updates"], edge_ln=cfg["edge_ln"], activation=cfg["activation"],
+              __target__="gotennet.models.representation.gotennet.GotenNetWrapper")
+    state = {"representation." + k: v for k, v in sd.items()}
+    state.update({"output_modules.0." + k: v for k, v in head.items()})
+    path = tmp_path / "model.ckpt"
+    torch.save({"hyper_parameters": {"representation": hp}, "state_dict": state}, path)
+    net = gotennet_amd.GotenNet.load_from_checkpoint(str(path))
+    got = net.state_dict()
+    assert set(got) == set(sd)
+    for k in sd:
+        assert torch.equal(got[k], sd[k]), k
+    assert net.cutoff == cfg["cutoff"] and net.gata_list[0].composed_update
+    with pytest.raises(FileNotFoundError):
+        gotennet_amd.GotenNet.load_from_checkpoint(str(tmp_path / "missing.ckpt"))
+
+
 def test_product_path_fails_loudly_on_cpu():
     import gotennet_amd
     from gotennet_amd._lib import GotenNetHipError
