@@ -46,6 +46,7 @@ SIGNATURES = {
     "gn_eqff_update": [_P, _P, _I, _I, _I, _P, _P, _P],
     "gn_gemm_ex": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],
     "gn_gemm_group": [_P, _I, _P],
+    "gn_edge_vectors": [_P, _P, _P, _I, _P, _P, _P],
     "gn_gemm_split": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],
     "gn_split_bf16x3": [_P, C.c_long, _P, _P],
     "gn_htr_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],

@@ -58,7 +58,28 @@ __global__ void radius_fill_kernel(const float* __restrict__ pos, const int64_t*
     }
 }
 
+// edge vectors of a FIXED edge list for new positions (same arithmetic as radius_fill_kernel)
+__global__ void edge_vectors_kernel(const float* __restrict__ pos, const int* __restrict__ src, const int* __restrict__ dst,
+                                    int E, float* __restrict__ edge_vec, float* __restrict__ edge_diff) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int j = src[e], i = dst[e];
+    const float vx = pos[3 * j] - pos[3 * i], vy = pos[3 * j + 1] - pos[3 * i + 1], vz = pos[3 * j + 2] - pos[3 * i + 2];
+    edge_vec[3 * e] = vx; edge_vec[3 * e + 1] = vy; edge_vec[3 * e + 2] = vz;
+    edge_diff[e] = (j == i) ? 0.0f : sqrtf(vx * vx + vy * vy + vz * vz);
+}
+
 }  // namespace gn
+
+extern "C" int gn_edge_vectors(const float* pos, const int* src, const int* dst, int E, float* edge_vec,
+                               float* edge_diff, void* stream) {
+    if (E < 0) return GN_ERR_BAD_ARG;
+    if (E == 0) return GN_OK;
+    hipLaunchKernelGGL(gn::edge_vectors_kernel, dim3((E + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       pos, src, dst, E, edge_vec, edge_diff);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
 
 extern "C" int gn_radius_count(const float* pos, const int64_t* batch, int N, float cutoff, int max_nbr,
                                int* deg, void* stream) {

@@ -178,14 +178,16 @@ def gemm_group(problems):
 
 class Graph:
     """CSR-by-target view of a target-sorted edge list + per-edge geometry (K1);
-    ``csc()`` adds the by-source view the backward needs."""
+    ``csc()`` adds the by-source view the backward needs.  Topology (index arrays) and geometry (rl, phi, cut)
+    are separate: ``set_geometry`` re-evaluates the geometry of a fixed edge list (static-topology steps that are
+    replayed from a hipGraph, pipeline.CapturedStep)."""
 
     def __init__(self, cfg: Config, pw: PackedWeights, n_atoms: int, edge_index: torch.Tensor,
-                 edge_diff: torch.Tensor, edge_vec: torch.Tensor):
+                 edge_diff: Optional[torch.Tensor] = None, edge_vec: Optional[torch.Tensor] = None):
         dev = edge_index.device
         E = edge_index.shape[1]
         self.N, self.E = n_atoms, E
-        self.edge_diff, self.edge_vec = edge_diff, edge_vec
+        self.cfg, self.pw = cfg, pw
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         self.src = torch.empty(E, **i32)
@@ -199,16 +201,34 @@ class Graph:
         self.rl = torch.empty((E, cfg.D), **f32)
         self.phi = torch.empty((E, cfg.R), **f32)
         self.cut = torch.empty(E, **f32)
-        call("gn_edge_geometry", ptr(edge_vec), ptr(edge_diff), ptr(self.src), ptr(self.dst), E,
+        self.perm = self.colptr = self.tgt_by_src = None
+        self.edge_diff = self.edge_vec = None
+        if edge_vec is not None:
+            self.set_geometry(edge_diff, edge_vec)
+
+    def set_geometry(self, edge_diff: torch.Tensor, edge_vec: torch.Tensor):
+        """K1 on the current edge list: unit vectors, real harmonics, radial basis, cutoff."""
+        cfg, pw = self.cfg, self.pw
+        self.edge_diff, self.edge_vec = edge_diff, edge_vec
+        call("gn_edge_geometry", ptr(edge_vec), ptr(edge_diff), ptr(self.src), ptr(self.dst), self.E,
              cfg.lmax, cfg.R, cfg.basis, ptr(pw.rb0), ptr(pw.rb1), float(cfg.cutoff),
              ptr(self.rl), ptr(self.phi), ptr(self.cut), _stream())
-        self.perm = self.colptr = self.tgt_by_src = None
+
+    def set_positions(self, pos: torch.Tensor):
+        """Edge vectors of the fixed edge list for new positions (gn_edge_vectors), then the geometry."""
+        if self.edge_vec is None:
+            self.edge_vec = torch.empty((self.E, 3), dtype=torch.float32, device=pos.device)
+            self.edge_diff = torch.empty(self.E, dtype=torch.float32, device=pos.device)
+        call("gn_edge_vectors", ptr(pos), ptr(self.src), ptr(self.dst), self.E, ptr(self.edge_vec), ptr(self.edge_diff),
+             _stream())
+        self.set_geometry(self.edge_diff, self.edge_vec)
 
     def csc(self):
         """Edges grouped by source (stable): integer index plumbing, no host sync."""
         if self.perm is None:
             self.perm = torch.sort(self.src, stable=True).indices.to(torch.int32)
-            cnt = torch.bincount(self.src, minlength=self.N)
+            cnt = torch.zeros(self.N, dtype=torch.int32, device=self.src.device)
+            cnt.index_add_(0, self.src.long(), torch.ones_like(self.src))    # (torch.bincount reads its size back: a sync)
             self.colptr = torch.zeros(self.N + 1, dtype=torch.int32, device=self.src.device)
             self.colptr[1:] = torch.cumsum(cnt, 0)
             self.tgt_by_src = self.dst[self.perm.long()].contiguous()   # target of each by-source entry

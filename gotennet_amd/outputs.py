@@ -73,7 +73,13 @@ class Atomwise(nn.Module):
     def _weights(self):
         d0, d1 = self.out_net[1].out_net[0], self.out_net[1].out_net[1]
         if isinstance(self.standardize, ScaleShift):
-            scale, shift = float(self.standardize.stddev[0]), float(self.standardize.mean[0])
+            # host copies of the two scalars (kernel arguments), re-read only when the buffers change: a read-back
+            # per step would synchronise the stream (and is not allowed inside a hipGraph capture)
+            sd, mn = self.standardize.stddev, self.standardize.mean
+            key = (sd._version, sd.data_ptr(), mn._version, mn.data_ptr())
+            if getattr(self, "_ss_key", None) != key:
+                self._ss, self._ss_key = (float(sd[0]), float(mn[0])), key
+            scale, shift = self._ss
         else:
             scale, shift = 1.0, 0.0
         return d0, d1, scale, shift

@@ -37,3 +37,55 @@ class EnergyForces:
         gh = self.head.grad_h_raw(pre1, cfg.F)
         g_vec, g_diff = engine.backward(cfg, pw, z32, g, tape, gh, None)
         return e, engine.pos_gradient(g, g_vec, g_diff, sign=-1.0)
+
+
+class CapturedStep:
+    """Energy + forces for a FIXED edge list (static topology: an MD trajectory of molecules whose neighbour lists do
+    not change, e.g. any molecule smaller than the cutoff) as ONE hipGraph replay per step.
+
+    A step of the fused path is ~190 kernel launches; for one 21-atom molecule the eager path is launch-bound
+    (2.7 ms on MI355X) while the kernels themselves need a fraction of that.  ``CapturedStep`` builds the CSR / CSC
+    topology once, records edge vectors -> geometry -> forward -> head -> backward -> force scatter into a
+    ``torch.cuda.CUDAGraph`` (hipGraph on ROCm) and replays it for every new set of positions.  Same kernels, same
+    order, same buffers: results are bit-identical to ``EnergyForces`` on the same edge list.
+
+        step = CapturedStep(EnergyForces(rep, head), z, edge_index, batch, n_mol)
+        energy, forces = step(pos)          # views of static output buffers: copy them to keep them
+    """
+
+    def __init__(self, ef: EnergyForces, z: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tensor, n_mol: int,
+                 warmup: int = 2):
+        rep, head = ef.rep, ef.head
+        self.cfg, self.pw = rep.config(), rep.packed_weights()
+        dev = z.device
+        self.z32 = z.to(torch.int32)
+        self.N, self.n_mol = z.shape[0], n_mol
+        self.head = head
+        self.mol_ptr = molecule_ptr(batch, n_mol)
+        self.pos = torch.zeros((self.N, 3), dtype=torch.float32, device=dev)      # static input buffer
+        self.g = engine.Graph(self.cfg, self.pw, self.N, edge_index)
+        self.g.csc()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():                             # warm-up off the capture
+            for _ in range(max(1, warmup)):
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.energy, self.forces = self._body()
+
+    def _body(self):
+        cfg, pw, g = self.cfg, self.pw, self.g
+        g.set_positions(self.pos)
+        h, X, tape = engine.forward(cfg, pw, self.z32, g, save=True)
+        e, y, pre1 = self.head.energy_raw(h, self.z32, self.mol_ptr, self.n_mol)
+        gh = self.head.grad_h_raw(pre1, cfg.F)
+        g_vec, g_diff = engine.backward(cfg, pw, self.z32, g, tape, gh, None)
+        return e, engine.pos_gradient(g, g_vec, g_diff, sign=-1.0)
+
+    @torch.no_grad()
+    def __call__(self, pos: torch.Tensor):
+        self.pos.copy_(pos)
+        self.graph.replay()
+        return self.energy, self.forces

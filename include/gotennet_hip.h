@@ -294,6 +294,12 @@ int gn_radius_count(const float* pos, const int64_t* batch, int N, float cutoff,
 int gn_radius_fill(const float* pos, const int64_t* batch, int N, float cutoff, int max_nbr,
                    const int64_t* rowptr, int64_t E, int64_t* edge_index, float* edge_vec,
                    float* edge_diff, void* stream);
+/* Edge vectors of a FIXED edge list for new positions (static-topology MD steps replayed from a hipGraph):
+ * edge_vec[e] = pos[src[e]] - pos[dst[e]], edge_diff[e] = |edge_vec[e]| (0 on self-loops); the arithmetic of
+ * gn_radius_fill, so a replayed step is bit-identical to an eager one on the same edge list. */
+int gn_edge_vectors(const float* pos, const int* src, const int* dst, int E, float* edge_vec, float* edge_diff,
+                    void* stream);
+
 
 #ifdef __cplusplus
 }

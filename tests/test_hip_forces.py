@@ -233,6 +233,37 @@ def test_full_size_properties():
     assert rel_err(e4.cpu(), e0[7:12].cpu()) < 1e-6 and rel_err(f4.cpu(), f0[sub].cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("n_mol,lmax", [(1, 2), (5, 2), (2, 4)])
+def test_captured_step_replays_bit_identical(n_mol, lmax):
+    """pipeline.CapturedStep (static topology, one hipGraph replay per step) against the eager fused path on the same
+    edge list, for several position sets: bit-identical energies and forces."""
+    import gotennet_amd
+    from gotennet_amd import synthetic
+    from gotennet_amd.graph import distance
+    from gotennet_amd.outputs import Atomwise
+    from gotennet_amd.pipeline import CapturedStep, EnergyForces
+    dev = "cuda"
+    torch.manual_seed(3)
+    rep = gotennet_amd.GotenNet(n_atom_basis=64, n_interactions=3, n_rbf=16, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
+                                num_heads=8, scale_edge=True, lmax=lmax, sep_dir=True, sep_tensor=True).to(dev).eval()
+    head = Atomwise(n_in=64, n_hidden=32, derivative="forces").to(dev).eval()
+    ef = EnergyForces(rep, head)
+    pos, batch, z = synthetic.make_batch("rmd17_aspirin", n_mol, seed=4)
+    pos, batch, z = pos.to(dev), batch.to(dev), z.to(dev)
+    ei, ed, ev = distance(pos, batch, 5.0, 32)
+    step = CapturedStep(ef, z, ei, batch, n_mol)
+    g = torch.Generator().manual_seed(9)
+    for k in range(4):
+        p = pos + 0.05 * k * torch.randn(pos.shape, generator=g).to(dev)      # small moves: the edge list stays valid
+        e_g, f_g = step(p)
+        e_g, f_g = e_g.clone(), f_g.clone()
+        src, dst = ei[0], ei[1]
+        vec = p[src] - p[dst]
+        diff = torch.where(src == dst, torch.zeros_like(vec[:, 0]), torch.sqrt(vec[:, 0] * vec[:, 0] + vec[:, 1] * vec[:, 1] + vec[:, 2] * vec[:, 2]))
+        e_e, f_e = ef(z, ei, diff, vec, batch, n_mol)
+        assert torch.equal(e_g, e_e) and torch.equal(f_g, f_e), k
+
+
 def test_forces_asymmetric_graph_neighbor_cap():
     """A dense molecule with max_num_neighbors far below the neighbour count: the capped radius graph is NOT
     symmetric (j->i present, i->j absent), so the by-source (CSC) backward pass sees different rows than the
