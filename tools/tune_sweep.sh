@@ -16,7 +16,7 @@ if [ "$1" != "run" ]; then
 else
   cp gotennet_amd/libgotennet_hip.so /tmp/base.so
   one() {
-    python bench.py --no-cpu-baseline --no-split --breakdown 2>gpurun_out/bd.txt | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-12s lmax2 %.3f ms   lmax4 %.3f ms' % ('$1', d['ms_per_step'], d['also']['lmax4']['ms_per_step']))"
+    python bench.py --no-cpu-baseline --no-split --no-graph --breakdown 2>gpurun_out/bd.txt | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-12s lmax2 %.3f ms   lmax4 %.3f ms' % ('$1', d['ms_per_step'], d['also']['lmax4']['ms_per_step']))"
     grep -E "message_backward|htr_backward|message_aggregate|htr_edge|attn_softmax" gpurun_out/bd.txt | awk '{printf "      %-24s %s us\n", $1, $6}'
   }
   one base
