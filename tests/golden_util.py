@@ -14,9 +14,50 @@ def case_names():
                   if not os.path.basename(p).startswith("kat_"))
 
 
+def seeded_fill(module, seed):
+    """Deterministic, order-independent weights: every parameter is filled from a generator seeded by
+    (seed, canonical parameter name).  tools/make_golden.py applies this to the REFERENCE modules, the tests to the
+    mirror modules, so the large ``seeded`` fixtures carry inputs and reference outputs only, not the weights."""
+    import zlib
+    with torch.no_grad():
+        for name, p in module.named_parameters(remove_duplicate=False):
+            canon = name.replace(".layers.", ".dense_layers.")        # MLP registers its layers twice
+            g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(canon.encode())) % (2 ** 31))
+            if canon.endswith("norm.weight"):
+                p.copy_(1.0 + 0.2 * (torch.rand(p.shape, generator=g) - 0.5))
+            elif p.dim() == 1:
+                p.copy_(0.1 * (torch.rand(p.shape, generator=g) - 0.5))
+            elif "A_na" in canon or "A_nbr" in canon:
+                p.copy_(0.5 * torch.randn(p.shape, generator=g))
+                if "A_na" in canon:
+                    p[0].zero_()
+            else:
+                fan_out, fan_in = p.shape
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * (6.0 / (fan_in + fan_out)) ** 0.5)
+
+
+def seeded_modules(cfg):
+    """(representation, head) mirror modules on the CPU with the seeded weights of a ``seeded`` fixture."""
+    import gotennet_amd
+    from gotennet_amd.outputs import Atomwise
+    hp = {k: cfg[k] for k in ("n_atom_basis", "n_interactions", "n_rbf", "lmax", "num_heads", "scale_edge", "sep_dir",
+                              "sep_tensor", "max_z")}
+    net = gotennet_amd.GotenNet(cutoff_fn=gotennet_amd.CosineCutoff(cfg["cutoff"]), **hp)
+    head = Atomwise(n_in=cfg["n_atom_basis"], n_hidden=cfg["head_hidden"], property="property", derivative="forces")
+    seeded_fill(net, cfg["seeded"])
+    seeded_fill(head, cfg["seeded"] + 1)
+    return net, head
+
+
 def load_case(name, dtype=torch.float32):
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     cfg = json.loads(bytes(z["cfg"]).decode())
+    if cfg.get("seeded"):
+        net, hd = seeded_modules(cfg)
+        sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in net.state_dict().items()}
+        head = {k: v.to(dtype) for k, v in hd.state_dict().items()}
+        t = {k: torch.from_numpy(z[k]) for k in z.files if k != "cfg"}
+        return cfg, sd, head, t
     sd = {k[3:]: torch.from_numpy(z[k]).to(dtype) if z[k].dtype.kind == "f" else torch.from_numpy(z[k])
           for k in z.files if k.startswith("sd/")}
     head = {k[5:]: torch.from_numpy(z[k]).to(dtype) for k in z.files if k.startswith("head/")}

@@ -15,7 +15,7 @@ FORCE_CASES = [n for n in case_names() if "shuffled" not in n]
 
 def _head_from_case(cfg, head_sd):
     from gotennet_amd.outputs import Atomwise
-    head = Atomwise(n_in=cfg["n_atom_basis"], n_hidden=16, property="property", derivative="forces")
+    head = Atomwise(n_in=cfg["n_atom_basis"], n_hidden=cfg.get("head_hidden", 16), property="property", derivative="forces")
     head.load_state_dict(head_sd, strict=True)
     return head.cuda().eval()
 

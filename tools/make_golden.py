@@ -91,6 +91,17 @@ CASES = {
                           dict(mols=[6, 5], box=3.0, seed=24)),
 }
 
+# full-width models (BASELINE configs[0] and the configs[1] model): weights come from tests.golden_util.seeded_fill,
+# the fixture stores inputs and reference outputs only
+SEEDED = {
+    # C1: QM9_small -- F=128, L=4, lmax=2, one 19-atom molecule, yaml flags
+    "c1_qm9_small_seeded": (dict(n_atom_basis=128, n_interactions=4, n_rbf=32, lmax=2, num_heads=8, scale_edge=False,
+                                 sep_dir=True, sep_tensor=True, max_z=10), dict(mols=[19], box=4.0, seed=31), 71, 64),
+    # C2 model (F=256, L=6, lmax=2) on three 21-atom molecules
+    "c2_model_3mol_seeded": (dict(n_atom_basis=256, n_interactions=6, n_rbf=32, lmax=2, num_heads=8, scale_edge=False,
+                                  sep_dir=True, sep_tensor=True, max_z=10), dict(mols=[21, 21, 21], box=4.6, seed=32), 72, 256),
+}
+
 CUTOFF = 5.0
 
 
@@ -236,6 +247,53 @@ def build(name, hp, spec):
           f"fp32-vs-fp64 dh={float((h.double()-h64).abs().max()):.2e} -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
+def build_seeded(name, hp, spec, wseed, head_hidden):
+    """Reference outputs (fp32 and fp64, energy/forces through the reference Atomwise) for seeded weights."""
+    sys.path.insert(0, ROOT)
+    from tests.golden_util import seeded_fill
+    sys.modules.setdefault("torch_scatter", types.ModuleType("torch_scatter"))
+    sys.modules["torch_scatter"].scatter = ref_shims._scatter
+    sys.modules.setdefault("ase", types.ModuleType("ase"))
+    sys.modules.setdefault("ase.data", types.ModuleType("ase.data"))
+    sys.modules["ase.data"].atomic_masses = np.ones(120)
+    sys.modules["ase"].data = sys.modules["ase.data"]
+    from gotennet.models.components import outputs as ref_out
+    pos, batch, z = make_molecules(spec)
+    out = {}
+    for tag, dt in (("", torch.float32), ("_f64", torch.float64)):
+        torch.manual_seed(0)
+        net = ref.GotenNet(cutoff_fn=ref_layers.CosineCutoff(CUTOFF), **hp)
+        head = ref_out.Atomwise(n_in=hp["n_atom_basis"], n_hidden=head_hidden, activation=torch.nn.functional.silu,
+                                property="property", derivative="forces")
+        seeded_fill(net, wseed)
+        seeded_fill(head, wseed + 1)
+        net, head = net.to(dt).eval(), head.to(dt).eval()
+        p = pos.to(dt).clone().requires_grad_(True)
+        ei, w32, vec32 = ref_layers.Distance(CUTOFF, max_num_neighbors=32, loop=True)(pos, batch)
+        vec = p[ei[0]] - p[ei[1]]
+        m_ = ei[0] != ei[1]
+        w = torch.zeros(vec.size(0), dtype=dt)
+        w[m_] = torch.norm(vec[m_], dim=-1)
+        hh, XX = net(z, ei, w, vec * 1.0)
+
+        class _D(dict):
+            __getattr__ = dict.__getitem__
+        res = head(_D(z=z, pos=p, batch=batch, representation=hh, vector_representation=XX))
+        with torch.no_grad():                         # (h, X) from the fp32 edge inputs cast to the run's dtype
+            h_in, X_in = net(z, ei, w32.to(dt).clone(), vec32.to(dt).clone())
+        out["h" + tag], out["X" + tag] = h_in.numpy(), X_in.numpy()
+        out["energy" + tag], out["forces" + tag] = res["property"].detach().numpy(), res["forces"].detach().numpy()
+        if not tag:
+            out.update(edge_index=ei.numpy(), edge_diff=w32.numpy(), edge_vec=vec32.numpy())
+    cfg = {**dict(cutoff=CUTOFF, epsilon=1e-8, sep_htr=True, n_mol=len(spec["mols"]), seeded=wseed, head_hidden=head_hidden), **hp}
+    arrays = dict(z=z.numpy(), pos=pos.numpy(), batch=batch.numpy(),
+                  cfg=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8), **out)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: N={len(z)} E={out['edge_index'].shape[1]} |h|max={np.abs(out['h']).max():.3f} "
+          f"fp32-vs-fp64 dh={np.abs(out['h'] - out['h_f64']).max():.2e} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 def sh_kat():
     """Known-answer table for TensorInit (layers.py:805-902) on fixed unit vectors, l <= 4,
     and for ExpNormalSmearing/CosineCutoff incl. d = 0 and d >= cutoff."""
@@ -264,5 +322,8 @@ if __name__ == "__main__":
     for name, (hp, spec) in CASES.items():
         if not only or name in only:
             build(name, hp, spec)
+    for name, (hp, spec, wseed, hh) in SEEDED.items():
+        if not only or name in only:
+            build_seeded(name, hp, spec, wseed, hh)
     if not only:
         sh_kat()
