@@ -186,6 +186,38 @@ def test_random_flag_combinations_match_oracle(hp):
     assert rel_err(f.cpu(), f_ref) < TOL
 
 
+def test_full_size_forward_matches_reference():
+    """BASELINE configs[1] at FULL size against the reference itself (tests/golden/c2_full_forward_seeded.npz: the
+    reference's CPU forward on the bench inputs with the seeded C2 model): bit-exact edge list, sampled rows and column
+    sums of (h, X), every molecule's energy."""
+    import json
+    import numpy as np
+    from gotennet_amd import synthetic
+    from gotennet_amd.graph import distance
+    from gotennet_amd.pipeline import EnergyForces
+    from tests.golden_util import GOLDEN_DIR, seeded_modules
+    import os
+    zf = np.load(os.path.join(GOLDEN_DIR, "c2_full_forward_seeded.npz"))
+    cfg = json.loads(bytes(zf["cfg"]).decode())
+    net, head = seeded_modules(cfg)
+    net, head = net.cuda().eval(), head.cuda().eval()
+    pos, batch, z = synthetic.make_batch(cfg["workload"], cfg["n_mol"], seed=cfg["batch_seed"])
+    pos, batch, z = pos.cuda(), batch.cuda(), z.cuda()
+    ei, ed, ev = distance(pos, batch, cfg["cutoff"], 32)
+    assert ei.shape[1] == int(zf["n_edges"])
+    chk = [int(ei[0].sum()), int(ei[1].sum()), int((ei[0] * 31 + ei[1]).sum() % (2 ** 61))]
+    assert chk == [int(v) for v in zf["edge_index_checksum"]]                # integer work: bit-exact
+    h, X = net(z, ei, ed, ev)
+    t = lambda k: torch.from_numpy(zf[k])
+    assert rel_err(h[t("rows_h").cuda()].cpu(), t("h_rows")) < TOL
+    assert rel_err(X[t("rows_X").cuda()].cpu(), t("X_rows")) < TOL
+    # column sums over 2688 atoms: errors relative to the absolute mass of the column sums' terms
+    assert float((h.double().sum(0).cpu() - t("h_colsum")).abs().max()) < TOL * float(zf["h_abs_sum"]) / h.shape[1]
+    assert float((X.double().sum(0).cpu() - t("X_colsum")).abs().max()) < TOL * float(zf["X_abs_sum"]) / X[0].numel()
+    e, _ = EnergyForces(net, head)(z, ei, ed, ev, batch, cfg["n_mol"], forces=False)
+    assert rel_err(e.cpu(), t("energy")) < TOL
+
+
 def test_full_size_properties():
     """BASELINE configs[1] at full size (128 aspirin-like molecules, F=256, L=6, lmax=2, the bench model): properties that
     need no reference -- bit-reproducibility, zero net force per molecule, rotation/translation behaviour of E and F,

@@ -294,6 +294,51 @@ def build_seeded(name, hp, spec, wseed, head_hidden):
           f"fp32-vs-fp64 dh={np.abs(out['h'] - out['h_f64']).max():.2e} -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
+def build_full_forward(name="c2_full_forward_seeded", wseed=72, n_mol=128):
+    """BASELINE configs[1] at FULL size (128 aspirin-like molecules, the bench inputs, the C2 model with seeded weights):
+    the reference's forward and per-molecule energies on the CPU (forces need > 62 GB of autograd state there).  The
+    fixture keeps sampled rows and column sums of (h, X) and all energies; inputs are regenerated from their seeds."""
+    sys.path.insert(0, ROOT)
+    from tests.golden_util import seeded_fill
+    from gotennet_amd import synthetic
+    sys.modules.setdefault("torch_scatter", types.ModuleType("torch_scatter"))
+    sys.modules["torch_scatter"].scatter = ref_shims._scatter
+    sys.modules.setdefault("ase", types.ModuleType("ase"))
+    sys.modules.setdefault("ase.data", types.ModuleType("ase.data"))
+    sys.modules["ase.data"].atomic_masses = np.ones(120)
+    sys.modules["ase"].data = sys.modules["ase.data"]
+    from gotennet.models.components import outputs as ref_out
+    hp = dict(n_atom_basis=256, n_interactions=6, n_rbf=32, lmax=2, num_heads=8, scale_edge=False, sep_dir=True,
+              sep_tensor=True, max_z=10)
+    pos, batch, z = synthetic.make_batch("rmd17_aspirin", n_mol, seed=0)
+    torch.manual_seed(0)
+    net = ref.GotenNet(cutoff_fn=ref_layers.CosineCutoff(CUTOFF), **hp)
+    head = ref_out.Atomwise(n_in=256, n_hidden=256, activation=torch.nn.functional.silu, property="property")
+    seeded_fill(net, wseed)
+    seeded_fill(head, wseed + 1)
+    net, head = net.eval(), head.eval()
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        ei, w, vec = ref_layers.Distance(CUTOFF, max_num_neighbors=32, loop=True)(pos, batch)
+        h, X = net(z, ei, w.clone(), vec.clone())
+
+        class _D(dict):
+            __getattr__ = dict.__getitem__
+        e = head(_D(z=z, pos=pos, batch=batch, representation=h, vector_representation=X))["property"]
+    rows_h, rows_X = torch.arange(0, len(z), 37), torch.arange(0, len(z), 149)
+    cfg = {**dict(cutoff=CUTOFF, epsilon=1e-8, sep_htr=True, n_mol=n_mol, seeded=wseed, head_hidden=256,
+                  workload="rmd17_aspirin", batch_seed=0), **hp}
+    arrays = dict(cfg=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8), n_edges=np.array(ei.shape[1]),
+                  edge_index_checksum=np.array([int(ei[0].sum()), int(ei[1].sum()), int((ei[0] * 31 + ei[1]).sum() % (2 ** 61))]),
+                  rows_h=rows_h.numpy(), h_rows=h[rows_h].numpy(), rows_X=rows_X.numpy(), X_rows=X[rows_X].numpy(),
+                  h_colsum=h.double().sum(0).numpy(), X_colsum=X.double().sum(0).numpy(),
+                  h_abs_sum=np.array(float(h.double().abs().sum())), X_abs_sum=np.array(float(X.double().abs().sum())),
+                  energy=e.numpy())
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: N={len(z)} E={ei.shape[1]} |h|max={float(h.abs().max()):.3f} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 def sh_kat():
     """Known-answer table for TensorInit (layers.py:805-902) on fixed unit vectors, l <= 4,
     and for ExpNormalSmearing/CosineCutoff incl. d = 0 and d >= cutoff."""
@@ -325,5 +370,7 @@ if __name__ == "__main__":
     for name, (hp, spec, wseed, hh) in SEEDED.items():
         if not only or name in only:
             build_seeded(name, hp, spec, wseed, hh)
+    if "c2_full_forward_seeded" in only:           # minutes of CPU time: only on request
+        build_full_forward()
     if not only:
         sh_kat()
