@@ -214,8 +214,11 @@ def test_full_size_forward_matches_reference():
     # column sums over 2688 atoms: errors relative to the absolute mass of the column sums' terms
     assert float((h.double().sum(0).cpu() - t("h_colsum")).abs().max()) < TOL * float(zf["h_abs_sum"]) / h.shape[1]
     assert float((X.double().sum(0).cpu() - t("X_colsum")).abs().max()) < TOL * float(zf["X_abs_sum"]) / X[0].numel()
-    e, _ = EnergyForces(net, head)(z, ei, ed, ev, batch, cfg["n_mol"], forces=False)
+    e, f = EnergyForces(net, head)(z, ei, ed, ev, batch, cfg["n_mol"])
     assert rel_err(e.cpu(), t("energy")) < TOL
+    # forces of the first 32 molecules by the reference's autograd (a quarter batch fits the build container)
+    nf = int(zf["n_force_molecules"]) * (pos.shape[0] // cfg["n_mol"])
+    assert rel_err(f[:nf].cpu(), t("forces_part")) < TOL
 
 
 def test_full_size_properties():

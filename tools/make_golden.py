@@ -325,6 +325,24 @@ def build_full_forward(name="c2_full_forward_seeded", wseed=72, n_mol=128):
         class _D(dict):
             __getattr__ = dict.__getitem__
         e = head(_D(z=z, pos=pos, batch=batch, representation=h, vector_representation=X))["property"]
+    # energy + forces by the reference's own autograd for the first n_force molecules (a quarter of the batch fits
+    # in this container's 62 GB; molecules are independent, so they are the full batch's values for those atoms)
+    n_force = 32
+    na = len(z) // n_mol
+    pf = pos[: n_force * na].clone().requires_grad_(True)
+    bf, zf_ = batch[: n_force * na], z[: n_force * na]
+    head_f = ref_out.Atomwise(n_in=256, n_hidden=256, activation=torch.nn.functional.silu, property="property",
+                              derivative="forces")
+    head_f.load_state_dict(head.state_dict())
+    ei_f, _, _ = ref_layers.Distance(CUTOFF, max_num_neighbors=32, loop=True)(pf.detach(), bf)
+    vec_f = pf[ei_f[0]] - pf[ei_f[1]]
+    m_f = ei_f[0] != ei_f[1]
+    w_f = torch.zeros(vec_f.size(0))
+    w_f[m_f] = torch.norm(vec_f[m_f], dim=-1)
+    hf, Xf = net(zf_, ei_f, w_f, vec_f * 1.0)
+    res_f = head_f(_D(z=zf_, pos=pf, batch=bf, representation=hf, vector_representation=Xf))
+    forces_part = res_f["forces"].detach()
+    assert torch.allclose(res_f["property"].detach(), e[:n_force], rtol=1e-5, atol=1e-5)
     rows_h, rows_X = torch.arange(0, len(z), 37), torch.arange(0, len(z), 149)
     cfg = {**dict(cutoff=CUTOFF, epsilon=1e-8, sep_htr=True, n_mol=n_mol, seeded=wseed, head_hidden=256,
                   workload="rmd17_aspirin", batch_seed=0), **hp}
@@ -333,7 +351,7 @@ def build_full_forward(name="c2_full_forward_seeded", wseed=72, n_mol=128):
                   rows_h=rows_h.numpy(), h_rows=h[rows_h].numpy(), rows_X=rows_X.numpy(), X_rows=X[rows_X].numpy(),
                   h_colsum=h.double().sum(0).numpy(), X_colsum=X.double().sum(0).numpy(),
                   h_abs_sum=np.array(float(h.double().abs().sum())), X_abs_sum=np.array(float(X.double().abs().sum())),
-                  energy=e.numpy())
+                  energy=e.numpy(), n_force_molecules=np.array(n_force), forces_part=forces_part.numpy())
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **arrays)
     print(f"{name}: N={len(z)} E={ei.shape[1]} |h|max={float(h.abs().max()):.3f} -> {os.path.getsize(path)/1024:.0f} KiB")
