@@ -100,6 +100,9 @@ SEEDED = {
     # C2 model (F=256, L=6, lmax=2) on three 21-atom molecules
     "c2_model_3mol_seeded": (dict(n_atom_basis=256, n_interactions=6, n_rbf=32, lmax=2, num_heads=8, scale_edge=False,
                                   sep_dir=True, sep_tensor=True, max_z=10), dict(mols=[21, 21, 21], box=4.6, seed=32), 72, 256),
+    # the north-star's "L=4" reading: the same model at lmax=4, one 21-atom molecule
+    "c2_model_lmax4_1mol_seeded": (dict(n_atom_basis=256, n_interactions=6, n_rbf=32, lmax=4, num_heads=8, scale_edge=False,
+                                        sep_dir=True, sep_tensor=True, max_z=10), dict(mols=[21], box=4.6, seed=33), 73, 256),
 }
 
 CUTOFF = 5.0
