@@ -115,7 +115,8 @@ int gn_gemm_ex(const float* A, int lda, const float* W, const float* bias, float
                int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
                const float* a_gate, int ldg, void* stream);
 
-/* Several INDEPENDENT gn_gemm_ex problems in one launch (no problem may read what another writes).  The atom-sized
+/* Several INDEPENDENT gn_gemm_ex problems (Dense products, layers.py:457-529; call sites gotennet.py:400-407, 432-441,
+ * 611, 728, 738) in one launch (no problem may read what another writes).  The atom-sized
  * products of a layer (x / v, EQ / EK_l / X W_vu^T, and the matching input-gradient products) fill a fraction of the
  * 256 CUs one at a time; a group walks all their tiles with one persistent grid.  n <= 4; every field has the meaning
  * of the gn_gemm_ex argument of the same name. */
@@ -138,7 +139,7 @@ typedef struct gn_gemm_desc {
 } gn_gemm_desc;
 int gn_gemm_group(const gn_gemm_desc* problems, int n, void* stream);
 
-/* 3 x bf16 split variant: same contract as gn_gemm_ex, but the weight is passed as three
+/* 3 x bf16 split variant of the same Dense products (layers.py:457-529): same contract as gn_gemm_ex, but the weight is passed as three
  * bf16 planes W3[3][Nout][K] (hi, mid, lo with W = hi + mid + lo to 2^-25; made once by gn_split_bf16x3) and the
  * product is accumulated in fp32 from the six plane pairs of order <= 2 on the bf16 matrix cores: fp32-class
  * error (<= 1e-6 relative) at 16/6 of the exact-fp32 MFMA rate.  K must be a multiple of 8. */
@@ -294,7 +295,8 @@ int gn_radius_count(const float* pos, const int64_t* batch, int N, float cutoff,
 int gn_radius_fill(const float* pos, const int64_t* batch, int N, float cutoff, int max_nbr,
                    const int64_t* rowptr, int64_t E, int64_t* edge_index, float* edge_vec,
                    float* edge_diff, void* stream);
-/* Edge vectors of a FIXED edge list for new positions (static-topology MD steps replayed from a hipGraph):
+/* Edge vectors of a FIXED edge list for new positions (static-topology MD steps replayed from a hipGraph; the
+ * arithmetic of Distance.forward, layers.py:1593-1600):
  * edge_vec[e] = pos[src[e]] - pos[dst[e]], edge_diff[e] = |edge_vec[e]| (0 on self-loops); the arithmetic of
  * gn_radius_fill, so a replayed step is bit-identical to an eager one on the same edge list. */
 int gn_edge_vectors(const float* pos, const int* src, const int* dst, int E, float* edge_vec, float* edge_diff,
