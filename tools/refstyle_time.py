@@ -1,0 +1,38 @@
+"""Reference-style call (GotenNetWrapper(batch) -> Atomwise(derivative='forces') with torch.autograd.grad inside) vs the
+fused pipeline, on the bench workload: what a GotenModel user gets without touching the calling code."""
+import os, sys, time, types, torch
+sys.path.insert(0, os.getcwd())
+import gotennet_amd
+from gotennet_amd import synthetic
+from gotennet_amd.graph import distance
+from gotennet_amd.outputs import Atomwise
+from gotennet_amd.pipeline import EnergyForces
+torch.manual_seed(0)
+net = gotennet_amd.GotenNetWrapper(n_atom_basis=256, n_interactions=6, n_rbf=32, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
+                                   num_heads=8, scale_edge=False, lmax=2, sep_dir=True, sep_tensor=True).cuda().eval()
+head = Atomwise(n_in=256, n_hidden=256, property="property", derivative="forces").cuda().eval()
+pos, batch, z = synthetic.make_batch("rmd17_aspirin", 128, seed=0)
+pos, batch, z = pos.cuda(), batch.cuda(), z.cuda()
+
+def ref_style():
+    p = pos.clone().requires_grad_(True)
+    inp = types.SimpleNamespace(z=z, pos=p, batch=batch)
+    inp.representation, inp.vector_representation = net(inp)
+    out = head(inp)
+    return out["property"], out["forces"]
+
+ei, ed, ev = distance(pos, batch, 5.0, 32)
+ef = EnergyForces(net, head)
+def fused():
+    return ef(z, ei, ed, ev, batch, 128)
+
+def timed(fn, it=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(it): fn()
+    torch.cuda.synchronize(); return 1e3 * (time.perf_counter() - t0) / it
+
+e1, f1 = ref_style(); e2, f2 = fused()
+print("reference-style (wrapper + radius graph + autograd.grad): %.3f ms/step" % timed(ref_style))
+print("fused pipeline (edge list given):                         %.3f ms/step" % timed(fused))
+print("max |dE| %.3e  max |dF| %.3e" % (float((e1 - e2).abs().max()), float((f1.detach() - f2).abs().max())))
