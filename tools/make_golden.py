@@ -360,6 +360,80 @@ def build_full_forward(name="c2_full_forward_seeded", wseed=72, n_mol=128):
     print(f"{name}: N={len(z)} E={ei.shape[1]} |h|max={float(h.abs().max()):.3f} -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
+# BASELINE configs[2] / configs[4] workloads (gotennet_amd.synthetic, the bench inputs) through the reference with the
+# seeded full-width models: name -> (hyper-parameters, workload, molecules, weight seed, head hidden, row stride h / X)
+WORKLOAD_CASES = {
+    # C3: MD22 Ac-Ala3-NHMe-like (42 atoms), the C2 model, energy + forces; molecules 0..1 of the bench batch
+    "c3_ac_ala3_2mol_seeded": (dict(n_atom_basis=256, n_interactions=6, n_rbf=32, lmax=2, num_heads=8, scale_edge=False,
+                                    sep_dir=True, sep_tensor=True, max_z=10), "md22_ac_ala3", 2, 74, 256, 1, 3),
+    # C5: MD22 double-walled-nanotube-like (370 atoms, ~63 neighbours inside 5 A -> the 32-neighbour cap of
+    # Distance.forward (layers.py:1588-1604) is active on almost every atom), F=256, L=6, lmax=3; molecule 0 of the bench batch
+    "c5_nanotube_1mol_seeded": (dict(n_atom_basis=256, n_interactions=6, n_rbf=32, lmax=3, num_heads=8, scale_edge=False,
+                                     sep_dir=True, sep_tensor=True, max_z=10), "md22_nanotube", 1, 75, 256, 7, 23),
+}
+
+
+def build_workload(name, hp, workload, n_mol, wseed, head_hidden, stride_h, stride_X):
+    """Reference (h, X), energy and forces on molecules of a gotennet_amd.synthetic workload (the bench inputs), radius
+    graph by the reference's Distance (neighbour cap included).  Stores the full edge list, energies, forces, sampled
+    rows + column sums of (h, X) in fp32, and the same rows from an fp64 forward."""
+    sys.path.insert(0, ROOT)
+    from tests.golden_util import seeded_fill
+    from gotennet_amd import synthetic
+    sys.modules.setdefault("torch_scatter", types.ModuleType("torch_scatter"))
+    sys.modules["torch_scatter"].scatter = ref_shims._scatter
+    sys.modules.setdefault("ase", types.ModuleType("ase"))
+    sys.modules.setdefault("ase.data", types.ModuleType("ase.data"))
+    sys.modules["ase.data"].atomic_masses = np.ones(120)
+    sys.modules["ase"].data = sys.modules["ase.data"]
+    from gotennet.models.components import outputs as ref_out
+    torch.set_num_threads(8)
+    pos, batch, z = synthetic.make_batch(workload, n_mol, seed=0)
+    torch.manual_seed(0)
+    net = ref.GotenNet(cutoff_fn=ref_layers.CosineCutoff(CUTOFF), **hp)
+    head = ref_out.Atomwise(n_in=hp["n_atom_basis"], n_hidden=head_hidden, activation=torch.nn.functional.silu,
+                            property="property", derivative="forces")
+    seeded_fill(net, wseed)
+    seeded_fill(head, wseed + 1)
+    net, head = net.eval(), head.eval()
+    dist = ref_layers.Distance(CUTOFF, max_num_neighbors=32, loop=True)
+    ei, w32, vec32 = dist(pos, batch)
+    deg = torch.bincount(ei[1], minlength=len(z))
+    p = pos.clone().requires_grad_(True)
+    vec = p[ei[0]] - p[ei[1]]
+    m_ = ei[0] != ei[1]
+    w = torch.zeros(vec.size(0))
+    w[m_] = torch.norm(vec[m_], dim=-1)
+    hh, XX = net(z, ei, w, vec * 1.0)
+
+    class _D(dict):
+        __getattr__ = dict.__getitem__
+    res = head(_D(z=z, pos=p, batch=batch, representation=hh, vector_representation=XX))
+    energy, forces = res["property"].detach(), res["forces"].detach()
+    del res, hh, XX
+    with torch.no_grad():
+        h, X = net(z, ei, w32.clone(), vec32.clone())
+        net64 = ref.GotenNet(cutoff_fn=ref_layers.CosineCutoff(CUTOFF), **hp)
+        seeded_fill(net64, wseed)
+        net64 = net64.double().eval()
+        h64, X64 = net64(z, ei, w32.double(), vec32.double())
+    rows_h, rows_X = torch.arange(0, len(z), stride_h), torch.arange(0, len(z), stride_X)
+    cfg = {**dict(cutoff=CUTOFF, epsilon=1e-8, sep_htr=True, n_mol=n_mol, seeded=wseed, head_hidden=head_hidden,
+                  workload=workload, batch_seed=0), **hp}
+    arrays = dict(cfg=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8),
+                  edge_index=ei.numpy().astype(np.int32), max_in_degree=np.array(int(deg.max())),
+                  rows_h=rows_h.numpy(), h_rows=h[rows_h].numpy(), h_rows_f64=h64[rows_h].numpy(),
+                  rows_X=rows_X.numpy(), X_rows=X[rows_X].numpy(), X_rows_f64=X64[rows_X].numpy(),
+                  h_colsum=h.double().sum(0).numpy(), X_colsum=X.double().sum(0).numpy(),
+                  h_abs_sum=np.array(float(h.double().abs().sum())), X_abs_sum=np.array(float(X.double().abs().sum())),
+                  energy=energy.numpy(), forces=forces.numpy())
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: N={len(z)} E={ei.shape[1]} max in-degree {int(deg.max())} |h|max={float(h.abs().max()):.3f} "
+          f"|X|max={float(X.abs().max()):.4f} fp32-vs-fp64 dh={float((h.double() - h64).abs().max()):.2e} "
+          f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def sh_kat():
     """Known-answer table for TensorInit (layers.py:805-902) on fixed unit vectors, l <= 4,
     and for ExpNormalSmearing/CosineCutoff incl. d = 0 and d >= cutoff."""
@@ -393,5 +467,8 @@ if __name__ == "__main__":
             build_seeded(name, hp, spec, wseed, hh)
     if "c2_full_forward_seeded" in only:           # minutes of CPU time: only on request
         build_full_forward()
+    for name, spec in WORKLOAD_CASES.items():      # tens of seconds and GBs of autograd state: only on request
+        if name in only:
+            build_workload(name, *spec)
     if not only:
         sh_kat()
