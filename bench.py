@@ -36,6 +36,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32, exact fp32
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
 class KernelTimer:
@@ -46,7 +47,7 @@ class KernelTimer:
     def tag_of(name, args):
         if name in ("gn_gemm_ex", "gn_gemm_split"):
             return f"gn_gemm[{args[6]}x{args[7]}x{args[8]}]"
-        if name == "gn_gemm_group":            # several independent problems in one launch
+        if name in ("gn_gemm_group", "gn_gemm_group_split"):   # several independent problems in one launch
             return "gn_gemm[" + "+".join(f"{args[0][i].M}x{args[0][i].N}x{args[0][i].K}" for i in range(args[1])) + "]"
         return name
 
@@ -91,8 +92,74 @@ def main():
     ap.add_argument("--no-split", action="store_true", help="skip the short 3xbf16-split side measurement")
     ap.add_argument("--no-graph", action="store_true", help="skip the single-molecule hipGraph-replay side measurement")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (path check)")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the short C3 / C5 side measurements")
+    ap.add_argument("--selftest-dist", action="store_true",
+                    help="CPU-only check of the launch / rendezvous / shard / all-reduce / JSON path (gloo backend, the step "
+                         "replaced by a per-molecule checksum of the synthetic inputs); no kernel runs, no throughput claim")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a)                      # plain `python bench.py --gpus N`: spawn one rank per GPU
+    worker(a)
 
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _spawned(local_rank, a, port):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(a.gpus),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes on this driver)
+    worker(a)
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: one process per GPU via torch.multiprocessing.spawn
+    (the same ranks `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` would start)."""
+    import torch.multiprocessing as mp
+    if not a.selftest_dist and torch.cuda.device_count() < a.gpus:
+        raise SystemExit(f"--gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node")
+    mp.spawn(_spawned, args=(a, _free_port()), nprocs=a.gpus, join=True)
+
+
+def selftest_dist(a, rank, world):
+    """The distributed skeleton of the bench without a GPU: rendezvous (gloo), molecule shards, the one all-reduce of
+    the zero-padded per-molecule vector, max-over-ranks timing, rank-0 JSON.  The per-molecule value is a checksum of
+    the synthetic inputs (sum of z * |pos|^2) -- input synthesis, not path arithmetic."""
+    import torch.distributed as dist
+    from gotennet_amd import synthetic
+    from gotennet_amd.parallel import reduce_energies
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = a.batch
+    pos, batch, z = synthetic.make_batch(a.workload, B, seed=0, first_molecule=rank * B)
+    val = torch.zeros(B, dtype=torch.float64).index_add_(0, batch, z.double() * (pos.double() ** 2).sum(1)).float()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        e_all = reduce_energies(val, rank * B, B * world)
+    dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    ok = bool(torch.equal(e_all[rank * B:(rank + 1) * B], val)) and int((e_all != 0).sum()) == B * world
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        out = {"selftest": "dist", "backend": "gloo", "n_gpus": 0, "n_ranks_seen": dist.get_world_size(),
+               "global_batch": B * world, "steps": a.steps, "energy_vector_len": int(e_all.numel()),
+               "energy_checksum": float(e_all.double().sum()), "shards_consistent": bool(flag.item() == 1.0),
+               "ms_per_step": round(1e3 * float(tmax.item()) / max(a.steps, 1), 4)}
+        os.write(JSON_FD, (json.dumps(out) + "\n").encode())
+    dist.destroy_process_group()
+
+
+def worker(a):
     # keep stdout clean for the ONE JSON line: RCCL prints a version banner to C stdout at exit
     global JSON_FD
     JSON_FD = os.dup(1)
@@ -101,8 +168,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
+    if a.selftest_dist:
+        return selftest_dist(a, rank, world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -114,38 +182,45 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
-    res = measure(a, a.lmax, a.steps, a.warmup, rank, world, dev, dist)
-    side = None
-    if a.lmax != 4 and not a.no_lmax4:
-        # the north-star's "L=4" target shape (lmax = 4), reported alongside (short run)
-        side = measure(a, 4, max(3, a.steps // 4), 2, rank, world, dev, dist)
-    split = None
-    if not a.no_split and os.environ.get("GN_GEMM_MODE", "f32") == "f32":
-        # opt-in projection mode (3 x bf16-split MFMA, fp32-class error), reported alongside
-        from gotennet_amd import engine
-        engine.GEMM_MODE = "split"
+    from gotennet_amd import engine
+    res = measure(a, a.workload, a.batch, a.lmax, a.steps, a.warmup, rank, world, dev, dist)
+    sides = world == 1                              # side measurements only on the single-GPU line
+    side = other = lat = None
+    wl = {}
+    if sides and a.lmax != 4 and not a.no_lmax4 and a.workload == "rmd17_aspirin":
+        # the north-star's "L=4" target shape (lmax = 4): the gather/scatter target is quoted on it
+        side = measure(a, a.workload, a.batch, 4, max(20, a.steps), 3, rank, world, dev, dist)
+    if sides and not a.no_split:
+        # the other projection arithmetic (exact fp32 MFMA <-> 3 x bf16-split MFMA), reported alongside
+        default_mode = engine.GEMM_MODE
+        engine.GEMM_MODE = "split" if default_mode == "f32" else "f32"
         try:
-            split = measure(a, a.lmax, max(3, a.steps // 4), 2, rank, world, dev, dist)
+            other = measure(a, a.workload, a.batch, a.lmax, max(5, a.steps // 2), 2, rank, world, dev, dist)
         finally:
-            engine.GEMM_MODE = "f32"
-    lat = None
-    if not a.no_graph and world == 1:
+            engine.GEMM_MODE = default_mode
+    if sides and not a.no_workloads and a.workload == "rmd17_aspirin":
+        # BASELINE configs[2] and configs[4] on the same model family (single GPU)
+        wl["md22_ac_ala3_b64"] = measure(a, "md22_ac_ala3", 64, 2, 10, 2, rank, world, dev, dist)
+        wl["md22_nanotube_b8_lmax3"] = measure(a, "md22_nanotube", 8, 3, 10, 2, rank, world, dev, dist)
+    if sides and not a.no_graph:
         lat = graph_latency(a, res["rep"], res["head"], dev)
     if rank == 0:
         out = res["out"]
+        also = out.setdefault("also", {})
+        sub = lambda so: {**{k: so[k] for k in ("value", "unit", "ms_per_step", "steps", "roofline",
+                                                 "roofline_gather_scatter", "roofline_htr_edge")},
+                          "config": so["config"]["workload"]}
         if lat is not None:
-            out.setdefault("also", {})["single_molecule_latency"] = lat
-        if split is not None:
-            so = split["out"]
-            out.setdefault("also", {})["split_bf16x3_projections"] = {
-                "value": so["value"], "unit": so["unit"], "ms_per_step": so["ms_per_step"], "steps": so["steps"],
-                "note": "GN_GEMM_MODE=split: every fp32 operand as hi+mid+lo bf16 planes, 6 bf16 MFMAs per product, "
-                        "fp32 accumulate; same 1e-4 parity tests pass (error vs fp64 equals the exact-fp32 path)"}
+            also["single_molecule_latency"] = lat
+        if other is not None:
+            so = other["out"]
+            also["other_projection_mode"] = {
+                "dtype": so["dtype"], "value": so["value"], "unit": so["unit"], "ms_per_step": so["ms_per_step"],
+                "steps": so["steps"], "roofline": so["roofline"]}
         if side is not None:
-            so = side["out"]
-            out.setdefault("also", {})["lmax4"] = {k: so[k] for k in ("value", "unit", "ms_per_step", "steps",
-                                                                       "roofline", "roofline_gather_scatter")}
-            out["also"]["lmax4"]["config"] = so["config"]["workload"]
+            also["lmax4"] = sub(side["out"])
+        for k, v in wl.items():
+            also[k] = sub(v["out"])
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(res["rep"], res["head"], a.workload, a.lmax)
         os.write(JSON_FD, (json.dumps(out) + "\n").encode())
@@ -183,10 +258,16 @@ def graph_latency(a, rep, head, dev, n_mol=1, iters=200):
     return {"molecules": n_mol, "atoms": int(pos.shape[0]), "edges": int(ei.shape[1]),
             "eager_ms_per_step": round(eager, 3), "hipgraph_replay_ms_per_step": round(replay, 3),
             "steps_per_s_hipgraph": round(1e3 / replay, 1), "bit_identical_to_eager": same,
-            "note": "static topology (fixed edge list, new positions every step): ~190 launches replayed as one hipGraph"}
+            "note": "static topology (fixed edge list, new positions every step): the step's launches replayed as one hipGraph"}
 
 
-def measure(a, lmax, steps, warmup, rank, world, dev, dist):
+#: launches of the GATA message stage (gotennet.py:452-559, 613-640): scores + segment softmax + message + aggregate.
+#: B_msg is the stage's algorithmic traffic, so the stage's launches are timed TOGETHER.
+MSG_STAGE = ("gn_attn_softmax", "gn_message_aggregate", "gn_message_fused")
+HTR_TAG = "gn_htr_edge"
+
+
+def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
     import gotennet_amd
     from gotennet_amd import _lib, synthetic
     from gotennet_amd.graph import distance
@@ -198,10 +279,9 @@ def measure(a, lmax, steps, warmup, rank, world, dev, dist):
     rep = gotennet_amd.GotenNet(n_atom_basis=F, n_interactions=L, n_rbf=R, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
                                 num_heads=H, scale_edge=False, lmax=lmax, sep_dir=True, sep_tensor=True).to(dev).eval()
     head = Atomwise(n_in=F, n_hidden=256, derivative="forces").to(dev).eval()
-    step_fn = EnergyForces(rep, head)
+    step_fn = EnergyForces(rep, head, check_edges=False)   # radius-graph order is target-major by construction
 
-    B = a.batch
-    pos, batch, z = synthetic.make_batch(a.workload, B, seed=0, first_molecule=rank * B)
+    pos, batch, z = synthetic.make_batch(workload, B, seed=0, first_molecule=rank * B)
     pos, batch, z = pos.to(dev), batch.to(dev), z.to(dev)
     ei, ed, ev = distance(pos, batch, 5.0, 32)
     mol_ptr = molecule_ptr(batch, B)
@@ -236,25 +316,27 @@ def measure(a, lmax, steps, warmup, rank, world, dev, dist):
     for tag, t in tot.items():
         fam[family(tag)] = fam.get(family(tag), 0.0) + t
     dominant = max(fam, key=fam.get)               # kernel family with the largest share of the step
-    msg_tag = "gn_message_aggregate"
+    stage_tags = {t for t in tot if t in MSG_STAGE}
     if a.breakdown and rank == 0:
         ssum = sum(tot.values())
-        print(f"# lmax={lmax}: per-kernel HIP-event breakdown of one step ({ssum:.3f} ms of events)", file=sys.stderr)
+        print(f"# {workload} b={B} lmax={lmax} mode={_engine_mode()}: per-kernel HIP-event breakdown of one step "
+              f"({ssum:.3f} ms of events)", file=sys.stderr)
         for tag in sorted(tot, key=tot.get, reverse=True):
             print(f"  {tag:42s} {tot[tag]:8.3f} ms/step {cnt[tag]:3d} calls {1e3 * tot[tag] / cnt[tag]:8.1f} us/call "
                   f"{100 * tot[tag] / ssum:5.1f}%", file=sys.stderr)
 
-    # ---- timed region: exactly K steps, events only around the dominant + message kernels
-    # (the ~130 projection launches of a step are bracketed on the LAST timed step only, so that the
-    # event records do not perturb `value`; the 6 message launches are bracketed on every step)
+    # ---- timed region: exactly K steps, events only around the dominant + message-stage + HTR kernels
+    # (the projection launches of a step are bracketed on the LAST timed step only, so that the event records do not
+    # perturb `value`; the message-stage and HTR launches are bracketed on every step)
     dom_tags = {t for t in tot if family(t) == dominant}
-    kt = KernelTimer(wanted={msg_tag} if len(dom_tags) > 8 else dom_tags | {msg_tag})
+    always = stage_tags | {HTR_TAG}
+    kt = KernelTimer(wanted=set(always) if len(dom_tags) > 8 else dom_tags | always)
     _lib.TIMER = kt
     fence()
     t0 = time.perf_counter()
     for it in range(steps):
         if it == steps - 1:
-            kt.wanted = dom_tags | {msg_tag}
+            kt.wanted = dom_tags | always
         e, f = step()
     fence()
     dt = time.perf_counter() - t0
@@ -264,6 +346,12 @@ def measure(a, lmax, steps, warmup, rank, world, dev, dist):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     assert torch.isfinite(e).all() and torch.isfinite(f).all()
+    # what the collective produced: every rank's shard present exactly once in the all-reduced vector
+    n_ranks_seen = dist.get_world_size() if dist is not None else 1
+    e_vec = e_all if dist is not None else e[:, 0]
+    if dist is not None:
+        assert torch.equal(e_all[rank * B:(rank + 1) * B], e[:, 0]), "all-reduced energy vector lost this rank's shard"
+    energy_checksum = float(e_vec.double().sum())
 
     tot, cnt = kt.summary()
 
@@ -286,24 +374,45 @@ def measure(a, lmax, steps, warmup, rank, world, dev, dist):
             if big is None or tot[tag] > big[1]:
                 big = (tag, tot[tag], us, fl / (us * 1e-6) / 1e12)
         ach = flops / (t_ms * 1e-3) / 1e12
-        from gotennet_amd import engine as _eng
-        exact = _eng.GEMM_MODE == "f32"
+        exact = _engine_mode() == "f32"
         return dict(kernel="gn::gemm_f32_mfma (all projection launches, exact fp32 MFMA)" if exact else
-                    "gn::gemm_bf16x3_mfma (all projection launches, 3xbf16-split MFMA)",
+                    "gn::gemm_bf16x3_mfma (all projection launches, 3xbf16-split MFMA: 6 bf16 MFMAs per fp32 product)",
                     bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                    frac=round(ach / MFMA_F32_PEAK_TF, 4), traffic=_pmc_traffic("gn_gemm_family_avg", lmax),
+                    frac=round(ach / MFMA_F32_PEAK_TF, 4),
+                    peak_note="achieved = ALGORITHMIC fp32 flops / time; peak = the fp32 MFMA peak (157.3 TF)" +
+                    ("" if exact else "; the split kernel EXECUTES 6x these flops on the bf16 matrix cores "
+                     f"(dense bf16 peak {MFMA_BF16_PEAK_TF} TF): executed/bf16-peak = {round(6 * ach / MFMA_BF16_PEAK_TF, 4)}"),
+                    traffic=_pmc_traffic("gn_gemm_family_avg", lmax, workload),
                     us_per_launch=round(1e3 * t_ms / n, 2), launches_per_step=n // dom_steps,
                     algorithmic_flops_per_step=flops / dom_steps,
                     largest_launch=dict(shape_MxNxK=big[0][8:-1], us=round(big[2], 2), tflops=round(big[3], 2),
                                         frac=round(big[3] / MFMA_F32_PEAK_TF, 4)))
 
     def roof_message():
-        us = 1e3 * tot[msg_tag] / cnt[msg_tag]
+        """GATA message STAGE: SURVEY 8d B_msg over the summed duration of the stage's launches (one fused launch,
+        or scores/softmax + message/aggregate)."""
+        tags = sorted(t for t in tot if t in MSG_STAGE)
+        layers = cnt[tags[0]] // steps if tags else 0
+        us = sum(1e3 * tot[t] / cnt[t] for t in tags)              # per layer: one launch of each stage kernel
         nbytes = algorithmic_bytes_message(N, E, F, M, D)
         ach = nbytes / (us * 1e-6) / 1e9
-        return dict(kernel=msg_tag, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic(msg_tag, lmax), us_per_launch=round(us, 2),
-                    launches_per_step=cnt[msg_tag] // steps, algorithmic_bytes_per_launch=nbytes)
+        return dict(kernel="+".join(tags), bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic("message_stage", lmax, workload),
+                    us_per_launch=round(us, 2), us_by_kernel={t: round(1e3 * tot[t] / cnt[t], 2) for t in tags},
+                    launches_per_step=layers, algorithmic_bytes_per_launch=nbytes)
+
+    def roof_htr():
+        """K7 gn_htr_edge: the kernel's own compulsory bytes (EQ / EK tables, rl, index, w written) / its duration."""
+        if HTR_TAG not in tot:
+            return None
+        us = 1e3 * tot[HTR_TAG] / cnt[HTR_TAG]
+        nbytes = 4 * N * 2 * D * F + E * (4 * (F + D) + 16)
+        ach = nbytes / (us * 1e-6) / 1e9
+        return dict(kernel=HTR_TAG, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic(HTR_TAG, lmax, workload), us_per_launch=round(us, 2),
+                    launches_per_step=cnt[HTR_TAG] // steps, algorithmic_bytes_per_launch=nbytes,
+                    note="bytes = 4N*2DF (EQ, EK tables) + E(4(F + D) + 16) (w written, rl, 2 x int64 index): the kernel's "
+                         "own share of SURVEY 8d B_htr (the t read / t' write of the stage sit in the gated GEMM epilogue)")
 
     def roof_other(name):
         t_ms = sum(tot[t] for t in tot if family(t) == name)
@@ -317,20 +426,25 @@ def measure(a, lmax, steps, warmup, rank, world, dev, dist):
             "metric": "molecules/sec (energy+force forward), rMD17 aspirin batch=128, 1/2/4/8 MI355X",
             "value": round(B * world * steps / dt, 1), "unit": "molecules/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if _engine_mode() == "f32" else "f32 (3xbf16-split MFMA, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"{a.workload} batch={B}/GPU (N={N} atoms, E={E} edges incl. self-loops), "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if _engine_mode() == "f32" else "f32 (3xbf16-split MFMA, fp32 accumulate)", "data": "synthetic",
+            "config": {"workload": f"{workload} batch={B}/GPU (N={N} atoms, E={E} edges incl. self-loops), "
                                    f"n_atom_basis={F}, n_interactions={L}, lmax={lmax}, n_rbf={R}, heads={H}, "
                                    "sep_dir/sep_tensor, energy+forces",
                        "global_batch": B * world, "parallelism": f"dp{world} (molecule shards, 1 all-reduce)"},
+            "n_ranks_seen": n_ranks_seen, "energy_vector_len": int(e_vec.numel()), "energy_checksum": energy_checksum,
             "roofline": roof_gemm_family() if dominant == "gn_gemm" else
-            (roof_message() if dominant == msg_tag else roof_other(dominant)),
+            (roof_message() if dominant in MSG_STAGE else roof_other(dominant)),
             "roofline_gather_scatter": roof_message(),
+            "roofline_htr_edge": roof_htr(),
         }
     return {"out": out, "rep": rep, "head": head}
 
 
-def _pmc_traffic(tag, lmax):
+def _pmc_traffic(tag, lmax, workload="rmd17_aspirin"):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), if present."""
+    if workload != "rmd17_aspirin":
+        return None
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         return d.get(f"lmax{lmax}", {}).get(tag)
@@ -338,28 +452,51 @@ def _pmc_traffic(tag, lmax):
         return None
 
 
-def cpu_baseline(rep, head, workload, lmax, n_mol=8, reps=2):
-    """The CPU oracle (checker) timed on this box's host cores: energy+forces via autograd
-    on a bounded sample (n_mol molecules of the same workload, same hyper-parameters)."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(rep, head, workload, lmax, n_mol=8, runs=5):
+    """The CPU oracle (checker) timed on this box's host cores (BASELINE.md section 3 protocol): energy+forces via
+    autograd on a bounded sample of the same workload and model, 1 warm-up + median of ``runs`` runs with all host
+    cores (capped at 64 threads), plus a single-thread figure on a smaller sample."""
     from gotennet_amd import synthetic
     from oracle import gotennet_oracle as orc
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
-    torch.set_num_threads(threads)
     sd = {k: v.detach().cpu() for k, v in rep.state_dict().items()}
     hsd = {k: v.detach().cpu() for k, v in head.state_dict().items()}
     c = rep.config()
     cfg = orc.default_config(n_atom_basis=c.F, n_interactions=c.L, n_rbf=c.R, num_heads=c.H, scale_edge=c.scale_edge,
                              lmax=lmax, sep_dir=c.sep_dir, sep_tensor=c.sep_tensor, cutoff=c.cutoff)
-    pos, batch, z = synthetic.make_batch(workload, n_mol, seed=0)
-    orc.energy_and_forces(sd, cfg, hsd, z, pos, batch, n_mol)           # warm-up
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        orc.energy_and_forces(sd, cfg, hsd, z, pos, batch, n_mol)
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": round(n_mol / dt, 2), "unit": "molecules/s", "cores": threads, "kind": "port",
-            "sample": f"{n_mol} molecules of {workload} (same model), energy+forces by torch autograd on the CPU oracle, "
-                      f"{reps} runs after 1 warm-up, {threads} threads"}
+
+    def timed(nm, nthreads, nruns):
+        torch.set_num_threads(nthreads)
+        pos, batch, z = synthetic.make_batch(workload, nm, seed=0)
+        orc.energy_and_forces(sd, cfg, hsd, z, pos, batch, nm)           # warm-up
+        ts = []
+        for _ in range(nruns):
+            t0 = time.perf_counter()
+            orc.energy_and_forces(sd, cfg, hsd, z, pos.clone(), batch, nm)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    t_all = timed(n_mol, threads, runs)
+    t_one = timed(2, 1, 3)
+    return {"value": round(n_mol / t_all, 2), "unit": "molecules/s", "cores": threads, "kind": "port",
+            "cpu_model": _cpu_model(), "host_cores": cores, "torch": torch.__version__,
+            "single_thread": {"value": round(2 / t_one, 3), "unit": "molecules/s", "cores": 1,
+                              "sample": f"2 molecules of {workload}, median of 3 runs after 1 warm-up"},
+            "sample": f"{n_mol} molecules of {workload} (same model: F=256, L=6, lmax={lmax}), energy+forces by torch "
+                      f"autograd on the CPU oracle (oracle/gotennet_oracle.py), median of {runs} runs after 1 warm-up, "
+                      f"{threads} threads"}
 
 
 if __name__ == "__main__":

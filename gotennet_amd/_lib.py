@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libgotennet_hip.so")
 
 GN_ERR_BAD_ARG = 10001
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 
@@ -48,7 +48,9 @@ SIGNATURES = {
     "gn_gemm_group": [_P, _I, _P],
     "gn_edge_vectors": [_P, _P, _P, _I, _P, _P, _P],
     "gn_gemm_split": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],
-    "gn_split_bf16x3": [_P, C.c_long, _P, _P],
+    "gn_split_bf16x3": [_P, _I, _I, _P, _P],
+    "gn_split_bf16x3_size": [_I, _I],
+    "gn_gemm_group_split": [_P, _I, _P],
     "gn_htr_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "gn_message_backward": [_P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                             _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.c_long, _I, _I, _I, _I, _I, _I, _P],
@@ -91,7 +93,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_long if name == "gn_split_bf16x3_size" else C.c_int
     if lib.gn_abi_version(None) != ABI_VERSION:
         raise GotenNetHipError("libgotennet_hip.so ABI version mismatch; rebuild")
     _lib = lib

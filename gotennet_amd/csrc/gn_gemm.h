@@ -32,6 +32,34 @@ struct GroupArgs {
 
 constexpr int BK = 32, PITCH = 36;
 
+// ---- 3 x bf16 split (gn_gemm_split.hip) ----------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int SPLIT_PB = 40;    // bf16 per LDS row of an A plane (32 + 8 pad: 80-byte pitch, the 16-lane ds_read_b128
+                                // groups hit 16 distinct 4-bank slots)
+
+// x = hi + mid + lo EXACTLY, each a bf16 (8 significand bits): hi = x truncated to its top 16 bits, r1 = x - hi is
+// exact (<= 16 significant bits), mid = r1 truncated, lo = r1 - mid has <= 8 significant bits left, so its own
+// truncation is exact too.  (Truncation instead of round-to-nearest: two bit operations instead of a convert and a
+// shift per plane, and no rounding term.)  Results below the fp32 normal range flush like any fp32 subtraction.
+__device__ __forceinline__ unsigned pack_hi16(float a, float b) {      // (bf16(a), bf16(b)) by truncation
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+__device__ __forceinline__ void split4_trunc(float4 v, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
+    const float r0 = v.x - trunc_bf16(v.x), r1 = v.y - trunc_bf16(v.y);
+    const float r2 = v.z - trunc_bf16(v.z), r3 = v.w - trunc_bf16(v.w);
+    const float s0 = r0 - trunc_bf16(r0), s1 = r1 - trunc_bf16(r1);
+    const float s2 = r2 - trunc_bf16(r2), s3 = r3 - trunc_bf16(r3);
+    uint2 h, m, l;
+    h.x = pack_hi16(v.x, v.y); h.y = pack_hi16(v.z, v.w);
+    m.x = pack_hi16(r0, r1);   m.y = pack_hi16(r2, r3);
+    l.x = pack_hi16(s0, s1);   l.y = pack_hi16(s2, s3);
+    hi = __builtin_bit_cast(bf16x4, h);
+    mid = __builtin_bit_cast(bf16x4, m);
+    lo = __builtin_bit_cast(bf16x4, l);
+}
+
 __device__ __forceinline__ int phys_row(const GemmArgs& p, int r) {
     return (r / p.row_cnt) * p.row_gstride + p.row_goff + (r % p.row_cnt);
 }
@@ -42,8 +70,6 @@ __device__ __forceinline__ float4 dsilu4(float4 v) { return make_float4(dsilu(v.
 
 }  // namespace gn
 
-// exact-fp32 launcher for a group of n <= GN_MAX_GROUP problems (gn_gemm.hip)
-int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st);
-
-// split kernel launcher (gn_gemm_split.hip); W3 = [3][N][K] bf16 (hi, mid, lo planes)
-int gn_gemm_split_launch(gn::GemmArgs p, const unsigned short* W3, void* stream);
+// launcher for a group of n <= GN_MAX_GROUP problems (gn_gemm.hip).  split = 0: exact fp32 MFMA, W = fp32 [N][K];
+// split = 1: 3 x bf16-split MFMA, W = the fragment-major bf16 planes written by gn_split_bf16x3
+int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split);

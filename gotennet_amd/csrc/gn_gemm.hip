@@ -27,13 +27,23 @@
 
 namespace gn {
 
-template <int TM, int TN, bool PRO, int PF>
+// SPLIT = true: the 3 x bf16-split arithmetic (gn_gemm_split.hip has the numerics): A is split into hi/mid/lo bf16
+// planes while it is staged into LDS ([3][BM][40] bf16 per slab, double-buffered); the weight arrives pre-split in
+// FRAGMENT-MAJOR order (gn_split_bf16x3: [n-tile of 32][k-step of 16][plane][lane][8 bf16], so one wave-wide 16-byte
+// load is one contiguous KiB = exactly one MFMA B operand) and goes L2 -> registers, never through LDS: the weights
+// are a few MB, L2-resident, and every wave needs a different column block.  Six v_mfma_f32_32x32x16_bf16 per
+// 32x32x16 product block, fp32 accumulate; everything else (grouping, persistent tile walk, prologues, epilogue) is
+// shared with the exact-fp32 instantiation.
+template <int TM, int TN, bool PRO, int PF, bool SPLIT>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;       // staged float4 rows per thread
     constexpr int STAGE = (BM + BN) * PITCH;        // floats per K-slab buffer (A rows then W rows)
     constexpr int CP = BN + 4;                      // epilogue tile pitch
-    constexpr int LDS_FLOATS = (2 * STAGE > BM * CP) ? 2 * STAGE : BM * CP;
+    constexpr int APL = BM * SPLIT_PB;              // SPLIT: bf16 elements per A plane of a slab
+    constexpr int STAGE_S = 3 * APL;                // SPLIT: bf16 elements per slab buffer
+    constexpr int MAIN_FLOATS = SPLIT ? (2 * STAGE_S) / 2 : 2 * STAGE;
+    constexpr int LDS_FLOATS = (MAIN_FLOATS > BM * CP) ? MAIN_FLOATS : BM * CP;
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
 
     // One launch walks the tiles of up to GN_MAX_GROUP independent problems (a "group": the atom-sized products of
@@ -112,11 +122,13 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
             aok[i] = gm < p.M;
             prow[i] = phys_row(p, aok[i] ? gm : 0);
         }
+        if constexpr (!SPLIT) {
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int gn = n0f + sr + 32 * i;
-            bok[i] = gn < p.N;
-            brow[i] = p.W + (size_t)(bok[i] ? gn : 0) * p.K + 4 * c4;
+            for (int i = 0; i < RB; ++i) {
+                const int gn = n0f + sr + 32 * i;
+                bok[i] = gn < p.N;
+                brow[i] = p.W + (size_t)(bok[i] ? gn : 0) * p.K + 4 * c4;
+            }
         }
     };
 
@@ -148,14 +160,52 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
             }
             qa[i] = v;
         }
+        if constexpr (!SPLIT) {
 #pragma unroll
-        for (int i = 0; i < RB; ++i) qb[i] = (bok[i] && kok) ? ld4(brow[i] + k0) : zero4();
+            for (int i = 0; i < RB; ++i) qb[i] = (bok[i] && kok) ? ld4(brow[i] + k0) : zero4();
+        }
     };
-    auto stash = [&](float* buf, const float4 (&qa)[RA], const float4 (&qb)[RB]) {
+    // slab buffer `sb` (0 / 1) of the double buffer
+    auto stash = [&](int sb, const float4 (&qa)[RA], const float4 (&qb)[RB]) {
+        if constexpr (SPLIT) {
+            __bf16* d0 = reinterpret_cast<__bf16*>(smem) + sb * STAGE_S + sr * SPLIT_PB + 4 * c4;
 #pragma unroll
-        for (int i = 0; i < RA; ++i) st4(&buf[(sr + 32 * i) * PITCH + 4 * c4], qa[i]);
+            for (int i = 0; i < RA; ++i) {
+                bf16x4 h, m, l;
+                split4_trunc(qa[i], h, m, l);
+                __bf16* d = d0 + 32 * i * SPLIT_PB;
+                *reinterpret_cast<bf16x4*>(d) = h;
+                *reinterpret_cast<bf16x4*>(d + APL) = m;
+                *reinterpret_cast<bf16x4*>(d + 2 * APL) = l;
+            }
+        } else {
+            float* buf = smem + sb * STAGE;
 #pragma unroll
-        for (int i = 0; i < RB; ++i) st4(&buf[(BM + sr + 32 * i) * PITCH + 4 * c4], qb[i]);
+            for (int i = 0; i < RA; ++i) st4(&buf[(sr + 32 * i) * PITCH + 4 * c4], qa[i]);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) st4(&buf[(BM + sr + 32 * i) * PITCH + 4 * c4], qb[i]);
+        }
+    };
+    // SPLIT: B operands of k-step g (16 deep) for this wave's TN column blocks, three planes each, L2 -> registers
+    const uint4* wfrag = reinterpret_cast<const uint4*>(p.W);
+    int ks2 = 0;                                    // k-steps per column block in the fragment-major weight (even)
+    size_t nt_off[TN];
+    auto set_btile = [&](int n0b) {
+        wfrag = reinterpret_cast<const uint4*>(p.W);
+        ks2 = 2 * ((p.K + BK - 1) / BK);
+        const int nt_last = (p.N + 31) / 32 - 1;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int nt = n0b / 32 + wn * TN + j;
+            nt = nt < nt_last ? nt : nt_last;        // column blocks past N: any valid block (results are never stored)
+            nt_off[j] = (size_t)nt * ks2 * 192 + lane;
+        }
+    };
+    auto load_b = [&](int g, uint4 (&q)[TN][3]) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) q[j][s_] = wfrag[nt_off[j] + (size_t)(g * 3 + s_) * 64];
     };
 
     // double-buffered LDS K loop, one barrier per slab; register set s holds slab kt+1 when slab kt is
@@ -176,7 +226,12 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    stash(smem, pa[0], pb[0]);
+    stash(0, pa[0], pb[0]);
+    uint4 bq[2][TN][3];
+    if constexpr (SPLIT) {
+        set_btile(n0);
+        load_b(0, bq[0]);
+    }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < PF; ++s)
@@ -189,6 +244,33 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
       for (int s = 0; s < PF; ++s) {
         const int kt = kt0 + s;
         if (kt >= nk) break;
+        if constexpr (SPLIT) {
+            const __bf16* Ap = reinterpret_cast<const __bf16*>(smem) + (kt & 1) * STAGE_S +
+                               (wm * 32 * TM + frow) * SPLIT_PB + (lane >> 5) * 8;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {        // two 16-deep MFMA steps per slab
+                const int g = 2 * kt + ks;
+                if (g + 1 < ks2) load_b(g + 1, bq[(ks + 1) & 1]);   // next step's weights in flight under this step's MFMAs
+                bf16x8 a[TM][3];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int s_ = 0; s_ < 3; ++s_)
+                        a[i][s_] = *reinterpret_cast<const bf16x8*>(Ap + s_ * APL + i * 32 * SPLIT_PB + ks * 16);
+                // smallest terms first (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi); consecutive MFMAs rotate over the
+                // TM*TN accumulators so that none waits on the one before it
+                constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
+                constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                a[i][TA[t]], __builtin_bit_cast(bf16x8, bq[ks & 1][j][TB[t]]), acc[i][j], 0, 0, 0);
+            }
+        } else {
         const float* As = smem + (kt & 1) * STAGE;
         const float* Bs = As + BM * PITCH;
 #pragma unroll
@@ -216,7 +298,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) stash(smem + ((kt + 1) & 1) * STAGE, pa[s], pb[s]);   // other buffer: last read in iteration kt-1
+        }
+        if (kt + 1 < nk) stash((kt + 1) & 1, pa[s], pb[s]);   // other buffer: last read in iteration kt-1
         __syncthreads();
         if (kt + 1 + PF < nk) fetch((kt + 1 + PF) * BK, pa[s], pb[s]);
       }
@@ -324,7 +407,7 @@ extern "C" int gn_gemm_ex(const float* A, int lda, const float* W, const float* 
     gn::GemmArgs p{A, W, bias, C, res, gate, pre_out, a_pre, a_gate, lda, ldc, ldp, ldg, Mrows, Nout, K,
                    act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, gate_mode,
                    nullptr, nullptr, 0};
-    return gn_gemm_launch(&p, 1, (hipStream_t)stream);
+    return gn_gemm_launch(&p, 1, (hipStream_t)stream, 0);
 }
 
 static int gemm_args_ok(int Mrows, int Nout, int K, int lda, int ldc, int act_lo, int act_hi, int row_cnt,
@@ -340,7 +423,7 @@ static int gemm_args_ok(int Mrows, int Nout, int K, int lda, int ldc, int act_lo
     return 1;
 }
 
-extern "C" int gn_gemm_group(const gn_gemm_desc* d, int n, void* stream) {
+static int gemm_group_impl(const gn_gemm_desc* d, int n, void* stream, int split) {
     if (n < 0 || n > gn::GN_MAX_GROUP || (n > 0 && !d)) return GN_ERR_BAD_ARG;
     gn::GemmArgs g[gn::GN_MAX_GROUP];
     int m = 0;
@@ -358,11 +441,15 @@ extern "C" int gn_gemm_group(const gn_gemm_desc* d, int n, void* stream) {
                               q.row_gstride, q.row_goff, q.gate_mode, q.A2, q.A3, q.a_seg};
     }
     if (m == 0) return GN_OK;
-    return gn_gemm_launch(g, m, (hipStream_t)stream);
+    return gn_gemm_launch(g, m, (hipStream_t)stream, split);
 }
 
+extern "C" int gn_gemm_group(const gn_gemm_desc* d, int n, void* stream) { return gemm_group_impl(d, n, stream, 0); }
+// the same group on the 3 x bf16-split path: every desc.W points to the planes written by gn_split_bf16x3
+extern "C" int gn_gemm_group_split(const gn_gemm_desc* d, int n, void* stream) { return gemm_group_impl(d, n, stream, 1); }
+
 // one launch for n <= GN_MAX_GROUP problems (validated by the callers)
-int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st) {
+int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     gn::GroupArgs ga;
     long big = 0, small = 0;
     bool pro = false;
@@ -400,13 +487,16 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st) {
     long grid = 8L * ((end + 7) / 8);
     const long cap = use_big ? 512 : 1024;
     if (grid > cap) grid = cap;
-    if (use_big) {
-        if (pro) hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, true, 1>), dim3((unsigned)grid), dim3(256), 0, st, ga);
-        else hipLaunchKernelGGL((gn::gemm_f32_mfma<2, 2, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, ga);
+#define GN_GEMM_GO(TM_, TN_, PRO_, SPLIT_) \
+    hipLaunchKernelGGL((gn::gemm_f32_mfma<TM_, TN_, PRO_, 1, SPLIT_>), dim3((unsigned)grid), dim3(256), 0, st, ga)
+    if (split) {
+        if (use_big) { if (pro) GN_GEMM_GO(2, 2, true, true); else GN_GEMM_GO(2, 2, false, true); }
+        else { if (pro) GN_GEMM_GO(1, 1, true, true); else GN_GEMM_GO(1, 1, false, true); }
     } else {
-        if (pro) hipLaunchKernelGGL((gn::gemm_f32_mfma<1, 1, true, 1>), dim3((unsigned)grid), dim3(256), 0, st, ga);
-        else hipLaunchKernelGGL((gn::gemm_f32_mfma<1, 1, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, ga);
+        if (use_big) { if (pro) GN_GEMM_GO(2, 2, true, false); else GN_GEMM_GO(2, 2, false, false); }
+        else { if (pro) GN_GEMM_GO(1, 1, true, false); else GN_GEMM_GO(1, 1, false, false); }
     }
+#undef GN_GEMM_GO
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
@@ -417,17 +507,14 @@ extern "C" int gn_gemm_split(const float* A, int lda, const unsigned short* W3, 
                              const float* res, const float* gate, int gate_mode, float* pre_out,
                              int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
                              const float* a_gate, int ldg, void* stream) {
-    if (Mrows < 0 || Nout <= 0 || K <= 0 || (K & 7) || (lda & 3) || (Nout & 3) || (ldc & 3) || (act_lo & 3) ||
-        (act_hi & 3) || row_cnt <= 0)
-        return GN_ERR_BAD_ARG;
-    if (gate != nullptr && res == nullptr && gate_mode == 0) return GN_ERR_BAD_ARG;
-    if (pro_mode < 0 || pro_mode > 2 || (pro_mode == 2 && (!a_pre || (ldp & 3))) || (a_gate && (ldg & 3)) ||
-        (pro_mode && ((pro_lo & 3) || (pro_hi & 3))))
+    if (!gemm_args_ok(Mrows, Nout, K, lda, ldc, act_lo, act_hi, row_cnt, res, gate, gate_mode, pro_mode, pro_lo, pro_hi,
+                      a_pre, ldp, a_gate, ldg) || !W3)
         return GN_ERR_BAD_ARG;
     if (Mrows == 0) return GN_OK;
-    gn::GemmArgs p{A, nullptr, bias, C, res, gate, pre_out, a_pre, a_gate, lda, ldc, ldp, ldg, Mrows, Nout, K,
-                   act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, gate_mode};
-    return gn_gemm_split_launch(p, W3, stream);
+    gn::GemmArgs p{A, reinterpret_cast<const float*>(W3), bias, C, res, gate, pre_out, a_pre, a_gate, lda, ldc, ldp, ldg,
+                   Mrows, Nout, K, act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, gate_mode,
+                   nullptr, nullptr, 0};
+    return gn_gemm_launch(&p, 1, (hipStream_t)stream, 1);
 }
 
 extern "C" int gn_gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc,

@@ -107,13 +107,14 @@ GEMM_MODE = os.environ.get("GN_GEMM_MODE", "f32")
 
 
 def split_weight(W: torch.Tensor) -> torch.Tensor:
-    """[3, N, K] bf16 planes of a weight, cached ON the tensor object (the packed weights are
-    long-lived objects; an in-place update bumps ``_version`` and invalidates the planes)."""
+    """bf16 hi/mid/lo planes of a weight [N, K] in the MFMA-fragment-major order of gn_split_bf16x3, cached ON the
+    tensor object (the packed weights are long-lived; GotenNet.invalidate_packed() drops them with the pack)."""
     cached = getattr(W, "_gn_split", None)
     if cached is not None and cached[0] == W._version and cached[1] == W.data_ptr():
         return cached[2]
-    w3 = torch.empty((3,) + tuple(W.shape), dtype=torch.bfloat16, device=W.device)
-    call("gn_split_bf16x3", ptr(W), W.numel(), ptr(w3), _stream())
+    N, K = W.shape
+    w3 = torch.empty(_lib.load().gn_split_bf16x3_size(N, K), dtype=torch.bfloat16, device=W.device)
+    call("gn_split_bf16x3", ptr(W.contiguous()), N, K, ptr(w3), _stream())
     W._gn_split = (W._version, W.data_ptr(), w3)
     return w3
 
@@ -124,7 +125,7 @@ def gemm(A, lda, W, bias, C, ldc, rows, nout, K, act=(0, 0), rowmap=(1, 1, 0), r
     """C = epi(pro(A) W^T + bias).  ``a_off`` / ``c_off`` / ``p_off`` / ``g_off``: float offsets of the first
     column.  ``dgate``: multiply the output by SiLU'(dgate) (same addressing as C)."""
     name = "gn_gemm_ex"
-    if GEMM_MODE == "split" and K % 8 == 0:
+    if GEMM_MODE == "split":
         name, W = "gn_gemm_split", split_weight(W)
     call(name, A.data_ptr() + 4 * a_off, lda, ptr(W), ptr(bias), C.data_ptr() + 4 * c_off, ldc,
          rows, nout, K, act[0], act[1], rowmap[0], rowmap[1], rowmap[2], ptr(res),
@@ -134,22 +135,10 @@ def gemm(A, lda, W, bias, C, ldc, rows, nout, K, act=(0, 0), rowmap=(1, 1, 0), r
 
 
 def gemm_group(problems):
-    """Several INDEPENDENT ``gemm(...)`` calls (a list of argument dicts) as ONE launch (gn_gemm_group); the
-    3xbf16-split mode has no grouped kernel and issues them one by one."""
+    """Several INDEPENDENT ``gemm(...)`` calls (a list of argument dicts) as ONE launch (gn_gemm_group, or
+    gn_gemm_group_split with the weights replaced by their cached bf16 planes)."""
     problems = [q for q in problems if q is not None]
-    if GEMM_MODE == "split" or (len(problems) == 1 and not problems[0].get("a_seg")):
-        for q in problems:
-            if q.get("a_seg"):                       # K-segmented A: chained products through `res`
-                segs = [q["A"], q["A2"]] + ([q["A3"]] if q.get("A3") is not None else [])
-                res = q.get("res")
-                for si, a in enumerate(segs):
-                    Wseg = q["W"][:, si * q["a_seg"]:(si + 1) * q["a_seg"]].contiguous()
-                    gemm(a, q["lda"], Wseg, q.get("bias") if si == 0 else None, q["C"], q["ldc"], q["rows"], q["nout"],
-                         q["a_seg"], rowmap=q.get("rowmap", (1, 1, 0)), res=res)
-                    res = q["C"]
-            else:
-                gemm(**{"bias": None, **q})
-        return
+    split = GEMM_MODE == "split"
     for i0 in range(0, len(problems), 4):
         chunk = problems[i0:i0 + 4]
         arr = (_lib.GemmDesc * len(chunk))()
@@ -158,7 +147,7 @@ def gemm_group(problems):
             act, rowmap, pro = g("act", (0, 0)), g("rowmap", (1, 1, 0)), g("pro", (0, 0, 0))
             dgate = g("dgate")
             d.A = q["A"].data_ptr() + 4 * g("a_off", 0); d.lda = q["lda"]
-            d.W = ptr(q["W"]); d.bias = ptr(g("bias"))
+            d.W = ptr(split_weight(q["W"]) if split else q["W"]); d.bias = ptr(g("bias"))
             d.C = q["C"].data_ptr() + 4 * g("c_off", 0); d.ldc = q["ldc"]
             d.M, d.N, d.K = q["rows"], q["nout"], q["K"]
             d.act_lo, d.act_hi = act
@@ -173,7 +162,7 @@ def gemm_group(problems):
             d.ldp = g("ldp", 0)
             d.a_gate = ptr(g("a_gate")); d.ldg = g("ldg", 0)
             d.A2, d.A3, d.a_seg = ptr(g("A2")), ptr(g("A3")), g("a_seg", 0)
-        call("gn_gemm_group", arr, len(chunk), _stream())
+        call("gn_gemm_group_split" if split else "gn_gemm_group", arr, len(chunk), _stream())
 
 
 class Graph:

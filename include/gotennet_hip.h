@@ -34,7 +34,7 @@ extern "C" {
 
 #define GN_OK 0
 #define GN_ERR_BAD_ARG 10001     /* shape/flag combination the kernels do not implement */
-#define GN_ABI_VERSION 1
+#define GN_ABI_VERSION 2
 
 /* Library identity: returns GN_ABI_VERSION; *arch_out (if non-NULL) receives "gfx950". */
 int gn_abi_version(const char** arch_out);
@@ -139,17 +139,23 @@ typedef struct gn_gemm_desc {
 } gn_gemm_desc;
 int gn_gemm_group(const gn_gemm_desc* problems, int n, void* stream);
 
-/* 3 x bf16 split variant of the same Dense products (layers.py:457-529): same contract as gn_gemm_ex, but the weight is passed as three
- * bf16 planes W3[3][Nout][K] (hi, mid, lo with W = hi + mid + lo to 2^-25; made once by gn_split_bf16x3) and the
- * product is accumulated in fp32 from the six plane pairs of order <= 2 on the bf16 matrix cores: fp32-class
- * error (<= 1e-6 relative) at 16/6 of the exact-fp32 MFMA rate.  K must be a multiple of 8. */
-int gn_split_bf16x3(const float* w, long n, unsigned short* out /* [3][n] */, void* stream);
+/* 3 x bf16 split variant of the same Dense products (layers.py:457-529): same contract as
+ * gn_gemm_ex / gn_gemm_group, but every weight is passed as the bf16 planes written ONCE per weight by
+ * gn_split_bf16x3 (W = hi + mid + lo exactly, each plane bf16; stored in the order the matrix cores consume them:
+ * [column block of 32][k-step of 16, padded to an even count][plane][lane][8], gn_split_bf16x3_size(N, K) bf16
+ * elements).  The product is accumulated in fp32 from the six plane pairs of order <= 2 on the bf16 matrix cores
+ * (v_mfma_f32_32x32x16_bf16): fp32-class error (<= 1e-6 relative to an fp64 product) at 16/6 of the exact-fp32
+ * MFMA rate.  A is split on the fly; K must be a multiple of 4 as for gn_gemm_ex. */
+long gn_split_bf16x3_size(int N, int K);
+int gn_split_bf16x3(const float* w /* [N][K] fp32 */, int N, int K, unsigned short* out, void* stream);
 int gn_gemm_split(const float* A, int lda, const unsigned short* W3, const float* bias, float* C, int ldc,
                   int Mrows, int Nout, int K, int act_lo, int act_hi,
                   int row_cnt, int row_gstride, int row_goff,
                   const float* res, const float* gate, int gate_mode, float* pre_out,
                   int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
                   const float* a_gate, int ldg, void* stream);
+/* gn_gemm_group on the split path: every problems[i].W points to gn_split_bf16x3 planes (cast to const float*). */
+int gn_gemm_group_split(const gn_gemm_desc* problems, int n, void* stream);
 
 /* ---- K6 GATA message / softmax / aggregate -------------------------------------------- */
 /* Attention weights (gotennet.py:497-511): s[e,h] = sum_{c in head h} q[i,c] k[j,c] t_attn[e,c];

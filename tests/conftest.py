@@ -15,3 +15,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT
+
+
+@pytest.fixture(params=["f32", "split"])
+def gemm_mode(request):
+    """Run a GPU parity test in both projection arithmetics: exact fp32 MFMA and the 3 x bf16-split MFMA."""
+    from gotennet_amd import engine
+    old = engine.GEMM_MODE
+    engine.GEMM_MODE = request.param
+    yield request.param
+    engine.GEMM_MODE = old

@@ -7,7 +7,7 @@ import torch
 from tests.golden_util import case_names, load_case, rel_err
 from tests.test_hip_parity import _net_from_case, _synthetic
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gemm_mode")]
 
 TOL = 1e-4          # north_star: forces within 1e-4 relative (max-norm)
 FORCE_CASES = [n for n in case_names() if "shuffled" not in n]

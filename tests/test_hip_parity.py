@@ -4,7 +4,7 @@ import torch
 
 from tests.golden_util import case_names, load_case, rel_err
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gemm_mode")]
 
 # north_star tolerance: (h, X) within 1e-4 relative (max-norm per tensor, fp32)
 TOL = 1e-4
@@ -195,8 +195,6 @@ def test_gemm_group_and_segmented_k():
     """gn_gemm_group: unlike problems in one launch (different M/N/K, epilogues, row maps), equal problems (one XCD
     cut), more than four problems (chunked), and the K-segmented A operand -- against fp64 matmuls."""
     from gotennet_amd import engine
-    if engine.GEMM_MODE != "f32":
-        pytest.skip("the 3xbf16-split mode issues grouped problems one by one")
     torch.manual_seed(1)
     dev = "cuda"
     r = lambda *s: torch.randn(*s, device=dev)

@@ -14,7 +14,7 @@ def test_library_exports_every_declared_symbol():
     from gotennet_amd.build import build_library
     build_library()
     hdr = open(os.path.join(ROOT, "include", "gotennet_hip.h")).read()
-    declared = set(re.findall(r"^int (gn_\w+)\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|long) (gn_\w+)\(", hdr, flags=re.M))
     assert declared, "header parse failed"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = ctypes.CDLL(_lib.LIB_PATH)
