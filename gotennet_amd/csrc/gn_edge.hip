@@ -26,10 +26,33 @@ __global__ void build_csr_kernel(const int64_t* __restrict__ ei, int E, int N,
     const int d = (int)ei[(size_t)E + e];
     src[e] = s;
     dst[e] = d;
-    const int prev = e > 0 ? (int)ei[(size_t)E + e - 1] : -1;
-    for (int n = prev + 1; n <= d; ++n) rowptr[n] = e;
+    // (targets outside [0, N) -- a caller error gn_check_edges reports -- must not make this kernel write out of bounds)
+    const int dc = d < 0 ? -1 : (d >= N ? N - 1 : d);
+    int prev = e > 0 ? (int)ei[(size_t)E + e - 1] : -1;
+    prev = prev < -1 ? -1 : (prev >= N ? N - 1 : prev);
+    for (int n = prev + 1; n <= dc; ++n) rowptr[n] = e;
     if (e == E - 1)
-        for (int n = d + 1; n <= N; ++n) rowptr[n] = E;
+        for (int n = dc + 1; n <= N; ++n) rowptr[n] = E;
+}
+
+// CosineCutoff (layers.py:149-152) of a distance vector -- for callers that drive one GATA layer directly
+__global__ void cosine_cutoff_kernel(const float* __restrict__ dist, int E, float cutoff, float* __restrict__ cut) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const float d = dist[e];
+    const float c = 0.5f * (cosf(d * 3.14159265358979323846f / cutoff) + 1.0f);
+    cut[e] = d < cutoff ? c : 0.0f;
+}
+
+// flag |= 1: edge_index[1] decreases somewhere (not target-major); |= 2: an index outside [0, N)
+__global__ void check_edges_kernel(const int64_t* __restrict__ ei, int E, int N, int* __restrict__ flag) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int64_t s = ei[e], d = ei[(size_t)E + e];
+    int bits = 0;
+    if (s < 0 || s >= N || d < 0 || d >= N) bits |= 2;
+    if (e > 0 && ei[(size_t)E + e - 1] > d) bits |= 1;
+    if (bits) atomicOr(flag, bits);              // integer flag: order-independent
 }
 
 __global__ void out_degree_kernel(const int* __restrict__ src, int E, int* __restrict__ outdeg) {
@@ -141,6 +164,24 @@ extern "C" int gn_build_csr(const int64_t* edge_index, int E, int N, int* src, i
     const int work = E > 0 ? E : N + 1;
     hipLaunchKernelGGL(gn::build_csr_kernel, dim3((work + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        edge_index, E, N, src, dst, rowptr);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+extern "C" int gn_cosine_cutoff(const float* dist, int E, float cutoff, float* cut, void* stream) {
+    if (E < 0) return GN_ERR_BAD_ARG;
+    if (E == 0) return GN_OK;
+    hipLaunchKernelGGL(gn::cosine_cutoff_kernel, dim3((E + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       dist, E, cutoff, cut);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+extern "C" int gn_check_edges(const int64_t* edge_index, int E, int N, int* flag, void* stream) {
+    if (E < 0 || N < 0 || !flag) return GN_ERR_BAD_ARG;
+    if (E == 0) return GN_OK;
+    hipLaunchKernelGGL(gn::check_edges_kernel, dim3((E + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       edge_index, E, N, flag);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }

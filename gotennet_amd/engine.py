@@ -31,9 +31,9 @@ class LayerWeights:
     Ws2: torch.Tensor; bs2: torch.Tensor          # gamma_s.1 [MF, F]
     Wv2: torch.Tensor; bv2: torch.Tensor          # gamma_v.1 [MF, F]
     We: torch.Tensor; be: torch.Tensor            # [W_re; W_rs] [(1+M)F, F]
-    Wvu: torch.Tensor
-    Wm0: torch.Tensor; bm0: torch.Tensor
-    Wm1: torch.Tensor; bm1: torch.Tensor
+    Wvu: Optional[torch.Tensor] = None                                         # EQFF (None in a stand-alone GATA pack)
+    Wm0: Optional[torch.Tensor] = None; bm0: Optional[torch.Tensor] = None
+    Wm1: Optional[torch.Tensor] = None; bm1: Optional[torch.Tensor] = None
     Wt: Optional[torch.Tensor] = None; bt: Optional[torch.Tensor] = None   # gamma_t
     Wvq: Optional[torch.Tensor] = None
     Wvk: List[torch.Tensor] = field(default_factory=list)   # one per degree, or ONE shared weight (sep_htr=False)
@@ -165,6 +165,28 @@ def gemm_group(problems):
         call("gn_gemm_group_split" if split else "gn_gemm_group", arr, len(chunk), _stream())
 
 
+def validate_edges(edge_index: torch.Tensor, n_atoms: int) -> int:
+    """Bit 0: ``edge_index[1]`` is not non-decreasing (needs a stable sort by target); bit 1: an index is outside
+    [0, n_atoms).  One tiny kernel + ONE host read of its flag (a stream synchronisation)."""
+    flag = torch.zeros(1, dtype=torch.int32, device=edge_index.device)
+    call("gn_check_edges", ptr(edge_index), edge_index.shape[1], n_atoms, ptr(flag), _stream())
+    return int(flag.item())
+
+
+def sorted_edges(edge_index, edge_diff, edge_vec, n_atoms: int):
+    """Validate a caller-supplied edge list; returns it target-major (stable: the order inside a target row is kept)
+    plus the permutation applied (None when it already was).  Raises on out-of-range indices."""
+    if edge_index.shape[1] == 0:
+        return edge_index, edge_diff, edge_vec, None
+    bits = validate_edges(edge_index, n_atoms)
+    if bits & 2:
+        raise ValueError(f"edge_index holds indices outside [0, {n_atoms})")
+    if not bits & 1:
+        return edge_index, edge_diff, edge_vec, None
+    order = torch.sort(edge_index[1], stable=True).indices
+    return edge_index[:, order].contiguous(), edge_diff[order], edge_vec[order], order
+
+
 class Graph:
     """CSR-by-target view of a target-sorted edge list + per-edge geometry (K1);
     ``csc()`` adds the by-source view the backward needs.  Topology (index arrays) and geometry (rl, phi, cut)
@@ -188,7 +210,7 @@ class Graph:
             self.outdeg = torch.zeros(n_atoms, **i32)
             call("gn_out_degree", ptr(self.src), E, ptr(self.outdeg), _stream())
         self.rl = torch.empty((E, cfg.D), **f32)
-        self.phi = torch.empty((E, cfg.R), **f32)
+        self.phi = torch.empty((E, max(cfg.R, 0)), **f32)
         self.cut = torch.empty(E, **f32)
         self.perm = self.colptr = self.tgt_by_src = None
         self.edge_diff = self.edge_vec = None
@@ -316,11 +338,7 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
         gemm_group([dict(A=nact, lda=4 * F_, W=lw.Ws2, bias=lw.bs2, C=xs, ldc=M * F_, rows=N, nout=M * F_, K=F_, a_off=2 * F_),
                     dict(A=nact, lda=4 * F_, W=lw.Wv2, bias=lw.bv2, C=vs, ldc=M * F_, rows=N, nout=M * F_, K=F_, a_off=3 * F_)])
         # ---- message / softmax / aggregate / residual (452-559, 613-640, 426-427)
-        call("gn_attn_softmax", ptr(nact), nact.data_ptr() + 4 * F_, 4 * F_, ptr(eproj), lde,
-             ptr(g.rowptr), ptr(g.src), ptr(g.outdeg), N, F_, H, ptr(attn), _stream())
-        call("gn_message_aggregate", ptr(xs), ptr(vs), M * F_, eproj.data_ptr() + 4 * F_, lde,
-             ptr(attn), ptr(g.rl), ptr(g.cut), ptr(g.rowptr), ptr(g.src),
-             ptr(h), ptr(X), ptr(h2), ptr(X2), N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
+        message_stage(cfg, g, nact, xs, vs, eproj, attn, h, X, h2, X2)
         h, h2 = h2, h
         X, X2 = X2, X
         # every product of the updated X (X W_vu^T for EQFF; EQ and the per-degree EK_l for HTR) in one launch
@@ -361,6 +379,85 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
         if trace is not None:
             trace.append((h.clone(), X.clone(), t.clone()))
     return h, X, tape
+
+
+def gata_layer(cfg: Config, lw: LayerWeights, g: "Graph", h: torch.Tensor, X: torch.Tensor, t: torch.Tensor):
+    """ONE GATA layer (gotennet.py:366-450) on its own, inference only: what ``GATA.forward`` of the mirror module runs
+    when a caller composes layers directly.  Same kernels as ``forward`` (which additionally fuses the neighbouring EQFF
+    launches into the grouped GEMMs).  ``g`` carries the CSR view, rl and the cosine cutoff.  -> (h', X', t')."""
+    F_, H, D, M, lmax, Fe = cfg.F, cfg.H, cfg.D, cfg.M, cfg.lmax, cfg.Fe
+    N, E = g.N, g.E
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=h.device)
+    last = lw.Wt is None
+    if cfg.layernorm:
+        hn = new(N, F_)
+        call("gn_layernorm", ptr(h), ptr(lw.ln_w), ptr(lw.ln_b), 1e-5, N, F_, ptr(hn), _stream())
+        h = hn
+    if cfg.steerable_norm:
+        Xn = new(N, D, F_)
+        call("gn_tensor_norm", ptr(X), ptr(lw.tln_w), 1e-12, N, F_, lmax, ptr(Xn), _stream())
+        X = Xn
+    lde = (1 + M) * F_
+    nact, xs, vs = new(N, 4 * F_), new(N, M * F_), new(N, M * F_)
+    eproj, attn = new(E, lde), new(E, H)
+    h2, X2 = new(N, F_), new(N, D, F_)
+    gemm_group([dict(A=t, lda=F_, W=lw.We, bias=lw.be, C=eproj, ldc=lde, rows=E, nout=lde, K=F_),
+                dict(A=h, lda=F_, W=lw.Wn1, bias=lw.bn1, C=nact, ldc=4 * F_, rows=N, nout=4 * F_, K=F_,
+                     act=(2 * F_, 4 * F_))])
+    gemm_group([dict(A=nact, lda=4 * F_, W=lw.Ws2, bias=lw.bs2, C=xs, ldc=M * F_, rows=N, nout=M * F_, K=F_, a_off=2 * F_),
+                dict(A=nact, lda=4 * F_, W=lw.Wv2, bias=lw.bv2, C=vs, ldc=M * F_, rows=N, nout=M * F_, K=F_, a_off=3 * F_)])
+    message_stage(cfg, g, nact, xs, vs, eproj, attn, h, X, h2, X2)
+    h, X = h2, X2
+    if last:
+        return h, X, t
+    EQ, EK, w, t2 = new(N, D, Fe), new(N, D, Fe), new(E, Fe), new(E, F_)
+    xprods = [dict(A=X, lda=F_, W=lw.Wvq, C=EQ, ldc=Fe, rows=N * D, nout=Fe, K=F_)]
+    if cfg.htr_mode & 1:
+        xprods.append(dict(A=X, lda=F_, W=lw.Wvk[0], C=EK, ldc=Fe, rows=N * D, nout=Fe, K=F_))
+    else:
+        off = 0
+        for l in range(1, lmax + 1):
+            cnt = 2 * l + 1
+            xprods.append(dict(A=X, lda=F_, W=lw.Wvk[l - 1], C=EK, ldc=Fe, rows=N * cnt, nout=Fe, K=F_,
+                               rowmap=(cnt, D, off)))
+            off += cnt
+    gemm_group(xprods)
+    call("gn_htr_edge", ptr(EQ), ptr(EK), ptr(g.rl), ptr(g.rowptr), ptr(g.src), N, Fe, lmax, cfg.htr_mode, None, ptr(w),
+         _stream())
+    if cfg.composed_update:
+        _edge_update_composed(cfg, lw, t, w, t2, E, None)
+    else:
+        gemm(t, F_, lw.Wt, lw.bt, t2, F_, E, F_, F_, act=(0, F_), res=t, gate=w)
+    return h, X, t2
+
+
+def eqff_layer(cfg: Config, lw: LayerWeights, h: torch.Tensor, X: torch.Tensor):
+    """ONE EQFF block (gotennet.py:716-748) on its own, inference only (``EQFF.forward`` of the mirror module).
+    Returns NEW tensors (h', X')."""
+    F_, D = cfg.F, cfg.D
+    N = h.shape[0]
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=h.device)
+    Xp, ctx, g1, mm = new(N, D, F_), new(N, 2 * F_), new(N, F_), new(N, 2 * F_)
+    gemm(X, F_, lw.Wvu, None, Xp, F_, N * D, F_, F_)
+    call("gn_eqff_context", ptr(h), ptr(Xp), float(cfg.eps), N, F_, D, ptr(ctx), _stream())
+    gemm(ctx, 2 * F_, lw.Wm0, lw.bm0, g1, F_, N, F_, 2 * F_, act=(0, F_))
+    gemm(g1, F_, lw.Wm1, lw.bm1, mm, 2 * F_, N, 2 * F_, F_)
+    h, X = h.clone(), X.clone()
+    call("gn_eqff_update", ptr(mm), ptr(Xp), N, F_, D, ptr(h), ptr(X), _stream())
+    return h, X
+
+
+def message_stage(cfg: Config, g: "Graph", nact, xs, vs, eproj, attn, h, X, h2, X2):
+    """GATA message stage (gotennet.py:452-559, 613-640, 426-427): scores + segment softmax, message, aggregate,
+    residual.  q | k are columns [0, 2F) of ``nact``; t_attn (pre-activation) columns [0, F) of ``eproj``, t_filter the
+    rest."""
+    F_, H, M = cfg.F, cfg.H, cfg.M
+    lde = (1 + M) * F_
+    call("gn_attn_softmax", ptr(nact), nact.data_ptr() + 4 * F_, 4 * F_, ptr(eproj), lde,
+         ptr(g.rowptr), ptr(g.src), ptr(g.outdeg), g.N, F_, H, ptr(attn), _stream())
+    call("gn_message_aggregate", ptr(xs), ptr(vs), M * F_, eproj.data_ptr() + 4 * F_, lde,
+         ptr(attn), ptr(g.rl), ptr(g.cut), ptr(g.rowptr), ptr(g.src),
+         ptr(h), ptr(X), ptr(h2), ptr(X2), g.N, F_, H, cfg.lmax, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
 
 
 def _edge_update_composed(cfg: Config, lw: LayerWeights, t, w_raw, t2, E: int, pre_t):

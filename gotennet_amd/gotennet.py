@@ -65,8 +65,72 @@ class _RepresentationPosFn(torch.autograd.Function):
         return engine.pos_gradient(g, g_vec, g_diff, sign=1.0), None, None, None
 
 
-class GATA(nn.Module):
-    """Parameter container for one GATA layer (reference gotennet.py:78-317)."""
+def _pack_gata(gata) -> engine.LayerWeights:
+    """GEMM operands of one GATA layer: projections that share an input are concatenated into one weight."""
+    c = lambda *ts: torch.cat([t.detach() for t in ts], dim=0).contiguous()
+    d = lambda t: t.detach().contiguous()
+    lw = engine.LayerWeights(
+        Wn1=c(gata.W_q.weight, gata.W_k.weight, gata.gamma_s[0].weight, gata.gamma_v[0].weight),
+        bn1=c(gata.W_q.bias, gata.W_k.bias, gata.gamma_s[0].bias, gata.gamma_v[0].bias),
+        Ws2=d(gata.gamma_s[1].weight), bs2=d(gata.gamma_s[1].bias),
+        Wv2=d(gata.gamma_v[1].weight), bv2=d(gata.gamma_v[1].bias),
+        We=c(gata.W_re.weight, gata.W_rs.weight), be=c(gata.W_re.bias, gata.W_rs.bias))
+    if not gata.last_layer and gata.edge_updates:
+        dl = gata.gamma_t.dense_layers
+        lw.Wt, lw.bt = d(dl[-1].weight), d(dl[-1].bias)
+        if len(dl) == 2:                   # "mlp"/"mlpa": hidden layer (+ optional LayerNorm "edge_ln")
+            lw.Wt0, lw.bt0 = d(dl[0].weight), d(dl[0].bias)
+            if dl[0].norm is not None:
+                lw.t_ln_w, lw.t_ln_b = d(dl[0].norm.weight), d(dl[0].norm.bias)
+        if gata.update_info["lin_w"]:
+            lw.Wedp, lw.bedp = d(gata.W_edp.weight), d(gata.W_edp.bias)
+            if gata.update_info["lin_ln"] == 1:
+                lw.w_ln_w, lw.w_ln_b = d(gata.gamma_w[0].weight), d(gata.gamma_w[0].bias)
+            elif gata.update_info["lin_ln"] == 2:
+                lw.w_ln_w, lw.w_ln_b = d(gata.W_edp.norm.weight), d(gata.W_edp.norm.bias)
+        lw.Wvq = d(gata.W_vq.weight)
+        lw.Wvk = [d(wk.weight) for wk in gata.W_vk] if gata.sep_htr else [d(gata.W_vk.weight)]
+    if gata.layernorm_:
+        lw.ln_w, lw.ln_b = d(gata.layernorm.weight), d(gata.layernorm.bias)
+    if gata.steerable_norm_:
+        lw.tln_w = d(gata.tensor_layernorm.weight)
+    return lw
+
+
+def _pack_eqff(eq, lw: Optional[engine.LayerWeights] = None) -> engine.LayerWeights:
+    d = lambda t: t.detach().contiguous()
+    if lw is None:
+        lw = engine.LayerWeights(*([None] * 8))
+    lw.Wvu = d(eq.W_vu.weight)
+    lw.Wm0, lw.bm0 = d(eq.gamma_m[0].weight), d(eq.gamma_m[0].bias)
+    lw.Wm1, lw.bm1 = d(eq.gamma_m[1].weight), d(eq.gamma_m[1].bias)
+    return lw
+
+
+class _LayerPackCache:
+    """Packed weights of a stand-alone layer module, rebuilt when a parameter changes (version counter / data_ptr;
+    ``invalidate_packed()`` after writes through ``.data``)."""
+
+    def _layer_pack(self, build):
+        key = tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        if getattr(self, "_lp", None) is None or self._lp[0] != key:
+            self._lp = (key, build(self))
+        return self._lp[1]
+
+    def invalidate_packed(self):
+        self._lp = None
+
+
+def _require_cuda(t: Tensor, what: str):
+    if not t.is_cuda:
+        raise GotenNetHipError(f"gotennet_amd.{what} runs on a ROCm device only (no CPU fallback; the CPU oracle lives in "
+                               "oracle/ for tests)")
+
+
+class GATA(_LayerPackCache, nn.Module):
+    """One GATA layer (reference gotennet.py:78-657): parameters under the reference's names, and ``forward`` with the
+    reference's signature driving the HIP kernels (inference only; inside ``GotenNet`` the stack driver sequences the
+    same kernels with the neighbouring EQFF launches fused in)."""
 
     def __init__(self, n_atom_basis: int, activation: Callable, weight_init=nn.init.xavier_uniform_,
                  bias_init=nn.init.zeros_, aggr: str = "add", epsilon: float = 1e-7, layer_norm: str = "",
@@ -106,7 +170,7 @@ class GATA(nn.Module):
         self.n_atom_basis, self.lmax, self.num_heads = n_atom_basis, lmax, num_heads
         self.last_layer, self.edge_updates, self.scale_edge = last_layer, edge_updates, scale_edge
         self.sep_htr, self.sep_dir, self.sep_tensor = sep_htr, sep_dir, sep_tensor
-        self.dropout, self.epsilon = dropout, epsilon
+        self.dropout, self.epsilon, self.cutoff = dropout, epsilon, cutoff
         multiplier = 3 + (lmax - 1 if sep_dir else 0) + (lmax - 1 if sep_tensor else 0)
         self.multiplier = multiplier
         D_ = partial(Dense, weight_init=weight_init, bias_init=bias_init)
@@ -169,6 +233,54 @@ class GATA(nn.Module):
         for m in self.modules():
             if isinstance(m, (Dense, nn.LayerNorm, TensorLayerNorm)):
                 m.reset_parameters()
+        self.invalidate_packed()
+
+    def layer_config(self) -> engine.Config:
+        return engine.Config(F=self.n_atom_basis, L=1, R=0, H=self.num_heads, lmax=self.lmax, M=self.multiplier,
+                             cutoff=float(self.cutoff), eps=float(self.epsilon), scale_edge=bool(self.scale_edge),
+                             sep_dir=bool(self.sep_dir), sep_tensor=bool(self.sep_tensor), htr_mode=self.htr_mode,
+                             layernorm=bool(self.layernorm_), steerable_norm=bool(self.steerable_norm_),
+                             composed_update=self.composed_update, gate_kind=self.gate_kind,
+                             t_last_act=0 if self.update_info["mlp"] else 3, lin_w=self.update_info["lin_w"],
+                             lin_ln=self.update_info["lin_ln"], evec=self.edge_vec_dim, emlp=self.edge_mlp_dim)
+
+    @torch.no_grad()
+    def forward(self, edge_index: Tensor, h: Tensor, X: Tensor, rl_ij: Tensor, t_ij: Tensor, r_ij: Tensor,
+                n_edges: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+        """Reference GATA.forward (gotennet.py:366-450): ``h`` [N,1,F] (or [N,F]), ``X`` [N,D,F], ``rl_ij`` [E,D],
+        ``t_ij`` [E,F] (or [E,1,F]), ``r_ij`` [E] distances (the cosine cutoff is applied inside, as in ``message``).
+        ``n_edges`` is accepted for signature compatibility; with ``scale_edge`` the out-degree of every source is
+        recomputed from ``edge_index`` exactly as GotenNet.forward does (gotennet.py:986-989).  Any edge order."""
+        _require_cuda(h, "GATA")
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("attention dropout (training mode) is not on the accelerated path; call .eval()")
+        cfg, lw = self.layer_config(), self._layer_pack(_pack_gata)
+        hs, ts = h.shape, t_ij.shape
+        N, E = h.shape[0], edge_index.shape[1]
+        f32c = lambda t: t.to(torch.float32).contiguous()
+        h2, X2, t2 = f32c(h.reshape(N, -1)), f32c(X), f32c(t_ij.reshape(E, -1))
+        rl, r = f32c(rl_ij.reshape(E, -1)), f32c(r_ij.reshape(-1))
+        edge_index = edge_index.contiguous()
+        order = None
+        if E:
+            bits = engine.validate_edges(edge_index, N)
+            if bits & 2:
+                raise ValueError(f"edge_index holds indices outside [0, {N})")
+            if bits & 1:
+                order = torch.sort(edge_index[1], stable=True).indices
+                edge_index, rl, r, t2 = edge_index[:, order].contiguous(), rl[order].contiguous(), r[order].contiguous(), \
+                    t2[order].contiguous()
+        g = engine.Graph(cfg, None, N, edge_index)
+        g.rl = rl
+        engine.call("gn_cosine_cutoff", engine.ptr(r), E, float(self.cutoff), engine.ptr(g.cut), engine._stream())
+        ho, Xo, to = engine.gata_layer(cfg, lw, g, h2, X2, t2)
+        if order is not None and to is not t2:
+            inv = torch.empty_like(order)
+            inv[order] = torch.arange(E, device=order.device)
+            to = to[inv]
+        elif order is not None:
+            to = f32c(t_ij.reshape(E, -1))
+        return ho.reshape(hs), Xo, to.reshape(ts)
 
 
 class TensorLayerNorm(nn.Module):
@@ -182,11 +294,13 @@ class TensorLayerNorm(nn.Module):
         self.register_buffer("weight", torch.ones(hidden_channels))
 
     def reset_parameters(self):
-        self.weight.data.fill_(1.0)
+        with torch.no_grad():
+            self.weight.fill_(1.0)
 
 
-class EQFF(nn.Module):
-    """Parameter container (reference gotennet.py:672-714)."""
+class EQFF(_LayerPackCache, nn.Module):
+    """EQFF block (reference gotennet.py:660-748): parameters under the reference's names; ``forward(h, X)`` drives the
+    HIP kernels (inference only)."""
 
     def __init__(self, n_atom_basis: int, activation: Callable, lmax: int, epsilon: float = 1e-8,
                  weight_init=nn.init.xavier_uniform_, bias_init=nn.init.zeros_):
@@ -201,6 +315,20 @@ class EQFF(nn.Module):
         self.W_vu.reset_parameters()
         for l in self.gamma_m:
             l.reset_parameters()
+        self.invalidate_packed()
+
+    @torch.no_grad()
+    def forward(self, h: Tensor, X: Tensor) -> Tuple[Tensor, Tensor]:
+        """Reference EQFF.forward (gotennet.py:716-748): ``h`` [N,1,F] (or [N,F]), ``X`` [N,D,F] -> (h', X')."""
+        _require_cuda(h, "EQFF")
+        N, F_ = h.shape[0], self.n_atom_basis
+        D = (self.lmax + 1) ** 2 - 1
+        cfg = engine.Config(F=F_, L=1, R=0, H=1, lmax=self.lmax, M=1, cutoff=0.0, eps=float(self.epsilon),
+                            scale_edge=False, sep_dir=False, sep_tensor=False)
+        lw = self._layer_pack(_pack_eqff)
+        ho, Xo = engine.eqff_layer(cfg, lw, h.reshape(N, F_).to(torch.float32).contiguous(),
+                                   X.to(torch.float32).contiguous())
+        return ho.reshape(h.shape), Xo
 
 
 class GotenNet(nn.Module):
@@ -222,6 +350,7 @@ class GotenNet(nn.Module):
                  evec_dim: Optional[int] = None, emlp_dim: Optional[int] = None, sep_htr: bool = True,
                  sep_dir: bool = False, sep_tensor: bool = False, edge_ln: str = ""):
         super().__init__()
+        self._packed = self._packed_key = None
         self.scale_edge = scale_edge
         if type(weight_init) == str:
             weight_init = get_weight_init_by_string(weight_init)
@@ -260,8 +389,7 @@ class GotenNet(nn.Module):
         #: set True when the caller guarantees ``edge_index[1]`` is non-decreasing (what
         #: radius_graph emits); skips the device->host sortedness check (one sync).
         self.assume_sorted_edges = False
-        self._packed = None
-        self._packed_key = None
+        self._warned_inference_only = False
 
     # ------------------------------------------------------------------ parameters
     def reset_parameters(self):
@@ -271,6 +399,26 @@ class GotenNet(nn.Module):
             l.reset_parameters()
         for l in self.eqff_list:
             l.reset_parameters()
+        self.invalidate_packed()
+
+    def invalidate_packed(self):
+        """Drop the packed / transposed / bf16-split copies of the weights (rebuilt on the next forward).
+
+        ``packed_weights`` notices parameter updates through autograd's version counter (optimizer steps,
+        ``load_state_dict``, ``copy_`` / ``fill_`` under ``torch.no_grad()``) and through ``data_ptr`` (``.to()``,
+        ``.cuda()``).  A write through ``param.data`` (``p.data.copy_(...)``, EMA weight swaps written that way) bumps
+        NEITHER: call this method after such a write."""
+        self._packed = self._packed_key = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_packed()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):              # .to() / .cuda() / .float() ...
+        out = super()._apply(fn, *args, **kwargs)
+        self._packed = self._packed_key = None
+        return out
 
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path: str, device="cpu"):
@@ -330,34 +478,7 @@ class GotenNet(nn.Module):
             rb0=d(getattr(self.radial_basis, BASIS_CODE[type(self.radial_basis)][1]).float()),
             rb1=d(getattr(self.radial_basis, BASIS_CODE[type(self.radial_basis)][2]).float()))
         for gata, eq in zip(self.gata_list, self.eqff_list):
-            lw = engine.LayerWeights(
-                Wn1=c(gata.W_q.weight, gata.W_k.weight, gata.gamma_s[0].weight, gata.gamma_v[0].weight),
-                bn1=c(gata.W_q.bias, gata.W_k.bias, gata.gamma_s[0].bias, gata.gamma_v[0].bias),
-                Ws2=d(gata.gamma_s[1].weight), bs2=d(gata.gamma_s[1].bias),
-                Wv2=d(gata.gamma_v[1].weight), bv2=d(gata.gamma_v[1].bias),
-                We=c(gata.W_re.weight, gata.W_rs.weight), be=c(gata.W_re.bias, gata.W_rs.bias),
-                Wvu=d(eq.W_vu.weight),
-                Wm0=d(eq.gamma_m[0].weight), bm0=d(eq.gamma_m[0].bias),
-                Wm1=d(eq.gamma_m[1].weight), bm1=d(eq.gamma_m[1].bias))
-            if not gata.last_layer and gata.edge_updates:
-                dl = gata.gamma_t.dense_layers
-                lw.Wt, lw.bt = d(dl[-1].weight), d(dl[-1].bias)
-                if len(dl) == 2:                   # "mlp"/"mlpa": hidden layer (+ optional LayerNorm "edge_ln")
-                    lw.Wt0, lw.bt0 = d(dl[0].weight), d(dl[0].bias)
-                    if dl[0].norm is not None:
-                        lw.t_ln_w, lw.t_ln_b = d(dl[0].norm.weight), d(dl[0].norm.bias)
-                if gata.update_info["lin_w"]:
-                    lw.Wedp, lw.bedp = d(gata.W_edp.weight), d(gata.W_edp.bias)
-                    if gata.update_info["lin_ln"] == 1:
-                        lw.w_ln_w, lw.w_ln_b = d(gata.gamma_w[0].weight), d(gata.gamma_w[0].bias)
-                    elif gata.update_info["lin_ln"] == 2:
-                        lw.w_ln_w, lw.w_ln_b = d(gata.W_edp.norm.weight), d(gata.W_edp.norm.bias)
-                lw.Wvq = d(gata.W_vq.weight)
-                lw.Wvk = [d(wk.weight) for wk in gata.W_vk] if gata.sep_htr else [d(gata.W_vk.weight)]
-            if gata.layernorm_:
-                lw.ln_w, lw.ln_b = d(gata.layernorm.weight), d(gata.layernorm.bias)
-            if gata.steerable_norm_:
-                lw.tln_w = d(gata.tensor_layernorm.weight)
+            lw = _pack_eqff(eq, _pack_gata(gata))
             pw.layers.append(lw)
         self._packed, self._packed_key = pw, key
         return pw
@@ -380,6 +501,18 @@ class GotenNet(nn.Module):
         if self.training and self.attn_dropout > 0:
             raise NotImplementedError("attention dropout (training mode) is not on the accelerated path; call .eval()")
 
+    def _warn_if_training(self):
+        """The hand-written backward produces INPUT gradients only (forces).  In a training loop ``loss.backward()``
+        would succeed and leave every ``param.grad`` None -- optimizers skip those silently -- so say it once."""
+        if self.training and torch.is_grad_enabled() and not self._warned_inference_only and \
+                any(p.requires_grad for p in self.parameters()):
+            import warnings
+            warnings.warn("gotennet_amd.GotenNet is an inference / force-evaluation path: its backward returns gradients "
+                          "w.r.t. positions (edge_vec, edge_diff) only, parameters receive NO gradient and the backward "
+                          "is not double-differentiable.  Call .eval() (or requires_grad_(False)) to silence this.",
+                          RuntimeWarning, stacklevel=3)
+            self._warned_inference_only = True
+
     def forward(self, atomic_numbers: Tensor, edge_index: Tensor, edge_diff: Tensor, edge_vec: Tensor,
                 _trace: Optional[list] = None) -> Tuple[Tensor, Tensor]:
         self._check_inputs(atomic_numbers, edge_index, edge_diff, edge_vec)
@@ -388,13 +521,10 @@ class GotenNet(nn.Module):
         edge_index = edge_index.contiguous()
         edge_diff = edge_diff.to(torch.float32).contiguous()
         edge_vec = edge_vec.to(torch.float32).contiguous()
-        order = None
-        if not self.assume_sorted_edges and edge_index.shape[1] > 1:
-            tgt = edge_index[1]
-            if not bool((tgt[1:] >= tgt[:-1]).all()):       # one host sync; skipped when assume_sorted_edges
-                order = torch.sort(tgt, stable=True).indices  # keeps the relative order inside a target row
-                edge_index, edge_diff, edge_vec = edge_index[:, order].contiguous(), edge_diff[order], edge_vec[order]
+        if not self.assume_sorted_edges:                    # one host sync; skipped when assume_sorted_edges
+            edge_index, edge_diff, edge_vec, _ = engine.sorted_edges(edge_index, edge_diff, edge_vec, N)
         z32 = atomic_numbers.to(torch.int32)
+        self._warn_if_training()
         if torch.is_grad_enabled() and (edge_vec.requires_grad or edge_diff.requires_grad):
             return _RepresentationFn.apply(edge_diff.contiguous(), edge_vec.contiguous(), self, z32, edge_index)
         with torch.no_grad():
@@ -414,6 +544,7 @@ class GotenNetWrapper(GotenNet):
         from .graph import distance
         atomic_numbers, pos, batch = inputs.z, inputs.pos, inputs.batch
         if torch.is_grad_enabled() and pos.requires_grad:
+            self._warn_if_training()
             self._check_inputs(atomic_numbers, torch.zeros((2, 0), dtype=torch.int64), pos.new_zeros(0), pos.new_zeros((0, 3)))
             return _RepresentationPosFn.apply(pos, self, atomic_numbers.to(torch.int32), batch)
         edge_index, edge_diff, edge_vec = distance(pos, batch, self.cutoff, self.max_num_neighbors)

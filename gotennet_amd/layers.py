@@ -42,14 +42,41 @@ def resolve_activation(act):
         f"activation {act!r}: the MI355X path implements SiLU/swish only (reference default)")
 
 
+def glorot_orthogonal_(tensor: torch.Tensor, scale: float = 2.0) -> torch.Tensor:
+    """'glo_orthogonal' (reference layers.py:360-371 over torch_geometric.nn.inits.glorot_orthogonal): an orthogonal
+    matrix rescaled to the Glorot variance scale / (fan_in + fan_out)."""
+    nn.init.orthogonal_(tensor)
+    with torch.no_grad():
+        fan = tensor.size(-2) + tensor.size(-1)
+        tensor.mul_((scale / (fan * tensor.var())).sqrt())
+    return tensor
+
+
+def he_orthogonal_(tensor: torch.Tensor) -> torch.Tensor:
+    """'he_orthogonal' (reference layers.py:374-423): orthogonal matrix, rows standardised to zero mean / unit
+    variance over the input axis, then scaled by fan_in ** -0.5."""
+    nn.init.orthogonal_(tensor)
+    with torch.no_grad():
+        three = tensor.dim() == 3
+        axis = [0, 1] if three else 1
+        fan_in = tensor.shape[:-1].numel() if three else tensor.shape[1]
+        var, mean = torch.var_mean(tensor, dim=axis, unbiased=True, keepdim=True)
+        tensor.copy_((tensor - mean) / (var + 1e-6) ** 0.5 * (1.0 / fan_in) ** 0.5)
+    return tensor
+
+
 def get_weight_init_by_string(name: str) -> Callable:
-    """Reference layers.py:423-452 (names only; 'glo_orthogonal'/'he_orthogonal' not needed for inference)."""
+    """Reference layers.py:426-452."""
     if name == "":
         return lambda x: x
     if name == "zeros":
         return nn.init.zeros_
     if name == "xavier_uniform":
         return nn.init.xavier_uniform_
+    if name == "glo_orthogonal":
+        return glorot_orthogonal_
+    if name == "he_orthogonal":
+        return he_orthogonal_
     raise ValueError(f"Unknown initialization {name}")
 
 
@@ -113,8 +140,9 @@ class ExpNormalSmearing(nn.Module):
 
     def reset_parameters(self):
         means, betas = self._initial_params()
-        self.means.data.copy_(means)
-        self.betas.data.copy_(betas)
+        with torch.no_grad():                       # in-place through autograd's version counter (cache keys see it)
+            self.means.copy_(means)
+            self.betas.copy_(betas)
 
 
 class GaussianRBF(nn.Module):
@@ -190,4 +218,5 @@ class EdgeInit(nn.Module):
 
     def reset_parameters(self):
         nn.init.xavier_uniform_(self.W_erp.weight)
-        self.W_erp.bias.data.fill_(0)
+        with torch.no_grad():
+            self.W_erp.bias.fill_(0)

@@ -70,37 +70,53 @@ class Atomwise(nn.Module):
         self.atomref = nn.Embedding.from_pretrained(atomref.type(torch.float32)) if atomref is not None else None
 
     # ---- raw (non-autograd) pieces used by the fused pipeline -----------------------
-    def _weights(self):
+    def invalidate_packed(self):
+        """Drop the cached host scalars / transposed weight.  The cache notices updates through autograd's version
+        counter and data_ptr; a write through ``param.data`` bumps neither -- call this after such a write."""
+        self._cache = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_packed()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._cache = None
+        return out
+
+    def _packed(self):
+        """Host copies of the kernel's scalar arguments (a read-back per step would synchronise the stream, and is not
+        allowed inside a hipGraph capture) and the transposed first-layer weight, rebuilt when any parameter changes."""
         d0, d1 = self.out_net[1].out_net[0], self.out_net[1].out_net[1]
+        ts = [d0.weight, d0.bias, d1.weight, d1.bias]
         if isinstance(self.standardize, ScaleShift):
-            # host copies of the two scalars (kernel arguments), re-read only when the buffers change: a read-back
-            # per step would synchronise the stream (and is not allowed inside a hipGraph capture)
-            sd, mn = self.standardize.stddev, self.standardize.mean
-            key = (sd._version, sd.data_ptr(), mn._version, mn.data_ptr())
-            if getattr(self, "_ss_key", None) != key:
-                self._ss, self._ss_key = (float(sd[0]), float(mn[0])), key
-            scale, shift = self._ss
-        else:
+            ts += [self.standardize.stddev, self.standardize.mean]
+        key = tuple((t._version, t.data_ptr()) for t in ts)
+        c = getattr(self, "_cache", None)
+        if c is None or c["key"] != key:
             scale, shift = 1.0, 0.0
-        return d0, d1, scale, shift
+            if isinstance(self.standardize, ScaleShift):
+                scale, shift = float(self.standardize.stddev[0]), float(self.standardize.mean[0])
+            c = dict(key=key, scale=scale, shift=shift, b2=float(d1.bias.detach().cpu()[0]),
+                     w1=d0.weight.detach(), w1t=d0.weight.detach().t().contiguous())
+            self._cache = c
+        return d0, d1, c
+
+    def _weights(self):
+        d0, d1, c = self._packed()
+        return d0, d1, c["scale"], c["shift"]
 
     def energy_raw(self, h: torch.Tensor, z32: torch.Tensor, mol_ptr: torch.Tensor, n_mol: int):
         """-> (energy [n_mol,1], y [N], pre1 [N,Hd])."""
-        d0, d1, scale, shift = self._weights()
+        d0, d1, c = self._packed()
+        scale, shift, b2 = c["scale"], c["shift"], c["b2"]
         N, Fd = h.shape
         Hd = d0.out_features
         pre1 = torch.empty((N, Hd), dtype=torch.float32, device=h.device)
-        w1 = getattr(self, "_w1", None)
-        if w1 is None or self._w1_key != (d0.weight._version, d0.weight.data_ptr()):
-            w1 = d0.weight.detach()
-            self._w1, self._w1_key = w1, (d0.weight._version, d0.weight.data_ptr())
-        engine.gemm(h, Fd, w1, d0.bias.detach(), pre1, Hd, N, Hd, Fd)
+        engine.gemm(h, Fd, c["w1"], d0.bias.detach(), pre1, Hd, N, Hd, Fd)
         y = torch.empty(N, dtype=torch.float32, device=h.device)
         e = torch.empty((n_mol, 1), dtype=torch.float32, device=h.device)
-        b2 = self._b2 if getattr(self, "_b2_ver", None) == d1.bias._version else None
-        if b2 is None:                       # scalar bias read once (host value needed for the kernel argument)
-            b2 = float(d1.bias.detach().cpu()[0])
-            self._b2, self._b2_ver = b2, d1.bias._version
         call("gn_head_energy", ptr(pre1), ptr(d1.weight.detach()), b2, scale, shift,
              ptr(self.atomref.weight.detach()) if self.atomref is not None else None, ptr(z32), ptr(mol_ptr),
              n_mol, Hd, ptr(y), ptr(e), engine._stream())
@@ -108,16 +124,12 @@ class Atomwise(nn.Module):
 
     def grad_h_raw(self, pre1: torch.Tensor, Fd: int) -> torch.Tensor:
         """d(sum of energies)/dh [N,F]."""
-        d0, d1, scale, _ = self._weights()
+        d0, d1, c = self._packed()
         N, Hd = pre1.shape
         g1 = torch.empty_like(pre1)
-        call("gn_head_grad", ptr(pre1), ptr(d1.weight.detach()), scale, N, Hd, ptr(g1), engine._stream())
-        w1t = getattr(self, "_w1t", None)
-        if w1t is None or self._w1t_ver != d0.weight._version or w1t.device != d0.weight.device:
-            w1t = d0.weight.detach().t().contiguous()
-            self._w1t, self._w1t_ver = w1t, d0.weight._version
+        call("gn_head_grad", ptr(pre1), ptr(d1.weight.detach()), c["scale"], N, Hd, ptr(g1), engine._stream())
         gh = torch.empty((N, Fd), dtype=torch.float32, device=pre1.device)
-        engine.gemm(g1, Hd, w1t, None, gh, Fd, N, Fd, Hd)
+        engine.gemm(g1, Hd, c["w1t"], None, gh, Fd, N, Fd, Hd)
         return gh
 
     # ---- reference-style call --------------------------------------------------------

@@ -47,9 +47,18 @@ int gn_abi_version(const char** arch_out);
  * Replaces PyG's implicit index handling in MessagePassing.propagate. */
 int gn_build_csr(const int64_t* edge_index, int E, int N, int* src, int* dst, int* rowptr, void* stream);
 
+/* Validation of a caller-supplied edge list (the reference gets this for free from PyG's scatter, which accepts any
+ * order; the CSR kernels here need target-major order): *flag (zeroed by the caller) |= 1 when edge_index[1] is not
+ * non-decreasing, |= 2 when any index lies outside [0, N).  GotenNet.forward / EnergyForces sort or raise on it. */
+int gn_check_edges(const int64_t* edge_index, int E, int N, int* flag, void* stream);
+
 /* Out-degree of every node counted over ALL edges incl. self-loops
  * (gotennet.py:986-989: scatter(ones, edge_index[0])).  outdeg must be zeroed by the caller. */
 int gn_out_degree(const int* src, int E, int* outdeg, void* stream);
+
+/* CosineCutoff alone (layers.py:149-152): cut[e] = 0.5 (cos(pi d / cutoff) + 1) for d < cutoff, else 0.  Used when a
+ * caller drives ONE GATA layer (GATA.forward, gotennet.py:366-450, takes r_ij and applies the cutoff inside message). */
+int gn_cosine_cutoff(const float* dist, int E, float cutoff, float* cut, void* stream);
 
 /* ---- K1 edge geometry ---------------------------------------------------------------- */
 /* unit vector on non-self edges (gotennet.py:978-980), TensorInit real harmonics

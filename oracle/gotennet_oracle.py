@@ -461,15 +461,23 @@ def shifted_softplus(x: Tensor) -> Tensor:
     return F.softplus(x) - math.log(2.0)
 
 
-def atomwise_energy(head: Dict[str, Tensor], h: Tensor, batch: Tensor, n_mol: int,
-                    activation: str = "silu") -> Tensor:
-    """outputs.py:323-376 (Atomwise, standardize=identity unless given):
-    y_i = W2 act(W1 h_i + b1) + b2; y = sum_{i in molecule} (stddev*y_i + mean)."""
+def atomwise_contributions(head: Dict[str, Tensor], h: Tensor, z: Optional[Tensor] = None,
+                           activation: str = "silu") -> Tensor:
+    """outputs.py:323-346: y_i = stddev * (W2 act(W1 h_i + b1) + b2) + mean [+ atomref[z_i]]."""
     act = F.silu if activation == "silu" else shifted_softplus
     y = F.linear(act(F.linear(h, head["out_net.1.out_net.0.weight"], head["out_net.1.out_net.0.bias"])),
                  head["out_net.1.out_net.1.weight"], head["out_net.1.out_net.1.bias"])
     if "standardize.stddev" in head:
         y = y * head["standardize.stddev"] + head["standardize.mean"]
+    if "atomref.weight" in head:
+        y = y + head["atomref.weight"][z]
+    return y
+
+
+def atomwise_energy(head: Dict[str, Tensor], h: Tensor, batch: Tensor, n_mol: int,
+                    activation: str = "silu", z: Optional[Tensor] = None) -> Tensor:
+    """outputs.py:323-376 (Atomwise, aggregation "sum"): y = sum_{i in molecule} y_i."""
+    y = atomwise_contributions(head, h, z, activation)
     return torch.zeros((n_mol, y.shape[1]), dtype=y.dtype).index_add_(0, batch, y)
 
 
@@ -480,6 +488,6 @@ def energy_and_forces(sd, cfg, head, z, pos, batch, n_mol, max_num_neighbors: in
     pos = pos.detach().clone().requires_grad_(True)
     ei, w, vec = distance(pos, batch, cfg["cutoff"], max_num_neighbors)
     h, X = gotennet_forward(sd, cfg, z, ei, w, vec)
-    e = atomwise_energy(head, h, batch, n_mol, activation)
+    e = atomwise_energy(head, h, batch, n_mol, activation, z=z)
     (g,) = torch.autograd.grad(e.sum(), pos)
     return e.detach(), -g, (h.detach(), X.detach(), ei)

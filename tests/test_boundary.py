@@ -1,0 +1,221 @@
+"""Boundary behaviour of the drop-in modules: stand-alone GATA / EQFF calls (reference gotennet.py:366-450, 716-748),
+caller-supplied edge lists in any order, the Atomwise head with non-trivial mean / stddev / atomref (outputs.py:323-376),
+cache invalidation after in-place weight writes, the inference-only warning."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import GOLDEN_DIR, load_case, rel_err
+
+TOL = 1e-4
+
+
+def _head_kat():
+    k = np.load(os.path.join(GOLDEN_DIR, "kat_head.npz"))
+    t = {n: torch.from_numpy(k[n]) for n in k.files if not n.startswith("head/")}
+    hsd = {n[5:]: torch.from_numpy(k[n]) for n in k.files if n.startswith("head/")}
+    return t, hsd
+
+
+# --------------------------------------------------------------------------------------------------- CPU
+def test_oracle_head_matches_reference_kat():
+    """The oracle's Atomwise restatement against the reference's own head with mean / stddev / atomref set."""
+    from oracle import gotennet_oracle as orc
+    t, hsd = _head_kat()
+    y = orc.atomwise_contributions(hsd, t["h"], t["z"])
+    e = orc.atomwise_energy(hsd, t["h"], t["batch"], int(t["n_mol"]), z=t["z"])
+    assert rel_err(y, t["contrib"]) < 1e-6
+    assert rel_err(e, t["energy"]) < 1e-6
+
+
+def test_weight_init_names_of_the_reference():
+    """Every init name the reference accepts (layers.py:426-452) builds a module (checkpoints carry them as strings)."""
+    import gotennet_amd
+    for name in ("xavier_uniform", "glo_orthogonal", "he_orthogonal", "zeros", ""):
+        net = gotennet_amd.GotenNet(n_atom_basis=32, n_interactions=1, n_rbf=8, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
+                                    lmax=1, weight_init=name)
+        assert torch.isfinite(net.gata_list[0].W_q.weight).all()
+    with pytest.raises(ValueError):
+        gotennet_amd.GotenNet(n_atom_basis=32, n_interactions=1, n_rbf=8, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
+                              weight_init="no_such_init")
+    w = torch.empty(64, 32)
+    from gotennet_amd.layers import glorot_orthogonal_, he_orthogonal_
+    glorot_orthogonal_(w)
+    assert abs(float(w.var()) - 2.0 / (64 + 32)) < 1e-6          # Glorot variance scale / (fan_in + fan_out)
+    he_orthogonal_(w)
+    assert abs(float(w.var(dim=1).mean()) - 1.0 / 32) < 1e-3     # standardised rows scaled by 1 / fan_in
+
+
+def test_packed_cache_invalidation_hooks():
+    """Version-counter writes are seen; load_state_dict / reset_parameters / invalidate_packed drop the pack."""
+    import gotennet_amd
+    net = gotennet_amd.GotenNet(n_atom_basis=32, n_interactions=2, n_rbf=8, cutoff_fn=gotennet_amd.CosineCutoff(5.0), lmax=2)
+    pw0 = net.packed_weights()
+    assert net.packed_weights() is pw0
+    with torch.no_grad():
+        net.gata_list[0].W_q.weight.mul_(2.0)                    # bumps _version
+    pw1 = net.packed_weights()
+    assert pw1 is not pw0 and torch.equal(pw1.layers[0].Wn1[:32], net.gata_list[0].W_q.weight)
+    net.gata_list[0].W_q.weight.data.mul_(0.5)                   # .data write: invisible to the version counter ...
+    net.invalidate_packed()                                      # ... so the documented hook must be called
+    assert torch.equal(net.packed_weights().layers[0].Wn1[:32], net.gata_list[0].W_q.weight)
+    pw2 = net.packed_weights()
+    net.load_state_dict(net.state_dict())
+    assert net.packed_weights() is not pw2
+    pw3 = net.packed_weights()
+    net.reset_parameters()
+    assert net.packed_weights() is not pw3
+
+
+# --------------------------------------------------------------------------------------------------- GPU
+def _mirror(cfg, sd):
+    from tests.test_hip_parity import _net_from_case
+    return _net_from_case(cfg, sd)
+
+
+@pytest.mark.gpu
+@pytest.mark.usefixtures("gemm_mode")
+@pytest.mark.parametrize("name", ["l2_sep_f32", "l3_sep_scale_f32", "opt_layernorm_tln", "opt_gauss_jointhtr_gated",
+                                  "opt_mlp_linwa_ln_gated"])
+def test_gata_and_eqff_modules_are_callable(name):
+    """gotennet_amd.GATA / EQFF used the way a caller composing layers uses the reference's (gotennet.py:995-1007):
+    every layer's (h, X, t) against the oracle's per-layer functions; also with a shuffled edge list."""
+    from oracle import gotennet_oracle as orc
+    cfg, sd, _, t = load_case(name)
+    net = _mirror(cfg, sd)
+    ei, ed = t["edge_index"], t["edge_diff"]
+    N, E = t["z"].shape[0], ei.shape[1]
+    # layer inputs from the oracle (pinned to the reference by the golden tests)
+    _, _, tr = orc.gotennet_forward(sd, cfg, t["z"], ei, ed, t["edge_vec"], return_trace=True)
+    rl = tr["rl"]
+    deg = torch.zeros(N).index_add_(0, ei[0], torch.ones(E))
+    n_edges = deg[ei[0]]
+    L = cfg["n_interactions"]
+    g = torch.Generator().manual_seed(0)
+    perm = torch.randperm(E, generator=g)
+    for li in range(L - 1):
+        h_in, X_in, t_in = tr["layers"][li]                      # outputs of layer li = inputs of layer li + 1
+        p, pe = f"gata_list.{li + 1}.", f"eqff_list.{li + 1}."
+        hn, Xn = orc.gata_input_norms(sd, cfg, p, h_in, X_in)
+        h_ref, X_ref = orc.gata_message_aggregate(sd, cfg, p, ei, hn, Xn, rl, t_in, ed, n_edges)
+        t_ref = t_in
+        if li + 1 != L - 1 and cfg.get("edge_updates", True):
+            t_ref = orc.gata_htr(sd, cfg, p, ei, X_ref, rl, t_in)
+        gata, eqff = net.gata_list[li + 1], net.eqff_list[li + 1]
+        for order in (None, perm):
+            sel = (lambda v: v) if order is None else (lambda v: v[order])
+            eic = (ei if order is None else ei[:, order]).cuda()
+            h1, X1, t1 = gata(eic, h_in.unsqueeze(1).cuda(), X_in.cuda(), sel(rl).cuda(), sel(t_in).cuda(), sel(ed).cuda(),
+                              sel(n_edges).unsqueeze(1).cuda())
+            assert h1.shape == (N, 1, cfg["n_atom_basis"])
+            assert rel_err(h1.squeeze(1).cpu(), h_ref) < TOL and rel_err(X1.cpu(), X_ref) < TOL
+            assert rel_err(t1.cpu(), sel(t_ref)) < TOL
+        h2_ref, X2_ref = orc.eqff(sd, cfg, pe, h_ref, X_ref)
+        h2, X2 = eqff(h1, X1)
+        assert rel_err(h2.squeeze(1).cpu(), h2_ref) < TOL and rel_err(X2.cpu(), X2_ref) < TOL
+
+
+@pytest.mark.gpu
+def test_energy_forces_accepts_any_edge_order_and_rejects_bad_indices():
+    """EnergyForces / CapturedStep validate the caller's edge list on the device: a shuffled list gives the sorted
+    list's energies and forces bit for bit (stable sort: same per-target order), out-of-range indices raise."""
+    from tests.test_hip_forces import _head_from_case
+    from gotennet_amd.pipeline import CapturedStep, EnergyForces
+    cfg, sd, head_sd, t = load_case("l2_sep_f32")
+    net, head = _mirror(cfg, sd), _head_from_case(cfg, head_sd)
+    ef = EnergyForces(net, head)
+    z, batch = t["z"].cuda(), t["batch"].cuda()
+    ei, ed, ev = t["edge_index"].cuda(), t["edge_diff"].cuda(), t["edge_vec"].cuda()
+    e0, f0 = (v.clone() for v in ef(z, ei, ed, ev, batch, cfg["n_mol"]))
+    assert rel_err(f0.cpu(), t["forces"]) < TOL
+    # permute whole target rows (keeps the order inside a row, so the stable sort restores the original list)
+    E = ei.shape[1]
+    tgt = ei[1]
+    key = (tgt * 7919 + 13) % 1009                              # scrambles the row order deterministically
+    order = torch.sort(key, stable=True).indices
+    assert not bool((tgt[order][1:] >= tgt[order][:-1]).all())
+    e1, f1 = ef(z, ei[:, order], ed[order], ev[order], batch, cfg["n_mol"])
+    assert torch.equal(e1, e0) and torch.equal(f1, f0)
+    # a fully random order: same sums in a different order inside the rows -> equal to rounding
+    g = torch.Generator().manual_seed(1)
+    rnd = torch.randperm(E, generator=g).cuda()
+    e2, f2 = ef(z, ei[:, rnd], ed[rnd], ev[rnd], batch, cfg["n_mol"])
+    assert rel_err(e2.cpu(), e0.cpu()) < 1e-5 and rel_err(f2.cpu(), f0.cpu()) < 1e-4
+    bad = ei.clone()
+    bad[0, 3] = z.shape[0]                                       # one past the last atom
+    with pytest.raises(ValueError):
+        ef(z, bad, ed, ev, batch, cfg["n_mol"])
+    with pytest.raises(ValueError):
+        CapturedStep(ef, z, bad, batch, cfg["n_mol"])
+    with pytest.raises(ValueError):
+        net(z, bad, ed, ev)
+    # CapturedStep on a shuffled list: same result as the eager path
+    step = CapturedStep(ef, z, ei[:, order], batch, cfg["n_mol"])
+    e3, f3 = step(t["pos"].cuda())
+    assert rel_err(e3.cpu(), e0.cpu()) < 1e-5 and rel_err(f3.cpu(), f0.cpu()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_head_scale_shift_atomref_against_reference():
+    """gn_head_energy with non-trivial mean / stddev / atomref against the reference Atomwise (tests/golden/kat_head.npz),
+    and the force path: F scales with stddev, E = stddev E0 + n mean + sum atomref[z]."""
+    from gotennet_amd.outputs import Atomwise, molecule_ptr
+    t, hsd = _head_kat()
+    F_, Hd = t["h"].shape[1], hsd["out_net.1.out_net.0.weight"].shape[0]
+    head = Atomwise(n_in=F_, n_hidden=Hd, property="property", contributions="contrib", mean=hsd["standardize.mean"],
+                    stddev=hsd["standardize.stddev"], atomref=t["atomref"])
+    head.load_state_dict(hsd, strict=True)
+    head = head.cuda().eval()
+    n_mol = int(t["n_mol"])
+    z32, batch = t["z"].cuda().to(torch.int32), t["batch"].cuda()
+    e, y, _ = head.energy_raw(t["h"].cuda(), z32, molecule_ptr(batch, n_mol), n_mol)
+    assert rel_err(e.cpu(), t["energy"]) < 1e-5
+    assert rel_err(y.cpu(), t["contrib"].reshape(-1)) < 1e-5
+    # reference-style call
+    class _In(dict):
+        __getattr__ = dict.__getitem__
+    out = head(_In(z=t["z"].cuda(), batch=batch, pos=None, representation=t["h"].cuda()))
+    assert rel_err(out["property"].cpu(), t["energy"]) < 1e-5 and rel_err(out["contrib"].cpu(), t["contrib"]) < 1e-5
+    # through the fused force pipeline
+    from tests.test_hip_forces import _head_from_case
+    from gotennet_amd.pipeline import EnergyForces
+    cfg, sd, head_sd, c = load_case("l2_sep_f32")
+    net = _mirror(cfg, sd)
+    plain = _head_from_case(cfg, head_sd)
+    atomref = torch.linspace(-2.0, 3.0, cfg["max_z"]).reshape(-1, 1)
+    scaled = Atomwise(n_in=cfg["n_atom_basis"], n_hidden=16, property="property", derivative="forces",
+                      mean=torch.tensor([1.7]), stddev=torch.tensor([0.35]), atomref=atomref)
+    scaled.load_state_dict({**head_sd, "standardize.mean": torch.tensor([1.7]), "standardize.stddev": torch.tensor([0.35]),
+                            "atomref.weight": atomref}, strict=True)
+    scaled = scaled.cuda().eval()
+    args = (c["z"].cuda(), c["edge_index"].cuda(), c["edge_diff"].cuda(), c["edge_vec"].cuda(), c["batch"].cuda(), cfg["n_mol"])
+    e0, f0 = (v.clone() for v in EnergyForces(net, plain)(*args))
+    e1, f1 = EnergyForces(net, scaled)(*args)
+    cnt = torch.bincount(c["batch"], minlength=cfg["n_mol"]).double()
+    ref_sum = torch.zeros(cfg["n_mol"], dtype=torch.double).index_add_(0, c["batch"], atomref.double()[c["z"], 0])
+    e_expect = 0.35 * e0.cpu().double().reshape(-1) + 1.7 * cnt + ref_sum
+    assert rel_err(e1.cpu().reshape(-1), e_expect) < 1e-5
+    assert rel_err(f1.cpu(), 0.35 * f0.cpu()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_training_mode_warns_once_and_stale_pack_is_refreshed():
+    import gotennet_amd
+    cfg, sd, _, t = load_case("l2_sep_f32")
+    net = _mirror(cfg, sd)
+    args = (t["z"].cuda(), t["edge_index"].cuda(), t["edge_diff"].cuda())
+    h0, _ = net(*args, t["edge_vec"].cuda())
+    with torch.no_grad():
+        net.gata_list[0].W_q.weight.mul_(1.5)
+    h1, _ = net(*args, t["edge_vec"].cuda())
+    assert not torch.equal(h0, h1)                               # the packed copy followed the in-place update
+    net.train()
+    ev = t["edge_vec"].cuda().requires_grad_(True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        net(*args, ev)
+        net(*args, ev)
+    assert sum("inference" in str(x.message) for x in w) == 1

@@ -456,6 +456,40 @@ def sh_kat():
     print("kat_basis written")
 
 
+def head_kat():
+    """Known-answer test for the reference Atomwise head (outputs.py:323-376) with NON-trivial mean / stddev / atomref:
+    random atom features in, per-molecule property and per-atom contributions out."""
+    sys.modules.setdefault("torch_scatter", types.ModuleType("torch_scatter"))
+    sys.modules["torch_scatter"].scatter = ref_shims._scatter
+    sys.modules.setdefault("ase", types.ModuleType("ase"))
+    sys.modules.setdefault("ase.data", types.ModuleType("ase.data"))
+    sys.modules["ase.data"].atomic_masses = np.ones(120)
+    sys.modules["ase"].data = sys.modules["ase.data"]
+    from gotennet.models.components import outputs as ref_out
+    g = torch.Generator().manual_seed(41)
+    F_, Hd, n_mol = 64, 32, 3
+    sizes = [9, 1, 14]
+    z = torch.randint(1, 10, (sum(sizes),), generator=g)
+    batch = torch.repeat_interleave(torch.arange(n_mol), torch.tensor(sizes))
+    h = torch.randn((len(z), F_), generator=g)
+    atomref = torch.randn((10, 1), generator=g) * 3.0
+    head = ref_out.Atomwise(n_in=F_, n_hidden=Hd, activation=torch.nn.functional.silu, property="property",
+                            contributions="contrib", mean=torch.tensor([1.7]), stddev=torch.tensor([0.35]),
+                            atomref=atomref)
+    randomise(head, 4100)
+
+    class _D(dict):
+        __getattr__ = dict.__getitem__
+    with torch.no_grad():
+        res = head(_D(z=z, batch=batch, representation=h, vector_representation=None))
+    out = dict(h=h.numpy(), z=z.numpy(), batch=batch.numpy(), n_mol=np.array(n_mol), atomref=atomref.numpy(),
+               energy=res["property"].numpy(), contrib=res["contrib"].numpy())
+    for k, v in head.state_dict().items():
+        out["head/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "kat_head.npz"), **out)
+    print("kat_head written:", sorted(k for k in out if k.startswith("head/")))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)  # deterministic reduction order for the goldens
     only = sys.argv[1:]                    # optional: names of the fixtures to (re)generate
@@ -472,3 +506,5 @@ if __name__ == "__main__":
             build_workload(name, *spec)
     if not only:
         sh_kat()
+    if not only or "kat_head" in only:
+        head_kat()
