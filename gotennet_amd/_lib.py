@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libgotennet_hip.so")
+#: GN_LIB_PATH: a tuning variant of the library built by tools/variants.py (same ABI); default = the product library
+LIB_PATH = os.environ.get("GN_LIB_PATH") or os.path.join(_PKG, "libgotennet_hip.so")
 
 GN_ERR_BAD_ARG = 10001
 ABI_VERSION = 2

@@ -25,11 +25,12 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build_library(force: bool = False, verbose: bool = False, extra_flags=(), out: str = LIB) -> str:
+    """``extra_flags`` / ``out``: tuning variants (-DGN_...=n) built next to the product library (tools/variants.py)."""
+    if not force and not needs_build() and out == LIB:
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + sources() + ["-o", LIB]
+    cmd = [hipcc] + FLAGS + list(extra_flags) + sources() + ["-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -61,6 +61,9 @@ __device__ __forceinline__ void split4_trunc(float4 v, bf16x4& hi, bf16x4& mid, 
 }
 
 __device__ __forceinline__ int phys_row(const GemmArgs& p, int r) {
+    // identity row map (row_cnt = 1: every product except the per-degree W_vk ones): no integer division -- the
+    // epilogue calls this once per stored row, and a runtime division is ~40 VALU instructions
+    if (p.row_cnt == 1) return r * p.row_gstride + p.row_goff;
     return (r / p.row_cnt) * p.row_gstride + p.row_goff + (r % p.row_cnt);
 }
 

@@ -23,7 +23,38 @@
 //   2: A <- A * SiLU'(P)            (backward through an activation; P = stored pre-activation)
 //   and, for every column, A <- A * G when a_gate != NULL.
 #include <cstdlib>
+#include <type_traits>
 #include "gn_gemm.h"
+
+#ifndef GN_SPLIT_LOOP
+#define GN_SPLIT_LOOP 2        // 2: branch-free A fetch two slabs ahead (exact s_waitcnt); 0: conditional loads
+#endif
+#ifndef GN_SPLIT_SKEW
+#define GN_SPLIT_SKEW 0        // > 0: workgroups start de-phased by up to this many kilocycles (epilogue store bursts)
+#endif
+#ifndef GN_SPLIT_NOSTORE
+#define GN_SPLIT_NOSTORE 0     // probe only: skip the global stores of the epilogue
+#endif
+#ifndef GN_SPLIT_SCHED
+#define GN_SPLIT_SCHED 0       // > 0: sched_group_barrier pattern [1 MFMA, n VALU] in the split main loop (tools/variants.py)
+#endif
+
+#ifndef GN_SPLIT_TRACE
+#define GN_SPLIT_TRACE 0       // probe builds only: per-tile phase timestamps of the first workgroups (gn_debug_trace)
+#endif
+#if GN_SPLIT_TRACE
+__device__ long long gn_trace_buf[64 * 16 * 8];
+#define GN_TR(slot)                                                                              \
+    do {                                                                                         \
+        if (SPLIT && tid == 0 && blockIdx.x < 64 && tile_no < 16)                                \
+            gn_trace_buf[(blockIdx.x * 16 + tile_no) * 8 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+extern "C" int gn_debug_trace(long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(gn_trace_buf), sizeof(gn_trace_buf));
+}
+#else
+#define GN_TR(slot) do {} while (0)
+#endif
 
 namespace gn {
 
@@ -34,9 +65,14 @@ namespace gn {
 // are a few MB, L2-resident, and every wave needs a different column block.  Six v_mfma_f32_32x32x16_bf16 per
 // 32x32x16 product block, fp32 accumulate; everything else (grouping, persistent tile walk, prologues, epilogue) is
 // shared with the exact-fp32 instantiation.
-template <int TM, int TN, bool PRO, int PF, bool SPLIT>
-__global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+// Wave grid: the 4 waves of a workgroup form WM x WN; each wave owns TM x TN MFMA tiles of 32 x 32, so the workgroup
+// tile is (32 TM WM) x (32 TN WN).  Exact fp32: 2 x 2 waves.  SPLIT, 128 x 128 tile: 1 x 4 waves of 4 x 1 tiles -- every
+// wave then needs ONE 32-column block of the weight per k-step (3 KiB from L2 through the 64 B/clk L1 path instead of
+// 6 KiB with 2 x 2 tiles per wave) and re-reads the whole A slab from LDS, which has the bandwidth to spare.
+template <int TM, int TN, int WM, int WN, bool PRO, int PF, bool SPLIT>
+__device__ __forceinline__ void gemm_body(const GroupArgs ga) {
+    static_assert(WM * WN == 4, "four waves per workgroup");
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int RA = BM / 32, RB = BN / 32;       // staged float4 rows per thread
     constexpr int STAGE = (BM + BN) * PITCH;        // floats per K-slab buffer (A rows then W rows)
     constexpr int CP = BN + 4;                      // epilogue tile pitch
@@ -104,7 +140,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int c4 = tid & 7;                         // staging map: thread -> (row sr + 32 i, float4 column c4)
     const int sr = tid >> 3;
     const int stride = gridDim.x >> 3;
@@ -137,7 +173,47 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
     // PF register sets of prefetched slabs: a fetched slab stays in flight for PF compute phases (PF = 1 is
     // what ships: PF = 2/3 measured no gain on MI355X and costs a wave of occupancy)
     float4 pa[PF][RA], pb[PF][RB];
+    // L2 (split, no prologue): branch-free A fetch into TWO register sets (slab s lives in set s & 1), so that the
+    // compiler can count its loads exactly (exec-masked loads force conservative s_waitcnt: the HBM latency of the A
+    // slab was exposed once per slab) and a slab stays in flight for two slab times.
+    constexpr bool L2 = SPLIT && !PRO && GN_SPLIT_LOOP == 2;
+    float4 qa2[2][RA];
+    bool kok2[2] = {true, true};
+    auto fetchA = [&](int k0, float4 (&qa)[RA], bool& kflag) {
+        const int kraw = k0 + 4 * c4;
+        const bool kok = kraw < p.K;
+        const int kc = kok ? kraw : 0;               // clamped: any valid column, zeroed by select in stashA
+        const int k0c = kok ? k0 : 0;
+        const float* Ab = p.A;
+        int ka = kc;
+        if (p.a_seg) {
+            const bool s2 = k0c >= 2 * p.a_seg, s1 = k0c >= p.a_seg;
+            Ab = s2 ? p.A3 : (s1 ? p.A2 : p.A);
+            ka = kc - (s2 ? 2 * p.a_seg : (s1 ? p.a_seg : 0));
+        }
+#pragma unroll
+        for (int i = 0; i < RA; ++i) qa[i] = ld4(Ab + (size_t)prow[i] * p.lda + ka);   // prow of a row past M is row 0: valid memory
+        kflag = kok;
+    };
+    auto stashA = [&](int sb, const float4 (&qa)[RA], bool kflag) {
+        __bf16* d0 = reinterpret_cast<__bf16*>(smem) + sb * STAGE_S + sr * SPLIT_PB + 4 * c4;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            bf16x4 h, m, l;
+            const bool ok = aok[i] && kflag;
+            const float4 v = make_float4(ok ? qa[i].x : 0.f, ok ? qa[i].y : 0.f, ok ? qa[i].z : 0.f, ok ? qa[i].w : 0.f);
+            split4_trunc(v, h, m, l);
+            __bf16* d = d0 + 32 * i * SPLIT_PB;
+            *reinterpret_cast<bf16x4*>(d) = h;
+            *reinterpret_cast<bf16x4*>(d + APL) = m;
+            *reinterpret_cast<bf16x4*>(d + 2 * APL) = l;
+        }
+    };
     auto fetch = [&](int k0, float4 (&qa)[RA], float4 (&qb)[RB]) {
+        if constexpr (L2) {                           // (the cross-tile prefetch of a tile's first slab: set 0)
+            fetchA(k0, qa2[0], kok2[0]);
+            return;
+        }
         const int kc = k0 + 4 * c4;
         const bool kok = kc < p.K;
         const bool pro = PRO && p.pro_mode && kc >= p.pro_lo && kc < p.pro_hi;
@@ -167,7 +243,9 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
     };
     // slab buffer `sb` (0 / 1) of the double buffer
     auto stash = [&](int sb, const float4 (&qa)[RA], const float4 (&qb)[RB]) {
-        if constexpr (SPLIT) {
+        if constexpr (L2) {
+            stashA(sb, qa2[0], kok2[0]);
+        } else if constexpr (SPLIT) {
             __bf16* d0 = reinterpret_cast<__bf16*>(smem) + sb * STAGE_S + sr * SPLIT_PB + 4 * c4;
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
@@ -212,11 +290,20 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
     // multiplied and is refilled with slab kt+1+PF right after it has been written to LDS
     int idx = blockIdx.x >> 3;
     if (idx >= tile_stop) return;
+#if GN_SPLIT_SKEW
+    if constexpr (SPLIT) {
+        const unsigned hsh = (blockIdx.x * 2654435761u) >> 22;                       // 0 .. 1023, uniform over the workgroups
+        const long long until = __builtin_readcyclecounter() + (long long)hsh * GN_SPLIT_SKEW;   // SKEW kilocycles ~ 1024 SKEW cycles max
+        while (__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     select(idx);
     set_tile(idx);
     fetch(0, pa[0], pb[0]);
   // persistent over tiles: workgroup b walks the tiles base + b/8, base + b/8 + gridDim/8, ... of ITS XCD's range
-  for (;;) {
+  int tile_no = 0;
+  for (;; ++tile_no) {
+    GN_TR(0);
     const int nk = (p.K + BK - 1) / BK;
     const int m0 = ((idx - g_begin) / tiles_n) * BM;
     const int n0 = ((idx - g_begin) % tiles_n) * BN;
@@ -233,44 +320,96 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
         load_b(0, bq[0]);
     }
     __syncthreads();
+    GN_TR(1);
+    const int khalf = (lane >> 5) * 16;
+    const int frow = lane & 31;
+    if constexpr (SPLIT) {
+        static_assert(PF == 1, "the split main loop prefetches one slab");
+        // One slab = two 16-deep k-steps.  While slab kt is multiplied: the weights of the NEXT k-step are in flight
+        // (L2 -> registers), slab kt + 1 (already in registers) is split and written to the other LDS buffer, and after
+        // the barrier slab kt + 2 goes in flight from HBM.  The last slab is peeled so that the steady-state body has
+        // no conditional code: it is ONE scheduling region and the split arithmetic can sit in the MFMAs' shadow.
+        if (!L2 && nk > 1) fetch(BK, pa[0], pb[0]);
+        auto kstep = [&](const __bf16* Ap, int ks, const uint4 (&bw)[TN][3]) {
+            bf16x8 a[TM][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int s_ = 0; s_ < 3; ++s_)
+                    a[i][s_] = *reinterpret_cast<const bf16x8*>(Ap + s_ * APL + i * 32 * SPLIT_PB + ks * 16);
+            // smallest terms first (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi); consecutive MFMAs rotate over the
+            // TM*TN accumulators so that none waits on the one before it
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            a[i][TA[t]], __builtin_bit_cast(bf16x8, bw[j][TB[t]]), acc[i][j], 0, 0, 0);
+        };
+        const __bf16* Abase = reinterpret_cast<const __bf16*>(smem) + (wm * 32 * TM + frow) * SPLIT_PB + (lane >> 5) * 8;
+        if constexpr (L2) {
+            // Load order per slab kt (vmcnt retires in order): weights of k-step 2kt+1, THEN the A slab kt+2 (two slab
+            // times ahead), mid-slab the weights of k-step 2kt+2: nothing that is needed soon ever queues behind an A
+            // load younger than one slab time.  sched_barrier(0) keeps the phases apart (without them the scheduler
+            // hoists across the whole region until the 256-register budget spills: measured 15-30 % slower).
+            auto slab = [&](int kt, auto SET, auto LAST) {
+                constexpr int set = decltype(SET)::value;            // register set of slab kt (= kt & 1)
+                constexpr bool last = decltype(LAST)::value;
+                const __bf16* Ap = Abase + set * STAGE_S;
+                load_b(2 * kt + 1, bq[1]);
+                if constexpr (!last) fetchA((kt + 2) * BK, qa2[set], kok2[set]);    // slab kt + 2 -> the set slab kt came from
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(Ap, 0, bq[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!last) load_b(2 * kt + 2, bq[0]);
+                kstep(Ap, 1, bq[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!last) stashA(set ^ 1, qa2[set ^ 1], kok2[set ^ 1]);  // slab kt + 1 -> the other LDS buffer
+                __syncthreads();
+            };
+            using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>;
+            using No = std::false_type; using Yes = std::true_type;
+            fetchA(BK, qa2[1], kok2[1]);             // slab 1 (zero-filled past K); slab 0 is already staged
+            int kt = 0;
+            for (; kt + 2 < nk; kt += 2) {
+                slab(kt, T0{}, No{});
+                slab(kt + 1, T1{}, No{});
+            }
+            if (nk - kt == 2) {
+                slab(kt, T0{}, No{});
+                slab(kt + 1, T1{}, Yes{});
+            } else {
+                slab(kt, T0{}, Yes{});
+            }
+        } else {
+        // (the conditional form: weights, MFMAs and the split each in their own basic block.  A branch-free single
+        // block, with or without sched_group_barrier interleaving, measured 15-30 % SLOWER on MI355X: the scheduler
+        // hoists until the 256-register budget spills)
+        for (int kt = 0; kt < nk; ++kt) {
+            const __bf16* Ap = Abase + (kt & 1) * STAGE_S;
+            load_b(2 * kt + 1, bq[1]);
+            kstep(Ap, 0, bq[0]);
+            if (kt + 1 < nk) load_b(2 * kt + 2, bq[0]);
+            kstep(Ap, 1, bq[1]);
+            if (kt + 1 < nk) stash((kt + 1) & 1, pa[0], pb[0]);
+            __syncthreads();
+            if (kt + 2 < nk) fetch((kt + 2) * BK, pa[0], pb[0]);
+        }
+        }
+    } else {
 #pragma unroll
     for (int s = 0; s < PF; ++s)
         if (1 + s < nk) fetch((1 + s) * BK, pa[s], pb[s]);
 
-    const int khalf = (lane >> 5) * 16;
-    const int frow = lane & 31;
     for (int kt0 = 0; kt0 < nk; kt0 += PF) {
 #pragma unroll
       for (int s = 0; s < PF; ++s) {
         const int kt = kt0 + s;
         if (kt >= nk) break;
-        if constexpr (SPLIT) {
-            const __bf16* Ap = reinterpret_cast<const __bf16*>(smem) + (kt & 1) * STAGE_S +
-                               (wm * 32 * TM + frow) * SPLIT_PB + (lane >> 5) * 8;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {        // two 16-deep MFMA steps per slab
-                const int g = 2 * kt + ks;
-                if (g + 1 < ks2) load_b(g + 1, bq[(ks + 1) & 1]);   // next step's weights in flight under this step's MFMAs
-                bf16x8 a[TM][3];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int s_ = 0; s_ < 3; ++s_)
-                        a[i][s_] = *reinterpret_cast<const bf16x8*>(Ap + s_ * APL + i * 32 * SPLIT_PB + ks * 16);
-                // smallest terms first (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi); consecutive MFMAs rotate over the
-                // TM*TN accumulators so that none waits on the one before it
-                constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
-                constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                for (int t = 0; t < 6; ++t)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                a[i][TA[t]], __builtin_bit_cast(bf16x8, bq[ks & 1][j][TB[t]]), acc[i][j], 0, 0, 0);
-            }
-        } else {
         const float* As = smem + (kt & 1) * STAGE;
         const float* Bs = As + BM * PITCH;
 #pragma unroll
@@ -298,11 +437,11 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
         }
-        }
         if (kt + 1 < nk) stash((kt + 1) & 1, pa[s], pb[s]);   // other buffer: last read in iteration kt-1
         __syncthreads();
         if (kt + 1 + PF < nk) fetch((kt + 1 + PF) * BK, pa[s], pb[s]);
       }
+    }
     }
 
     // next tile's first slab goes in flight now and lands during the epilogue (same problem only: the epilogue
@@ -315,6 +454,11 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
         fetch(0, pa[0], pb[0]);
     }
 
+    GN_TR(2);
+    // (An epilogue straight from the accumulators -- a lane owns one column of each 32 x 32 tile, so a store instruction
+    // would write two full 128-byte row segments with no LDS round trip -- measured 2x SLOWER per tile: 64 dword stores
+    // per lane instead of 16 dwordx4; tools/gemm_trace.py.)
+    {
     // epilogue through LDS: accumulators -> [BM][BN+4] tile -> coalesced float4 rows
     // (lane holds column (lane & 31), rows (r&3) + 8 (r>>2) + 4 (lane>>5) of each 32x32 tile)
 #pragma unroll
@@ -327,6 +471,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
                 smem[row * CP + wn * 32 * TN + j * 32 + (lane & 31)] = acc[i][j][r];
             }
     __syncthreads();
+    GN_TR(3);
     {
         constexpr int C4 = BN / 4;                  // 256 % C4 == 0: a thread keeps ONE column group
         const int cc = (tid % C4) * 4, gn = n0 + cc;
@@ -372,12 +517,19 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
                     const size_t off = (size_t)phys_row(p, gm) * p.ldc + gn;
                     if (p.pre_out) st4(p.pre_out + off, v);
                     if (act) v = silu4(v);
+#if GN_SPLIT_NOSTORE
+                    if (v.x == 123456.f) st4(p.C + off, v);
+#else
                     if (p.nt_store) st4_nt(p.C + off, v); else st4(p.C + off, v);
+#endif
                 }
             }
         }
     }
+    GN_TR(4);
     __syncthreads();                                // LDS is reused by the next tile's first slab
+    }
+    GN_TR(5);
     if (!has_next) break;
     if (!same) {                                    // first tile of the next problem
         select(next);
@@ -386,6 +538,18 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
     }
     idx = next;
   }
+}
+
+template <int TM, int TN, int WM, int WN, bool PRO, int PF>
+__global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
+    gemm_body<TM, TN, WM, WN, PRO, PF, false>(ga);
+}
+
+// 3 x bf16-split instantiation: two workgroups per CU (one wave of each per SIMD: while one is in its epilogue or at a
+// barrier the other feeds the matrix pipe), so the register budget is capped at 256 per lane.
+template <int TM, int TN, int WM, int WN, bool PRO>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_mfma(const GroupArgs ga) {
+    gemm_body<TM, TN, WM, WN, PRO, 1, true>(ga);
 }
 
 }  // namespace gn
@@ -487,16 +651,28 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     long grid = 8L * ((end + 7) / 8);
     const long cap = use_big ? 512 : 1024;
     if (grid > cap) grid = cap;
-#define GN_GEMM_GO(TM_, TN_, PRO_, SPLIT_) \
-    hipLaunchKernelGGL((gn::gemm_f32_mfma<TM_, TN_, PRO_, 1, SPLIT_>), dim3((unsigned)grid), dim3(256), 0, st, ga)
+#define GN_GEMM_GO_S(TM_, TN_, WM_, WN_, PRO_) \
+    hipLaunchKernelGGL((gn::gemm_bf16x3_mfma<TM_, TN_, WM_, WN_, PRO_>), dim3((unsigned)grid), dim3(256), 0, st, ga)
+#define GN_GEMM_GO_F(TM_, TN_, WM_, WN_, PRO_) \
+    hipLaunchKernelGGL((gn::gemm_f32_mfma<TM_, TN_, WM_, WN_, PRO_, 1>), dim3((unsigned)grid), dim3(256), 0, st, ga)
+#ifndef GN_SPLIT_GRID
+#define GN_SPLIT_GRID 14
+#endif
+#if GN_SPLIT_GRID == 14
+#define GN_SPLIT_BIG(PRO_) GN_GEMM_GO_S(4, 1, 1, 4, PRO_)
+#else
+#define GN_SPLIT_BIG(PRO_) GN_GEMM_GO_S(2, 2, 2, 2, PRO_)
+#endif
     if (split) {
-        if (use_big) { if (pro) GN_GEMM_GO(2, 2, true, true); else GN_GEMM_GO(2, 2, false, true); }
-        else { if (pro) GN_GEMM_GO(1, 1, true, true); else GN_GEMM_GO(1, 1, false, true); }
+        if (use_big) { if (pro) GN_SPLIT_BIG(true); else GN_SPLIT_BIG(false); }
+        else { if (pro) GN_GEMM_GO_S(1, 1, 2, 2, true); else GN_GEMM_GO_S(1, 1, 2, 2, false); }
     } else {
-        if (use_big) { if (pro) GN_GEMM_GO(2, 2, true, false); else GN_GEMM_GO(2, 2, false, false); }
-        else { if (pro) GN_GEMM_GO(1, 1, true, false); else GN_GEMM_GO(1, 1, false, false); }
+        if (use_big) { if (pro) GN_GEMM_GO_F(2, 2, 2, 2, true); else GN_GEMM_GO_F(2, 2, 2, 2, false); }
+        else { if (pro) GN_GEMM_GO_F(1, 1, 2, 2, true); else GN_GEMM_GO_F(1, 1, 2, 2, false); }
     }
-#undef GN_GEMM_GO
+#undef GN_SPLIT_BIG
+#undef GN_GEMM_GO_S
+#undef GN_GEMM_GO_F
     GN_LAUNCH_CHECK();
     return GN_OK;
 }

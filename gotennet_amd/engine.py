@@ -101,9 +101,11 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-#: projection arithmetic: "split" = 3 x bf16 split on the bf16 matrix cores (fp32-class error, 2.67x the
-#: fp32 MFMA rate); "f32" = exact fp32 MFMA.  Env GN_GEMM_MODE overrides.
-GEMM_MODE = os.environ.get("GN_GEMM_MODE", "f32")
+#: projection arithmetic: "split" (default) = every fp32 operand as three bf16 planes, six bf16 MFMAs per product,
+#: fp32 accumulate: fp32-class error (<= 1e-6 vs an fp64 product, the same as the exact kernel; every GPU parity test
+#: runs in both modes) at 2.67x the fp32 MFMA rate; "f32" = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf
+#: chain).  Env GN_GEMM_MODE overrides.
+GEMM_MODE = os.environ.get("GN_GEMM_MODE", "split")
 
 
 def split_weight(W: torch.Tensor) -> torch.Tensor:
