@@ -57,13 +57,68 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_ATTN) void attn_softmax_kernel(
     }
 }
 
+// The same two phases for ONE target inside the message kernel (gn_message_fused): scores and the normalised weights
+// stay in LDS (`sc`, deg * H floats; the reduction buffer of the message kernel, idle until its epilogue) when the
+// target's degree fits (`in_lds`), else they go through the global a[] rows of this target like the stand-alone
+// kernel.  The normalised weights are ALSO written to a[] (the force backward and the other degree-group launches read
+// them).  All 256 threads of the workgroup must call it.
+__device__ __forceinline__ void attn_phases(const float* __restrict__ q, const float* __restrict__ k, int ldqk,
+                                            const float* __restrict__ ta, int ldt, const int* __restrict__ src,
+                                            const int* __restrict__ outdeg, int i, int e0, int e1, int F, int H,
+                                            float inv_sqrt_f, float* __restrict__ a, float* sc, bool in_lds) {
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
+    const int lph = lps / H;
+    const float4 qi = ld4(q + (size_t)i * ldqk + c0);
+    for (int e = e0 + slot; e < e1; e += ns) {
+        const float4 kj = ld4(k + (size_t)src[e] * ldqk + c0);
+        float4 te = ld4(ta + (size_t)e * ldt + c0);
+        te = make_float4(silu(te.x), silu(te.y), silu(te.z), silu(te.w));
+        float p = qi.x * kj.x * te.x;
+        p += qi.y * kj.y * te.y;
+        p += qi.z * kj.z * te.z;
+        p += qi.w * kj.w * te.w;
+        p = group_sum(p, lph);
+        if ((lp & (lph - 1)) == 0) {
+            if (in_lds) sc[(e - e0) * H + lp / lph] = p; else a[(size_t)e * H + lp / lph] = p;
+        }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int h = wave; h < H; h += 4) {
+        float mx = -INFINITY;
+        for (int e = e0 + lane; e < e1; e += 64) mx = fmaxf(mx, in_lds ? sc[(e - e0) * H + h] : a[(size_t)e * H + h]);
+        mx = wave_max(mx);
+        float sm = 0.f;
+        for (int e = e0 + lane; e < e1; e += 64) {
+            const float ex = expf((in_lds ? sc[(e - e0) * H + h] : a[(size_t)e * H + h]) - mx);
+            if (in_lds) sc[(e - e0) * H + h] = ex; else a[(size_t)e * H + h] = ex;
+            sm += ex;
+        }
+        sm = wave_sum(sm) + 1e-16f;
+        for (int e = e0 + lane; e < e1; e += 64) {
+            const float nrm = outdeg ? sqrtf((float)outdeg[src[e]]) * inv_sqrt_f : inv_sqrt_f;
+            const float w = (in_lds ? sc[(e - e0) * H + h] : a[(size_t)e * H + h]) / sm * nrm;
+            if (in_lds) sc[(e - e0) * H + h] = w;
+            a[(size_t)e * H + h] = w;
+        }
+    }
+    __syncthreads();
+}
+
+// q / k / t_attn / outdeg of the fused form (null q = the attention weights were computed by an earlier launch)
+struct AttnIn {
+    const float* q; const float* k; int ldqk;
+    const float* ta; const int* outdeg; float inv_sqrt_f;
+};
+
 // ------------------------------------------------------------------ K6 message + aggregate (lmax <= 2: one launch)
 // M F-wide blocks of the value vector: 0 = scalar; direction gate of degree l: block
 // (SEP_DIR ? l : 1); tensor gate: block TB0 + (SEP_TENSOR ? l-1 : 0), TB0 = 1 + (SEP_DIR ? LMAX : 1).
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, bool FUSE>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
     const float* __restrict__ x, const float* __restrict__ v, int ldxv,
-    const float* __restrict__ tf, int ldt, const float* __restrict__ a,
+    const float* __restrict__ tf, int ldt, float* a, const AttnIn at,
     const float* __restrict__ rl, const float* __restrict__ cut,
     const int* __restrict__ rowptr, const int* __restrict__ src,
     const float* __restrict__ h_in, const float* __restrict__ X_in,
@@ -82,6 +137,9 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
     const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
     const int per_head = (M * F) / H;
+    // FUSE: attention scores + segment softmax of this target first (gotennet.py:497-511); the weights then come from LDS
+    const bool a_lds = FUSE && (e1 - e0) * H <= CH * 1024;
+    if constexpr (FUSE) attn_phases(at.q, at.k, at.ldqk, at.ta, ldt, src, at.outdeg, i, e0, e1, F, H, at.inv_sqrt_f, a, red, a_lds);
 
     int hb[M];
 #pragma unroll
@@ -98,6 +156,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
         const float* vr = v + (size_t)j * ldxv + c0;
         const float* tr = tf + (size_t)e * ldt + c0;
         const float* ar = a + (size_t)e * H;
+        const float* al = red + (e - e0) * H;      // FUSE: this edge's weights in LDS
         const float* Xj = X_in + (size_t)j * D * F + c0;
         const float* re = rl + (size_t)e * D;
         float4 o[M];
@@ -105,7 +164,8 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
         for (int b = 0; b < M; ++b) {
             // gotennet.py:516-529: (t_filter * x_j) * cutoff + attn * v_j
             const float4 sp = (ld4_nt(tr + b * F) * ld4(xr + b * F)) * ce;
-            o[b] = fma4(ar[hb[b]], ld4(vr + b * F), sp);
+            const float ab = (FUSE && a_lds) ? al[hb[b]] : ar[hb[b]];
+            o[b] = fma4(ab, ld4(vr + b * F), sp);
         }
         acc[0] = acc[0] + o[0];
         int m = 0;
@@ -122,6 +182,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
     }
 
     // fixed-order reduction over slots, CH rows per pass; slot s finishes rows s, s+ns, ...
+    if constexpr (FUSE) __syncthreads();            // `red` held the attention weights until every slot left the edge loop
 #pragma unroll
     for (int base = 0; base < ROWS; base += CH) {
         if (base) __syncthreads();
@@ -150,10 +211,10 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
 // (1 + D) accumulator rows are cut into degree groups {scalar,1,2}, {3}, {4} so that every launch
 // keeps <= 9 float4 accumulators per lane (3+ waves/SIMD instead of 2 at 246 VGPRs).  Gates are
 // per degree, so the groups re-read nothing but the per-edge scalars.
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR>
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR, bool FUSE>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G) void message_aggregate_group_kernel(
     const float* __restrict__ x, const float* __restrict__ v, int ldxv,
-    const float* __restrict__ tf, int ldt, const float* __restrict__ a,
+    const float* __restrict__ tf, int ldt, float* a, const AttnIn at,
     const float* __restrict__ rl, const float* __restrict__ cut,
     const int* __restrict__ rowptr, const int* __restrict__ src,
     const float* __restrict__ h_in, const float* __restrict__ X_in,
@@ -165,7 +226,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G) void message_aggregate_group
     constexpr int XROWS = (LHI + 1) * (LHI + 1) - LLO * LLO;     // rows of degrees LLO..LHI
     constexpr int ROWS = (SCALAR ? 1 : 0) + XROWS;
     constexpr int M0 = LLO * LLO - 1;                             // first X row of the group
-    constexpr int CH = ROWS < 9 ? ROWS : 9;                       // rows reduced per LDS pass (<= 36 KiB)
+    constexpr int CH = ROWS < GN_K6G_CH ? ROWS : GN_K6G_CH;       // rows reduced per LDS pass (4 KiB each)
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
 
     const int i = xcd_item(blockIdx.x, N);
@@ -174,6 +235,9 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G) void message_aggregate_group
     const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
     const int per_head = (M * F) / H;
+    // FUSE (the first degree group): attention weights of this target, kept in LDS and written to a[] for the other groups
+    const bool a_lds = FUSE && (e1 - e0) * H <= CH * 1024;
+    if constexpr (FUSE) attn_phases(at.q, at.k, at.ldqk, at.ta, ldt, src, at.outdeg, i, e0, e1, F, H, at.inv_sqrt_f, a, red, a_lds);
 
     int hb[M];                                      // attention head of this lane's channels in block b
 #pragma unroll
@@ -190,12 +254,14 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G) void message_aggregate_group
         const float* vr = v + (size_t)j * ldxv + c0;
         const float* tr = tf + (size_t)e * ldt + c0;
         const float* ar = a + (size_t)e * H;
+        const float* al = red + (e - e0) * H;      // FUSE: this edge's weights in LDS
         const float* Xj = X_in + (size_t)j * D * F + c0;
         const float* re = rl + (size_t)e * D;
         // gotennet.py:516-529: (t_filter * x_j) * cutoff + attn * v_j, block b of the value vector
         auto gate = [&](int b) {
             const float4 sp = (ld4_nt(tr + b * F) * ld4(xr + b * F)) * ce;
-            return fma4(ar[hb[b]], ld4(vr + b * F), sp);
+            const float ab = (FUSE && a_lds) ? al[hb[b]] : ar[hb[b]];
+            return fma4(ab, ld4(vr + b * F), sp);
         };
         // all gate loads first (independent, issued back to back), then the X_j rows
         constexpr int NL = LHI - LLO + 1;
@@ -219,6 +285,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G) void message_aggregate_group
     }
 
     // fixed-order reduction over slots, CH rows per pass; slot s finishes rows s, s+ns, ...
+    if constexpr (FUSE) __syncthreads();            // `red` held the attention weights until every slot left the edge loop
 #pragma unroll
     for (int base = 0; base < ROWS; base += CH) {
         if (base) __syncthreads();
@@ -303,30 +370,31 @@ extern "C" int gn_attn_softmax(const float* q, const float* k, int ldqk, const f
     return GN_OK;
 }
 
-#define GN_MSG_ONE(L, SD, ST, LLO, LHI, SC)                                                                 \
-    hipLaunchKernelGGL((gn::message_aggregate_group_kernel<L, SD, ST, LLO, LHI, SC>), dim3(gn::xcd_grid(N)), dim3(256), \
-                       0, (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in,  \
+#define GN_MSG_ONE(L, SD, ST, LLO, LHI, SC, FU)                                                                 \
+    hipLaunchKernelGGL((gn::message_aggregate_group_kernel<L, SD, ST, LLO, LHI, SC, FU>), dim3(gn::xcd_grid(N)), dim3(256), \
+                       0, (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, at, rl, cut, rowptr, src, h_in, X_in,  \
                        h_out, X_out, N, F, H)
-// degree groups per lmax: {scalar,1..min(lmax,2)}, {3}, {4}
-#define GN_MSG_MONO(L, SD, ST)                                                                              \
-    hipLaunchKernelGGL((gn::message_aggregate_kernel<L, SD, ST>), dim3(gn::xcd_grid(N)), dim3(256), 0,         \
-                       (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in,    \
+// degree groups per lmax: {scalar,1..min(lmax,2)}, {3}, {4}; the attention phases ride in the first launch
+#define GN_MSG_MONO(L, SD, ST, FU)                                                                          \
+    hipLaunchKernelGGL((gn::message_aggregate_kernel<L, SD, ST, FU>), dim3(gn::xcd_grid(N)), dim3(256), 0,     \
+                       (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, at, rl, cut, rowptr, src, h_in, X_in, \
                        h_out, X_out, N, F, H)
-#define GN_MSG_LAUNCH(L, SD, ST)                                      \
-    do {                                                              \
-        if constexpr (L <= 2) { GN_MSG_MONO(L, SD, ST); }             \
-        else {                                                        \
-            GN_MSG_ONE(L, SD, ST, 1, 2, true);                        \
-            GN_MSG_ONE(L, SD, ST, 3, 3, false);                       \
-            if constexpr (L >= 4) { GN_MSG_ONE(L, SD, ST, 4, 4, false); } \
-        }                                                             \
+#define GN_MSG_LAUNCH_F(L, SD, ST, FU)                                    \
+    do {                                                                  \
+        if constexpr (L <= 2) { GN_MSG_MONO(L, SD, ST, FU); }             \
+        else {                                                            \
+            GN_MSG_ONE(L, SD, ST, 1, 2, true, FU);                        \
+            GN_MSG_ONE(L, SD, ST, 3, 3, false, false);                    \
+            if constexpr (L >= 4) { GN_MSG_ONE(L, SD, ST, 4, 4, false, false); } \
+        }                                                                 \
     } while (0)
+#define GN_MSG_LAUNCH(L, SD, ST) \
+    do { if (fuse) GN_MSG_LAUNCH_F(L, SD, ST, true); else GN_MSG_LAUNCH_F(L, SD, ST, false); } while (0)
 
-extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, const float* t_filter, int ldt,
-                                    const float* a, const float* rl, const float* cut,
-                                    const int* rowptr, const int* src,
-                                    const float* h_in, const float* X_in, float* h_out, float* X_out,
-                                    int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream) {
+static int message_launch(const float* x, const float* v, int ldxv, const float* t_filter, int ldt, float* a,
+                          gn::AttnIn at, bool fuse, const float* rl, const float* cut, const int* rowptr, const int* src,
+                          const float* h_in, const float* X_in, float* h_out, float* X_out,
+                          int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream) {
     if (!feature_dim_ok(F) || N < 0 || H <= 0 || lmax < 1 || lmax > 4 || (ldxv & 3) || (ldt & 3) || X_in == X_out)
         return GN_ERR_BAD_ARG;
     const int M = 1 + (sep_dir ? lmax : 1) + (sep_tensor ? lmax : 1);
@@ -350,6 +418,27 @@ extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, co
     }
     GN_LAUNCH_CHECK();
     return GN_OK;
+}
+
+extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, const float* t_filter, int ldt,
+                                    const float* a, const float* rl, const float* cut,
+                                    const int* rowptr, const int* src,
+                                    const float* h_in, const float* X_in, float* h_out, float* X_out,
+                                    int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream) {
+    return message_launch(x, v, ldxv, t_filter, ldt, const_cast<float*>(a), gn::AttnIn{}, false, rl, cut, rowptr, src,
+                          h_in, X_in, h_out, X_out, N, F, H, lmax, sep_dir, sep_tensor, stream);
+}
+
+extern "C" int gn_message_fused(const float* q, const float* k, int ldqk, const float* eproj, int ldt,
+                                const int* outdeg, const float* x, const float* v, int ldxv, float* a,
+                                const float* rl, const float* cut, const int* rowptr, const int* src,
+                                const float* h_in, const float* X_in, float* h_out, float* X_out,
+                                int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream) {
+    if (!feature_dim_ok(F) || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || (F / 4) / H > 64 || (ldqk & 3) || !a)
+        return GN_ERR_BAD_ARG;
+    const gn::AttnIn at{q, k, ldqk, eproj, outdeg, (float)(1.0 / sqrt((double)F))};
+    return message_launch(x, v, ldxv, eproj + F, ldt, a, at, true, rl, cut, rowptr, src, h_in, X_in, h_out, X_out,
+                          N, F, H, lmax, sep_dir, sep_tensor, stream);
 }
 
 extern "C" int gn_htr_edge(const float* EQ, const float* EK, const float* rl, const int* rowptr, const int* src,

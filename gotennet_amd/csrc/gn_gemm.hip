@@ -35,6 +35,12 @@
 #ifndef GN_SPLIT_NOSTORE
 #define GN_SPLIT_NOSTORE 0     // probe only: skip the global stores of the epilogue
 #endif
+#ifndef GN_SPLIT_ABL
+#define GN_SPLIT_ABL 0         // probe builds only (wrong results): 1 no weight loads, 2 one A fragment address, 4 no split/stash,
+#endif                         // 8 no A fetch, 16 no barrier in the K loop -- what each part of the split main loop costs
+#ifndef GN_SPLIT_MINW
+#define GN_SPLIT_MINW 2        // minimum waves per SIMD of the split kernel (register cap 512 / n)
+#endif
 #ifndef GN_SPLIT_SCHED
 #define GN_SPLIT_SCHED 0       // > 0: sched_group_barrier pattern [1 MFMA, n VALU] in the split main loop (tools/variants.py)
 #endif
@@ -359,17 +365,17 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
             auto slab = [&](int kt, auto SET, auto LAST) {
                 constexpr int set = decltype(SET)::value;            // register set of slab kt (= kt & 1)
                 constexpr bool last = decltype(LAST)::value;
-                const __bf16* Ap = Abase + set * STAGE_S;
-                load_b(2 * kt + 1, bq[1]);
-                if constexpr (!last) fetchA((kt + 2) * BK, qa2[set], kok2[set]);    // slab kt + 2 -> the set slab kt came from
+                const __bf16* Ap = Abase + ((GN_SPLIT_ABL & 2) ? 0 : set * STAGE_S);
+                if (!(GN_SPLIT_ABL & 1)) load_b(2 * kt + 1, bq[1]);
+                if constexpr (!last) { if (!(GN_SPLIT_ABL & 8)) fetchA((kt + 2) * BK, qa2[set], kok2[set]); }   // slab kt + 2 -> the set slab kt came from
                 __builtin_amdgcn_sched_barrier(0);
                 kstep(Ap, 0, bq[0]);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!last) load_b(2 * kt + 2, bq[0]);
-                kstep(Ap, 1, bq[1]);
+                if constexpr (!last) { if (!(GN_SPLIT_ABL & 1)) load_b(2 * kt + 2, bq[0]); }
+                kstep(Ap, (GN_SPLIT_ABL & 2) ? 0 : 1, bq[(GN_SPLIT_ABL & 1) ? 0 : 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!last) stashA(set ^ 1, qa2[set ^ 1], kok2[set ^ 1]);  // slab kt + 1 -> the other LDS buffer
-                __syncthreads();
+                if constexpr (!last) { if (!(GN_SPLIT_ABL & 4)) stashA(set ^ 1, qa2[set ^ 1], kok2[set ^ 1]); }  // slab kt + 1 -> the other LDS buffer
+                if (!(GN_SPLIT_ABL & 16) || last) __syncthreads();
             };
             using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>;
             using No = std::false_type; using Yes = std::true_type;
@@ -548,7 +554,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
 // 3 x bf16-split instantiation: two workgroups per CU (one wave of each per SIMD: while one is in its epilogue or at a
 // barrier the other feeds the matrix pipe), so the register budget is capped at 256 per lane.
 template <int TM, int TN, int WM, int WN, bool PRO>
-__global__ __launch_bounds__(256, 2) void gemm_bf16x3_mfma(const GroupArgs ga) {
+__global__ __launch_bounds__(256, GN_SPLIT_MINW) void gemm_bf16x3_mfma(const GroupArgs ga) {
     gemm_body<TM, TN, WM, WN, PRO, 1, true>(ga);
 }
 
@@ -614,6 +620,16 @@ extern "C" int gn_gemm_group_split(const gn_gemm_desc* d, int n, void* stream) {
 
 // one launch for n <= GN_MAX_GROUP problems (validated by the callers)
 int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
+#ifndef GN_SPLIT_GRID
+#define GN_SPLIT_GRID 14
+#endif
+#if GN_SPLIT_GRID == 12            // 64 x 128 tile, waves 1 x 4 of 2 x 1 MFMA tiles: ~130 registers, three workgroups per CU
+    const int BMB = split ? 64 : 128, BNB = 128;
+    const long cap_big = split ? 768 : 512;
+#else
+    const int BMB = 128, BNB = 128;
+    const long cap_big = 512;
+#endif
     gn::GroupArgs ga;
     long big = 0, small = 0;
     bool pro = false;
@@ -634,7 +650,7 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     for (int i = 0; i < gn::GN_MAX_GROUP; ++i) {
         ga.g[i] = g[i < n ? i : n - 1];
         ga.g[i].nt_store = (double)ga.g[i].M * ga.g[i].N * 4.0 >= nt_min;
-        if (i < n) end += use_big ? (long)((g[i].M + 127) / 128) * ((g[i].N + 127) / 128)
+        if (i < n) end += use_big ? (long)((g[i].M + BMB - 1) / BMB) * ((g[i].N + BNB - 1) / BNB)
                                   : (long)((g[i].M + 63) / 64) * ((g[i].N + 63) / 64);
         ga.tile_end[i] = (int)end;
     }
@@ -649,17 +665,16 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     if (end == 0) return GN_OK;
     // persistent launch: at most 2 (big tiles) / 4 (small tiles) workgroups per CU walk the tile list (+2 %)
     long grid = 8L * ((end + 7) / 8);
-    const long cap = use_big ? 512 : 1024;
+    const long cap = use_big ? cap_big : 1024;
     if (grid > cap) grid = cap;
 #define GN_GEMM_GO_S(TM_, TN_, WM_, WN_, PRO_) \
     hipLaunchKernelGGL((gn::gemm_bf16x3_mfma<TM_, TN_, WM_, WN_, PRO_>), dim3((unsigned)grid), dim3(256), 0, st, ga)
 #define GN_GEMM_GO_F(TM_, TN_, WM_, WN_, PRO_) \
     hipLaunchKernelGGL((gn::gemm_f32_mfma<TM_, TN_, WM_, WN_, PRO_, 1>), dim3((unsigned)grid), dim3(256), 0, st, ga)
-#ifndef GN_SPLIT_GRID
-#define GN_SPLIT_GRID 14
-#endif
 #if GN_SPLIT_GRID == 14
 #define GN_SPLIT_BIG(PRO_) GN_GEMM_GO_S(4, 1, 1, 4, PRO_)
+#elif GN_SPLIT_GRID == 12
+#define GN_SPLIT_BIG(PRO_) GN_GEMM_GO_S(2, 1, 1, 4, PRO_)
 #else
 #define GN_SPLIT_BIG(PRO_) GN_GEMM_GO_S(2, 2, 2, 2, PRO_)
 #endif

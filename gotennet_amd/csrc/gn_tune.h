@@ -44,6 +44,10 @@
 #define GN_W_ATTN 0        // 2: 29 -> 55 us; 4: 37 us
 #endif
 
+#ifndef GN_K6G_CH
+#define GN_K6G_CH 9        // message_aggregate_group_kernel: accumulator rows reduced per LDS pass (4 KiB per row)
+#endif
+
 #define GN_TUNE_CAT_(a, b) a##b
 #define GN_TUNE_CAT(a, b) GN_TUNE_CAT_(a, b)
 #define GN_WPE_SEL_0

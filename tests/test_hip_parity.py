@@ -279,3 +279,46 @@ def test_softmax_high_degree():
     h, X = net(z.cuda(), ei.cuda(), w.cuda(), vec.cuda())
     assert rel_err(h.cpu(), h_ref) < TOL
     assert rel_err(X.cpu(), X_ref) < TOL
+
+
+@pytest.mark.parametrize("name", ["l2_sep_f32", "l3_sep_scale_f32", "l4_sep_f32", "l1_nosep_scale_f32"])
+def test_fused_attention_launch_is_bit_identical(name):
+    """gn_message_fused (opt-in: scores + segment softmax inside the message kernel, weights in LDS) against the
+    default two-launch form: same arithmetic in the same order -> bit-identical (h, X) and golden parity."""
+    from gotennet_amd import engine
+    cfg, sd, _, t = load_case(name)
+    net = _net_from_case(cfg, sd)
+    args = (t["z"].cuda(), t["edge_index"].cuda(), t["edge_diff"].cuda(), t["edge_vec"].cuda())
+    h0, X0 = net(*args)
+    engine.FUSE_ATTENTION = True
+    try:
+        h1, X1 = net(*args)
+    finally:
+        engine.FUSE_ATTENTION = False
+    assert torch.equal(h0, h1) and torch.equal(X0, X1)
+    assert rel_err(h1.cpu(), t["h"]) < TOL and rel_err(X1.cpu(), t["X"]) < TOL
+
+
+def test_fused_attention_high_degree_spills_to_global():
+    """A 600-edge target at lmax = 1: deg * H exceeds the LDS reduction buffer, the weights go through global memory."""
+    import gotennet_amd
+    from gotennet_amd import engine
+    torch.manual_seed(5)
+    net = gotennet_amd.GotenNet(n_atom_basis=64, n_interactions=2, n_rbf=16, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
+                                num_heads=8, scale_edge=True, lmax=1).cuda().eval()
+    n = 600
+    g = torch.Generator().manual_seed(2)
+    pos = torch.rand((n, 3), generator=g) * 2.5
+    z = torch.randint(1, 9, (n,), generator=g)
+    src = torch.cat([torch.arange(0, n), torch.arange(1, n)])
+    dst = torch.cat([torch.zeros(n, dtype=torch.long), torch.arange(1, n)])
+    vec = pos[src] - pos[dst]
+    w = torch.where(src != dst, vec.norm(dim=1), torch.zeros(src.numel()))
+    args = (z.cuda(), torch.stack([src, dst]).cuda(), w.cuda(), vec.cuda())
+    h0, X0 = net(*args)
+    engine.FUSE_ATTENTION = True
+    try:
+        h1, X1 = net(*args)
+    finally:
+        engine.FUSE_ATTENTION = False
+    assert torch.equal(h0, h1) and torch.equal(X0, X1)
