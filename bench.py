@@ -375,18 +375,25 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
                 big = (tag, tot[tag], us, fl / (us * 1e-6) / 1e12)
         ach = flops / (t_ms * 1e-3) / 1e12
         exact = _engine_mode() == "f32"
-        return dict(kernel="gn::gemm_f32_mfma (all projection launches, exact fp32 MFMA)" if exact else
-                    "gn::gemm_bf16x3_mfma (all projection launches, 3xbf16-split MFMA: 6 bf16 MFMAs per fp32 product)",
-                    bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                    frac=round(ach / MFMA_F32_PEAK_TF, 4),
-                    peak_note="achieved = ALGORITHMIC fp32 flops / time; peak = the fp32 MFMA peak (157.3 TF)" +
-                    ("" if exact else "; the split kernel EXECUTES 6x these flops on the bf16 matrix cores "
-                     f"(dense bf16 peak {MFMA_BF16_PEAK_TF} TF): executed/bf16-peak = {round(6 * ach / MFMA_BF16_PEAK_TF, 4)}"),
-                    traffic=_pmc_traffic("gn_gemm_family_avg", lmax, workload),
-                    us_per_launch=round(1e3 * t_ms / n, 2), launches_per_step=n // dom_steps,
-                    algorithmic_flops_per_step=flops / dom_steps,
-                    largest_launch=dict(shape_MxNxK=big[0][8:-1], us=round(big[2], 2), tflops=round(big[3], 2),
-                                        frac=round(big[3] / MFMA_F32_PEAK_TF, 4)))
+        common = dict(traffic=_pmc_traffic("gn_gemm_family_avg", lmax, workload),
+                      us_per_launch=round(1e3 * t_ms / n, 2), launches_per_step=n // dom_steps,
+                      algorithmic_flops_per_step=flops / dom_steps)
+        if exact:
+            return dict(kernel="gn::gemm_f32_mfma (all projection launches, exact fp32 MFMA)", bound="mfma",
+                        achieved=round(ach, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TF, 4),
+                        **common,
+                        largest_launch=dict(shape_MxNxK=big[0][8:-1], us=round(big[2], 2), tflops=round(big[3], 2),
+                                            frac=round(big[3] / MFMA_F32_PEAK_TF, 4)))
+        # 3 x bf16-split: the kernel EXECUTES six bf16 MFMA flops per algorithmic fp32 flop, so it is priced against
+        # the dense bf16 matrix peak: achieved = 6 x algorithmic flops / time
+        return dict(kernel="gn::gemm_bf16x3_mfma (all projection launches; every fp32 product as 6 bf16 MFMAs, fp32 accumulate)",
+                    bound="mfma", achieved=round(6 * ach, 1), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
+                    frac=round(6 * ach / MFMA_BF16_PEAK_TF, 4),
+                    note="achieved = EXECUTED bf16 MFMA flops (6 x algorithmic) / summed launch time; peak = dense bf16 MFMA",
+                    algorithmic_tflops=round(ach, 2), algorithmic_vs_fp32_mfma_peak=round(ach / MFMA_F32_PEAK_TF, 4),
+                    **common,
+                    largest_launch=dict(shape_MxNxK=big[0][8:-1], us=round(big[2], 2), executed_tflops=round(6 * big[3], 1),
+                                        frac=round(6 * big[3] / MFMA_BF16_PEAK_TF, 4), algorithmic_tflops=round(big[3], 2)))
 
     def roof_message():
         """GATA message STAGE: SURVEY 8d B_msg over the summed duration of the stage's launches (one fused launch,

@@ -66,3 +66,36 @@ def test_two_rank_energy_allreduce_matches_single_process():
     for rank, first, count, e_all in res:
         assert e_all.shape == (total,)
         assert torch.allclose(e_all, e_ref, rtol=1e-5, atol=1e-6)   # molecules are independent units
+
+
+def _bench_selftest(gpus, batch):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--selftest-dist",
+                          "--batch", str(batch), "--steps", "3", "--workload", "qm9_small"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                      # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_one_rank_per_gpu():
+    """`python bench.py --gpus 2` with no launcher: bench.py spawns the ranks itself (torch.multiprocessing.spawn), they
+    rendezvous on 127.0.0.1, shard the molecules, all-reduce the zero-padded per-molecule vector and rank 0 prints one
+    JSON line.  (--selftest-dist: gloo, the step replaced by a checksum of the synthetic inputs; no kernel runs.)"""
+    from gotennet_amd import synthetic
+    B = 3
+    two = _bench_selftest(2, B)
+    assert two["n_ranks_seen"] == 2 and two["global_batch"] == 2 * B and two["energy_vector_len"] == 2 * B
+    assert two["shards_consistent"] is True
+    one = _bench_selftest(1, B)
+    assert one["n_ranks_seen"] == 1 and one["energy_vector_len"] == B
+    # rank r owns molecules [B r, B (r + 1)): the 2-rank vector is the first 2B molecules of the workload
+    pos, batch, z = synthetic.make_batch("qm9_small", 2 * B, seed=0)
+    val = torch.zeros(2 * B, dtype=torch.float64).index_add_(0, batch, z.double() * (pos.double() ** 2).sum(1)).float()
+    assert abs(two["energy_checksum"] - float(val.double().sum())) < 1e-3 * abs(float(val.double().sum()))
+    assert abs(one["energy_checksum"] - float(val[:B].double().sum())) < 1e-3 * abs(float(val[:B].double().sum()))
