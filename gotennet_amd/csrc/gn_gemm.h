@@ -76,3 +76,7 @@ __device__ __forceinline__ float4 dsilu4(float4 v) { return make_float4(dsilu(v.
 // launcher for a group of n <= GN_MAX_GROUP problems (gn_gemm.hip).  split = 0: exact fp32 MFMA, W = fp32 [N][K];
 // split = 1: 3 x bf16-split MFMA, W = the fragment-major bf16 planes written by gn_split_bf16x3
 int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split);
+
+// wave-specialised split kernel (gn_gemm_ws.hip): eligibility of a group and its launch (ga as built by gn_gemm_launch)
+bool gn_gemm_ws_eligible(const gn::GemmArgs* g, int n);
+int gn_gemm_ws_launch(const gn::GroupArgs& ga, long tiles, hipStream_t st);

@@ -322,3 +322,48 @@ def test_fused_attention_high_degree_spills_to_global():
     finally:
         engine.FUSE_ATTENTION = False
     assert torch.equal(h0, h1) and torch.equal(X0, X1)
+
+
+def test_wave_specialised_gemm_opt_in():
+    """GN_GEMM_WS=1 (read once per process by the launcher): the wave-specialised split kernel must reproduce the
+    default kernel bit for bit on the edge-sized products (same term order), with riders and every epilogue kind."""
+    import os
+    import subprocess
+    import sys
+    from gotennet_amd import engine
+    if engine.GEMM_MODE != "split":
+        pytest.skip("the wave-specialised kernel exists for the split arithmetic only")
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from gotennet_amd import engine
+engine.GEMM_MODE = "split"
+torch.manual_seed(0)
+dev = "cuda"
+r = lambda *s: torch.randn(*s, device=dev)
+E, N, F = 5000, 300, 256
+t, h, w = r(E, F), r(N, F), r(E, F)
+We, be, Wn, bn, Wt, bt = r(6 * F, F) / 16, r(6 * F), r(4 * F, F) / 16, r(4 * F), r(F, F) / 16, r(F)
+ep, na, pre, t2 = (torch.empty(E, 6 * F, device=dev), torch.empty(N, 4 * F, device=dev), torch.empty(N, 4 * F, device=dev),
+                   torch.empty(E, F, device=dev))
+engine.gemm_group([dict(A=t, lda=F, W=We, bias=be, C=ep, ldc=6 * F, rows=E, nout=6 * F, K=F),
+                   dict(A=h, lda=F, W=Wn, bias=bn, C=na, ldc=4 * F, rows=N, nout=4 * F, K=F, act=(2 * F, 4 * F), pre_out=pre)])
+engine.gemm_group([dict(A=t, lda=F, W=Wt, bias=bt, C=t2, ldc=F, rows=E, nout=F, K=F, act=(0, F), res=t, gate=w)])
+g, WeT, gin, gout = r(E, 6 * F), r(F, 6 * F) / 40, r(E, F), torch.empty(E, F, device=dev)
+gx, WsT, gnp = r(N, 5 * F), r(F, 5 * F) / 36, torch.zeros(N, 4 * F, device=dev)
+engine.gemm_group([dict(A=g, lda=6 * F, W=WeT, C=gout, ldc=F, rows=E, nout=F, K=6 * F, res=gin),
+                   dict(A=gx, lda=5 * F, W=WsT, C=gnp, ldc=4 * F, rows=N, nout=F, K=5 * F, c_off=2 * F, dgate=pre, g_off=2 * F)])
+torch.cuda.synchronize()
+torch.save([v.cpu() for v in (ep, na, pre, t2, gout, gnp)], sys.argv[1])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for ws in ("0", "1"):
+            path = os.path.join(td, f"ws{ws}.pt")
+            env = dict(os.environ, GN_GEMM_WS=ws)
+            res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
+            assert res.returncode == 0, res.stderr[-2000:]
+            outs[ws] = torch.load(path)
+    for a, b in zip(outs["0"], outs["1"]):
+        assert torch.equal(a, b)
