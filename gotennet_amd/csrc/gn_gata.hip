@@ -13,52 +13,8 @@
 namespace gn {
 
 // ------------------------------------------------------------------ attention weights
-// reference gotennet.py:497-511 + PyG softmax.  a[e,h] holds raw scores between the two phases.
-__global__ __launch_bounds__(256) GN_WPE(GN_W_ATTN) void attn_softmax_kernel(
-    const float* __restrict__ q, const float* __restrict__ k, int ldqk,
-    const float* __restrict__ ta, int ldt,
-    const int* __restrict__ rowptr, const int* __restrict__ src, const int* __restrict__ outdeg,
-    int N, int F, int H, float inv_sqrt_f, float* __restrict__ a) {
-    const int i = xcd_item(blockIdx.x, N);
-    if (i < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
-    const int lph = lps / H;                       // lanes per head (power of two, >= 1)
-    const int e0 = rowptr[i], e1 = rowptr[i + 1];
-    const float4 qi = ld4(q + (size_t)i * ldqk + c0);
-    for (int e = e0 + slot; e < e1; e += ns) {
-        const float4 kj = ld4(k + (size_t)src[e] * ldqk + c0);
-        float4 te = ld4(ta + (size_t)e * ldt + c0);          // stored pre-activation: t_attn = SiLU(.)
-        te = make_float4(silu(te.x), silu(te.y), silu(te.z), silu(te.w));
-        float p = qi.x * kj.x * te.x;
-        p += qi.y * kj.y * te.y;
-        p += qi.z * kj.z * te.z;
-        p += qi.w * kj.w * te.w;
-        p = group_sum(p, lph);
-        if ((lp & (lph - 1)) == 0) a[(size_t)e * H + lp / lph] = p;
-    }
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int h = wave; h < H; h += 4) {
-        float mx = -INFINITY;
-        for (int e = e0 + lane; e < e1; e += 64) mx = fmaxf(mx, a[(size_t)e * H + h]);
-        mx = wave_max(mx);
-        float sm = 0.f;
-        for (int e = e0 + lane; e < e1; e += 64) {
-            const float ex = expf(a[(size_t)e * H + h] - mx);
-            a[(size_t)e * H + h] = ex;
-            sm += ex;
-        }
-        sm = wave_sum(sm) + 1e-16f;
-        for (int e = e0 + lane; e < e1; e += 64) {
-            const float nrm = outdeg ? sqrtf((float)outdeg[src[e]]) * inv_sqrt_f : inv_sqrt_f;
-            a[(size_t)e * H + h] = a[(size_t)e * H + h] / sm * nrm;
-        }
-    }
-}
-
-// The same two phases for ONE target inside the message kernel (gn_message_fused): scores and the normalised weights
-// stay in LDS (`sc`, deg * H floats; the reduction buffer of the message kernel, idle until its epilogue) when the
+// The two attention phases for ONE target (also used inside the message kernel, gn_message_fused): scores and the
+// normalised weights stay in LDS (`sc`, deg * H floats; the reduction buffer of the message kernel, idle until its epilogue) when the
 // target's degree fits (`in_lds`), else they go through the global a[] rows of this target like the stand-alone
 // kernel.  The normalised weights are ALSO written to a[] (the force backward and the other degree-group launches read
 // them).  All 256 threads of the workgroup must call it.
@@ -104,6 +60,20 @@ __device__ __forceinline__ void attn_phases(const float* __restrict__ q, const f
         }
     }
     __syncthreads();
+}
+
+// reference gotennet.py:497-511 + PyG softmax.  Scores and weights of a target stay in LDS between the phases (up to
+// 512 incoming edges at H = 8; longer rows go through their a[] entries in global memory).
+__global__ __launch_bounds__(256) GN_WPE(GN_W_ATTN) void attn_softmax_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, int ldqk,
+    const float* __restrict__ ta, int ldt,
+    const int* __restrict__ rowptr, const int* __restrict__ src, const int* __restrict__ outdeg,
+    int N, int F, int H, float inv_sqrt_f, float* a) {
+    __shared__ float sc[GN_ATTN_LDS];
+    const int i = xcd_item(blockIdx.x, N);
+    if (i < 0) return;
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    attn_phases(q, k, ldqk, ta, ldt, src, outdeg, i, e0, e1, F, H, inv_sqrt_f, a, sc, (e1 - e0) * H <= GN_ATTN_LDS);
 }
 
 // q / k / t_attn / outdeg of the fused form (null q = the attention weights were computed by an earlier launch)
@@ -212,7 +182,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
 // keeps <= 9 float4 accumulators per lane (3+ waves/SIMD instead of 2 at 246 VGPRs).  Gates are
 // per degree, so the groups re-read nothing but the per-edge scalars.
 template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR, bool FUSE>
-__global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G) void message_aggregate_group_kernel(
+__device__ __forceinline__ void message_aggregate_group_body(
     const float* __restrict__ x, const float* __restrict__ v, int ldxv,
     const float* __restrict__ tf, int ldt, float* a, const AttnIn at,
     const float* __restrict__ rl, const float* __restrict__ cut,
@@ -306,6 +276,22 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G) void message_aggregate_group
     }
 }
 
+#define GN_MSG_GROUP_ARGS                                                                                   \
+    const float *__restrict__ x, const float *__restrict__ v, int ldxv, const float *__restrict__ tf, int ldt, float *a, \
+        const AttnIn at, const float *__restrict__ rl, const float *__restrict__ cut, const int *__restrict__ rowptr,    \
+        const int *__restrict__ src, const float *__restrict__ h_in, const float *__restrict__ X_in,                     \
+        float *__restrict__ h_out, float *__restrict__ X_out, int N, int F, int H
+#define GN_MSG_GROUP_PASS x, v, ldxv, tf, ldt, a, at, rl, cut, rowptr, src, h_in, X_in, h_out, X_out, N, F, H
+// one degree group per launch; the two-degree group {3,4} (16 accumulator rows) gets its own occupancy target
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR, bool FUSE>
+__global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G) void message_aggregate_group_kernel(GN_MSG_GROUP_ARGS) {
+    message_aggregate_group_body<LMAX, SEP_DIR, SEP_TENSOR, LLO, LHI, SCALAR, FUSE>(GN_MSG_GROUP_PASS);
+}
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR, bool FUSE>
+__global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G34) void message_aggregate_group34_kernel(GN_MSG_GROUP_ARGS) {
+    message_aggregate_group_body<LMAX, SEP_DIR, SEP_TENSOR, LLO, LHI, SCALAR, FUSE>(GN_MSG_GROUP_PASS);
+}
+
 // ------------------------------------------------------------------ K7 HTR edge weights
 // gotennet.py:351-364, 580-609 (sep_htr, rejection on): literal two-rejection form.
 template <int LMAX>
@@ -384,8 +370,15 @@ extern "C" int gn_attn_softmax(const float* q, const float* k, int ldqk, const f
         if constexpr (L <= 2) { GN_MSG_MONO(L, SD, ST, FU); }             \
         else {                                                            \
             GN_MSG_ONE(L, SD, ST, 1, 2, true, FU);                        \
-            GN_MSG_ONE(L, SD, ST, 3, 3, false, false);                    \
-            if constexpr (L >= 4) { GN_MSG_ONE(L, SD, ST, 4, 4, false, false); } \
+            if constexpr (L >= 4 && GN_K6_MERGE34) {                      \
+                hipLaunchKernelGGL((gn::message_aggregate_group34_kernel<L, SD, ST, 3, 4, false, false>), dim3(gn::xcd_grid(N)), \
+                                   dim3(256), 0, (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, at, rl, cut, rowptr, src, \
+                                   h_in, X_in, h_out, X_out, N, F, H);    \
+            }                                                             \
+            else {                                                        \
+                GN_MSG_ONE(L, SD, ST, 3, 3, false, false);                \
+                if constexpr (L >= 4) { GN_MSG_ONE(L, SD, ST, 4, 4, false, false); } \
+            }                                                             \
         }                                                                 \
     } while (0)
 #define GN_MSG_LAUNCH(L, SD, ST) \
