@@ -278,7 +278,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
     torch.manual_seed(0)                                   # identical replicated weights on every rank
     rep = gotennet_amd.GotenNet(n_atom_basis=F, n_interactions=L, n_rbf=R, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
                                 num_heads=H, scale_edge=False, lmax=lmax, sep_dir=True, sep_tensor=True).to(dev).eval()
-    head = Atomwise(n_in=F, n_hidden=256, derivative="forces").to(dev).eval()
+    head = Atomwise(n_in=F, n_hidden=256, derivative="forces", activation="silu").to(dev).eval()
     step_fn = EnergyForces(rep, head, check_edges=False)   # radius-graph order is target-major by construction
 
     pos, batch, z = synthetic.make_batch(workload, B, seed=0, first_molecule=rank * B)

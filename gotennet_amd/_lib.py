@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GN_LIB_PATH") or os.path.join(_PKG, "libgotennet_hip.so")
 
 GN_ERR_BAD_ARG = 10001
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 
@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
                 ("row_cnt", _I), ("row_gstride", _I), ("row_goff", _I),
                 ("res", _P), ("gate", _P), ("gate_mode", _I), ("pre_out", _P),
                 ("pro_mode", _I), ("pro_lo", _I), ("pro_hi", _I), ("a_pre", _P), ("ldp", _I),
-                ("a_gate", _P), ("ldg", _I), ("A2", _P), ("A3", _P), ("a_seg", _I)]
+                ("a_gate", _P), ("ldg", _I), ("A2", _P), ("A3", _P), ("a_seg", _I), ("act_kind", _I)]
 
 
 SIGNATURES = {
@@ -38,32 +38,32 @@ SIGNATURES = {
     "gn_edge_geometry": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P],
     "gn_node_init": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P],
     "gn_edge_init": [_P, _P, _P, _P, _I, _I, _I, _P, _P],
-    "gn_layernorm_silu": [_P, _P, _P, _F, _I, _I, _P, _P],
+    "gn_layernorm_silu": [_P, _P, _P, _F, _I, _I, _P, _I, _P],
     "gn_layernorm": [_P, _P, _P, _F, _I, _I, _P, _P],
     "gn_tensor_norm": [_P, _P, _F, _I, _I, _I, _P, _P],
     "gn_gemm": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
-    "gn_attn_softmax": [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P],
+    "gn_attn_softmax": [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P],
     "gn_message_aggregate": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "gn_message_fused": [_P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gn_message_fused": [_P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gn_htr_edge": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "gn_eqff_context": [_P, _P, _F, _I, _I, _I, _P, _P],
     "gn_eqff_update": [_P, _P, _I, _I, _I, _P, _P, _P],
-    "gn_gemm_ex": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],
+    "gn_gemm_ex": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _I, _P],
     "gn_gemm_group": [_P, _I, _P],
     "gn_edge_vectors": [_P, _P, _P, _I, _P, _P, _P],
-    "gn_gemm_split": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],
+    "gn_gemm_split": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _I, _P],
     "gn_split_bf16x3": [_P, _I, _I, _P, _P],
     "gn_split_bf16x3_size": [_I, _I],
     "gn_gemm_group_split": [_P, _I, _P],
-    "gn_htr_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "gn_htr_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "gn_message_backward": [_P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                            _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.c_long, _I, _I, _I, _I, _I, _I, _P],
+                            _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.c_long, _I, _I, _I, _I, _I, _I, _I, _P],
     "gn_message_backward_groups": [_I, _I, _I],
     "gn_eqff_backward_a": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "gn_eqff_backward_b": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "gn_edge_init_backward": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "gn_node_init_backward": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P],
-    "gn_layernorm_silu_backward": [_P, _P, _P, _F, _P, _I, _I, _P, _P],
+    "gn_layernorm_silu_backward": [_P, _P, _P, _F, _P, _I, _I, _P, _I, _P],
     "gn_layernorm_backward": [_P, _P, _F, _P, _I, _I, _P, _P],
     "gn_tensor_norm_backward": [_P, _P, _P, _F, _I, _I, _I, _P, _P],
     "gn_gate": [_P, _I, _L, _P, _P],
@@ -71,8 +71,8 @@ SIGNATURES = {
     "gn_edge_gate_backward": [_P, _P, _I, _P, _L, _P, _P, _P],
     "gn_edge_geometry_backward": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _I, _P, _I, _P, _P, _P, _P],
     "gn_pos_scatter": [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P],
-    "gn_head_energy": [_P, _P, _F, _F, _F, _P, _P, _P, _I, _I, _P, _P, _P],
-    "gn_head_grad": [_P, _P, _F, _I, _I, _P, _P],
+    "gn_head_energy": [_P, _P, _F, _F, _F, _P, _P, _P, _I, _I, _P, _P, _I, _P],
+    "gn_head_grad": [_P, _P, _F, _I, _I, _P, _I, _P],
     "gn_radius_count": [_P, _P, _I, _F, _I, _P, _P],
     "gn_radius_fill": [_P, _P, _I, _F, _I, _P, C.c_int64, _P, _P, _P, _P],
 }

@@ -19,8 +19,6 @@
 
 namespace gn {
 
-__device__ __forceinline__ float4 silu4(float4 v) { return make_float4(silu(v.x), silu(v.y), silu(v.z), silu(v.w)); }
-__device__ __forceinline__ float4 dsilu4(float4 v) { return make_float4(dsilu(v.x), dsilu(v.y), dsilu(v.z), dsilu(v.w)); }
 
 // cross-slot fixed-order reduction of ROWS float4 accumulators; `wr(row, sum)` is called by
 // exactly one slot per row.  red: >= min(ROWS, 9) * 1024 floats of LDS.
@@ -45,7 +43,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT) void htr_bwd_target_kerne
     const float* __restrict__ gtp, const float* __restrict__ pre_t, const float* __restrict__ w,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
     const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F,
-    float* __restrict__ gEQ, float* __restrict__ g_rl, float* __restrict__ g_pre_t) {
+    float* __restrict__ gEQ, float* __restrict__ g_rl, float* __restrict__ g_pre_t, int act) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int KP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));
     constexpr int CH = D < 9 ? D : 9;
@@ -60,9 +58,9 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT) void htr_bwd_target_kerne
     for (int m = 0; m < D; ++m) { eq[m] = ld4(EQ + ((size_t)i * D + m) * F + c0); acc[m] = zero4(); }
     for (int e = e0 + slot; e < e1; e += ns) {
         const float4 gte = ld4(gtp + (size_t)e * F + c0), pte = ld4(pre_t + (size_t)e * F + c0);
-        const float4 gw = gte * silu4(pte);
+        const float4 gw = gte * act4(pte, act);
         // t' = t + SiLU(pre_t) * w:  d/d pre_t, ready for the plain W_t^T product that follows
-        st4(g_pre_t + (size_t)e * F + c0, gte * ld4(w + (size_t)e * F + c0) * dsilu4(pte));
+        st4(g_pre_t + (size_t)e * F + c0, gte * ld4(w + (size_t)e * F + c0) * dact4(pte, act));
         const float* kj = EK + (size_t)src[e] * D * F + c0;
         const float* re = rl + (size_t)e * D;
         float part[KP];
@@ -113,7 +111,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_SRC) void htr_bwd_source_kerne
     const float* __restrict__ gtp, const float* __restrict__ pre_t,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
     const int* __restrict__ colptr, const int* __restrict__ perm, const int* __restrict__ dst, int N, int F,
-    float* __restrict__ gEK) {
+    float* __restrict__ gEK, int act) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int CH = D < 9 ? D : 9;
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
@@ -127,7 +125,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_SRC) void htr_bwd_source_kerne
     for (int m = 0; m < D; ++m) { ek[m] = ld4(EK + ((size_t)j * D + m) * F + c0); acc[m] = zero4(); }
     for (int pp = p0 + slot; pp < p1; pp += ns) {
         const int e = perm[pp];
-        const float4 gw = ld4(gtp + (size_t)e * F + c0) * silu4(ld4(pre_t + (size_t)e * F + c0));
+        const float4 gw = ld4(gtp + (size_t)e * F + c0) * act4(ld4(pre_t + (size_t)e * F + c0), act);
         const float* qi = EQ + (size_t)dst[pp] * D * F + c0;
         const float* re = rl + (size_t)e * D;
         int m0 = 0;
@@ -191,6 +189,7 @@ struct MsgBwdArgs {
     float* g_rl; float* g_cut;                         // this call's slice (written, not accumulated)
     int N, F, H;
     float inv_sqrt_f;
+    int act;                                           // GN_ACT_*: t_attn = act(W_re t + b)
 };
 
 // by-target pass: g_tf, g_cut, g_rl, attention backward (g_a -> g_s), g_ta, g_q
@@ -315,8 +314,8 @@ __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, const f
         const float gs = g_s_[(size_t)e * H + hq];
         const float4 kj = ld4(qk_ + (size_t)src_[e] * p.ldqk + F + c0);
         const float4 pta = ld4_nt(eproj_ + (size_t)e * p.lde + c0);
-        gq = fma4(gs, kj * silu4(pta), gq);
-        st4_nt(g_eproj_ + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dsilu4(pta));   // d/d(pre-activation of t_attn)
+        gq = fma4(gs, kj * act4(pta, p.act), gq);
+        st4_nt(g_eproj_ + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dact4(pta, p.act));   // d/d(pre-activation of t_attn)
     }
     st4(&red[slot * F + c0], gq);
     __syncthreads();
@@ -395,7 +394,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kerne
         }
         const float gs = p.g_s[(size_t)e * H + hq];
         const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
-        const float4 ta = silu4(ld4_nt(p.eproj + (size_t)e * p.lde + c0));
+        const float4 ta = act4(ld4_nt(p.eproj + (size_t)e * p.lde + c0), p.act);
         acc[2 * M + D] = fma4(gs, qi * ta, acc[2 * M + D]);
     }
     reduce_rows<ROWS>(acc, red, slot, c0, F, ns, [&](int row, float4 s) {
@@ -533,8 +532,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const MsgBwdArgs p, const
         const float gs = p.g_s[(size_t)e * H + hq];
         const float4 kj = ld4(p.qk + (size_t)p.src[e] * p.ldqk + F + c0);
         const float4 pta = ld4_nt(p.eproj + (size_t)e * p.lde + c0);
-        gq = fma4(gs, kj * silu4(pta), gq);
-        st4_nt(p.g_eproj + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dsilu4(pta));
+        gq = fma4(gs, kj * act4(pta, p.act), gq);
+        st4_nt(p.g_eproj + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dact4(pta, p.act));
     }
     st4(&red[slot * F + c0], gq);
     __syncthreads();
@@ -607,7 +606,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC_G) void msg_bwd_source_gro
         if (SCALAR) {
             const float gs = p.g_s[(size_t)e * H + hq];
             const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
-            const float4 ta = silu4(ld4_nt(p.eproj + (size_t)e * p.lde + c0));
+            const float4 ta = act4(ld4_nt(p.eproj + (size_t)e * p.lde + c0), p.act);
             acc[2 * NB + XR] = fma4(gs, qi * ta, acc[2 * NB + XR]);
         }
     }
@@ -627,7 +626,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT_G) void htr_bwd_target_gro
     const float* __restrict__ gtp, const float* __restrict__ pre_t, const float* __restrict__ w,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
     const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F,
-    float* __restrict__ gEQ, float* __restrict__ g_rl, float* __restrict__ g_pre_t) {
+    float* __restrict__ gEQ, float* __restrict__ g_rl, float* __restrict__ g_pre_t, int act) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int XR = (LHI + 1) * (LHI + 1) - LLO * LLO, M0 = LLO * LLO - 1;
     constexpr int KP = XR <= 4 ? 4 : (XR <= 8 ? 8 : 16);
@@ -642,8 +641,8 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT_G) void htr_bwd_target_gro
     for (int m = 0; m < XR; ++m) { eq[m] = ld4(EQ + ((size_t)i * D + M0 + m) * F + c0); acc[m] = zero4(); }
     for (int e = rowptr[i] + slot; e < rowptr[i + 1]; e += ns) {
         const float4 gte = ld4(gtp + (size_t)e * F + c0), pte = ld4(pre_t + (size_t)e * F + c0);
-        const float4 gw = gte * silu4(pte);
-        if (FIRST) st4(g_pre_t + (size_t)e * F + c0, gte * ld4(w + (size_t)e * F + c0) * dsilu4(pte));
+        const float4 gw = gte * act4(pte, act);
+        if (FIRST) st4(g_pre_t + (size_t)e * F + c0, gte * ld4(w + (size_t)e * F + c0) * dact4(pte, act));
         const float* kj = EK + (size_t)src[e] * D * F + c0;
         const float* re = rl + (size_t)e * D;
         float part[KP];
@@ -692,7 +691,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_SRC_G) void htr_bwd_source_gro
     const float* __restrict__ gtp, const float* __restrict__ pre_t,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
     const int* __restrict__ colptr, const int* __restrict__ perm, const int* __restrict__ dst, int N, int F,
-    float* __restrict__ gEK) {
+    float* __restrict__ gEK, int act) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int XR = (LHI + 1) * (LHI + 1) - LLO * LLO, M0 = LLO * LLO - 1;
     constexpr int CH = XR < 9 ? XR : 9;
@@ -706,7 +705,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_SRC_G) void htr_bwd_source_gro
     for (int m = 0; m < XR; ++m) acc[m] = zero4();
     for (int pp = colptr[j] + slot; pp < colptr[j + 1]; pp += ns) {
         const int e = perm[pp];
-        const float4 gw = ld4(gtp + (size_t)e * F + c0) * silu4(ld4(pre_t + (size_t)e * F + c0));
+        const float4 gw = ld4(gtp + (size_t)e * F + c0) * act4(ld4(pre_t + (size_t)e * F + c0), act);
         const float* qi = EQ + (size_t)dst[pp] * D * F + c0;
         const float* re = rl + (size_t)e * D;
 #pragma unroll
@@ -832,7 +831,7 @@ __global__ __launch_bounds__(256) void node_init_bwd_kernel(
 template <bool SILU>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-    const float* __restrict__ gout, int N, int F, float* __restrict__ gx) {
+    const float* __restrict__ gout, int N, int F, float* __restrict__ gx, int act) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= N) return;
@@ -847,13 +846,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     float s1 = 0.f, s2 = 0.f;
     for (int f = lane; f < F; f += 64) {
         const float xh = (xr[f] - mean) * rstd;
-        const float g = gr[f] * (SILU ? dsilu(xh * gamma[f] + beta[f]) : 1.0f) * gamma[f];
+        const float g = gr[f] * (SILU ? dact1(xh * gamma[f] + beta[f], act) : 1.0f) * gamma[f];
         s1 += g; s2 += g * xh;
     }
     s1 = wave_sum(s1) / (float)F; s2 = wave_sum(s2) / (float)F;
     for (int f = lane; f < F; f += 64) {
         const float xh = (xr[f] - mean) * rstd;
-        const float g = gr[f] * (SILU ? dsilu(xh * gamma[f] + beta[f]) : 1.0f) * gamma[f];
+        const float g = gr[f] * (SILU ? dact1(xh * gamma[f] + beta[f], act) : 1.0f) * gamma[f];
         gx[(size_t)row * F + f] = rstd * (g - s1 - xh * s2);
     }
 }
@@ -963,13 +962,13 @@ __global__ void pos_scatter_kernel(const float* __restrict__ g_vec, const float*
 __global__ __launch_bounds__(256) void head_energy_kernel(
     const float* __restrict__ pre1, const float* __restrict__ W2, float b2, float scale, float shift,
     const float* __restrict__ atomref, const int* __restrict__ z, const int* __restrict__ mol_ptr,
-    int Hd, float* __restrict__ y, float* __restrict__ energy) {
+    int Hd, float* __restrict__ y, float* __restrict__ energy, int act) {
     const int b = blockIdx.x;
     const int n0 = mol_ptr[b], n1 = mol_ptr[b + 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int n = n0 + wave; n < n1; n += 4) {
         float s = 0.f;
-        for (int k = lane; k < Hd; k += 64) s += silu(pre1[(size_t)n * Hd + k]) * W2[k];
+        for (int k = lane; k < Hd; k += 64) s += act1(pre1[(size_t)n * Hd + k], act) * W2[k];
         s = wave_sum(s);
         if (lane == 0) y[n] = (s + b2) * scale + shift + (atomref ? atomref[z[n]] : 0.f);
     }
@@ -983,10 +982,10 @@ __global__ __launch_bounds__(256) void head_energy_kernel(
 }
 
 __global__ void head_grad_kernel(const float* __restrict__ pre1, const float* __restrict__ W2, float scale,
-                                 int N, int Hd, float* __restrict__ gpre1) {
+                                 int N, int Hd, float* __restrict__ gpre1, int act) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)N * Hd) return;
-    gpre1[idx] = scale * W2[idx % Hd] * dsilu(pre1[idx]);
+    gpre1[idx] = scale * W2[idx % Hd] * dact1(pre1[idx], act);
 }
 
 }  // namespace gn
@@ -1006,23 +1005,24 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
                                const float* EQ,
                                const float* EK, const float* rl, const int* rowptr, const int* src, const int* dst,
                                const int* colptr, const int* perm, int N, int F, int lmax, int mode,
-                               float* gEQ, float* gEK, float* g_rl, float* g_pre_t, void* stream) {
-    if (!bwd_dim_ok(F) || N < 0 || lmax < 1 || lmax > 4 || mode < 0 || mode > 31) return GN_ERR_BAD_ARG;
+                               float* gEQ, float* gEK, float* g_rl, float* g_pre_t, int act, void* stream) {
+    if (!bwd_dim_ok(F) || N < 0 || lmax < 1 || lmax > 4 || mode < 0 || mode > 31 || act < 0 || act >= GN_ACT_COUNT)
+        return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
     if (mode)
         return gn_htr_backward_general(g_t_out, pre_t, w, w_raw, EQ, EK, rl, rowptr, src, dst, colptr, perm, N, F, lmax,
-                                       mode, gEQ, gEK, g_rl, g_pre_t, st);
+                                       mode, gEQ, gEK, g_rl, g_pre_t, act, st);
     const dim3 grid(gn::xcd_grid(N)), block(256);
 #define GN_HTRB(L, LLO, LHI, FIRST)                                                                              \
     hipLaunchKernelGGL((gn::htr_bwd_target_group_kernel<L, LLO, LHI, FIRST>), grid, block, 0, st, g_t_out, pre_t, w, \
-                       EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl, g_pre_t);                                        \
+                       EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl, g_pre_t, act);                                   \
     hipLaunchKernelGGL((gn::htr_bwd_source_group_kernel<L, LLO, LHI>), grid, block, 0, st, g_t_out, pre_t, EQ, EK, \
-                       rl, colptr, perm, dst, N, F, gEK)
+                       rl, colptr, perm, dst, N, F, gEK, act)
     if (lmax <= 2) {
-        GN_SWITCH_LMAX(htr_bwd_target_kernel, grid, block, st, g_t_out, pre_t, w, EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl, g_pre_t);
+        GN_SWITCH_LMAX(htr_bwd_target_kernel, grid, block, st, g_t_out, pre_t, w, EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl, g_pre_t, act);
         GN_LAUNCH_CHECK();
-        GN_SWITCH_LMAX(htr_bwd_source_kernel, grid, block, st, g_t_out, pre_t, EQ, EK, rl, colptr, perm, dst, N, F, gEK);
+        GN_SWITCH_LMAX(htr_bwd_source_kernel, grid, block, st, g_t_out, pre_t, EQ, EK, rl, colptr, perm, dst, N, F, gEK, act);
     } else if (lmax == 3) {
         GN_HTRB(3, 1, 2, true); GN_HTRB(3, 3, 3, false);
     } else {
@@ -1049,14 +1049,14 @@ extern "C" int gn_message_backward(
     const int* rowptr, const int* src, const int* dst, const int* colptr, const int* perm,
     float* g_eproj, float* g_s, float* g_nproj, int ldn, float* g_x, float* g_v, float* g_X_out,
     float* g_rl, float* g_cut, float* ga_parts, long E,
-    int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream) {
+    int N, int F, int H, int lmax, int sep_dir, int sep_tensor, int act, void* stream) {
     if (!bwd_dim_ok(F) || N < 0 || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || lmax < 1 || lmax > 4 ||
-        (ldxv & 3) || (lde & 3) || (ldqk & 3) || (ldn & 3) || g_X_out == g_X1)
+        (ldxv & 3) || (lde & 3) || (ldqk & 3) || (ldn & 3) || g_X_out == g_X1 || act < 0 || act >= GN_ACT_COUNT)
         return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     gn::MsgBwdArgs p{x, v, ldxv, eproj, lde, a, qk, ldqk, X_in, rl, cut, outdeg, g_h1, g_X1,
                      rowptr, src, dst, colptr, perm, g_eproj, g_s, g_nproj, ldn, g_x, g_v, g_X_out, g_rl, g_cut,
-                     N, F, H, (float)(1.0 / sqrt((double)F))};
+                     N, F, H, (float)(1.0 / sqrt((double)F)), act};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(gn::xcd_grid(N)), block(256);
     if (gn_message_backward_groups(lmax, sep_dir, sep_tensor) > 1) {
@@ -1145,11 +1145,11 @@ extern "C" int gn_node_init_backward(const float* g_ctx, const int* z, const flo
 }
 
 extern "C" int gn_layernorm_silu_backward(const float* x, const float* gamma, const float* beta, float eps,
-                                          const float* g_out, int N, int F, float* g_x, void* stream) {
-    if (N < 0 || F <= 0) return GN_ERR_BAD_ARG;
+                                          const float* g_out, int N, int F, float* g_x, int act, void* stream) {
+    if (N < 0 || F <= 0 || act < 0 || act >= GN_ACT_COUNT) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipLaunchKernelGGL(gn::layernorm_bwd_kernel<true>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       x, gamma, beta, eps, g_out, N, F, g_x);
+                       x, gamma, beta, eps, g_out, N, F, g_x, act);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
@@ -1159,7 +1159,7 @@ extern "C" int gn_layernorm_backward(const float* x, const float* gamma, float e
     if (N < 0 || F <= 0) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipLaunchKernelGGL(gn::layernorm_bwd_kernel<false>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       x, gamma, gamma, eps, g_out, N, F, g_x);
+                       x, gamma, gamma, eps, g_out, N, F, g_x, 0);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
@@ -1191,21 +1191,22 @@ extern "C" int gn_pos_scatter(const float* g_vec, const float* g_diff, const flo
 
 extern "C" int gn_head_energy(const float* pre1, const float* W2, float b2, float scale, float shift,
                               const float* atomref, const int* z, const int* mol_ptr, int n_mol, int Hd,
-                              float* y, float* energy, void* stream) {
-    if (n_mol < 0 || Hd <= 0) return GN_ERR_BAD_ARG;
+                              float* y, float* energy, int act, void* stream) {
+    if (n_mol < 0 || Hd <= 0 || act < 0 || act >= GN_ACT_COUNT) return GN_ERR_BAD_ARG;
     if (n_mol == 0) return GN_OK;
     hipLaunchKernelGGL(gn::head_energy_kernel, dim3(n_mol), dim3(256), 0, (hipStream_t)stream,
-                       pre1, W2, b2, scale, shift, atomref, z, mol_ptr, Hd, y, energy);
+                       pre1, W2, b2, scale, shift, atomref, z, mol_ptr, Hd, y, energy, act);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
 
-extern "C" int gn_head_grad(const float* pre1, const float* W2, float scale, int N, int Hd, float* g_pre1, void* stream) {
-    if (N < 0 || Hd <= 0) return GN_ERR_BAD_ARG;
+extern "C" int gn_head_grad(const float* pre1, const float* W2, float scale, int N, int Hd, float* g_pre1, int act,
+                            void* stream) {
+    if (N < 0 || Hd <= 0 || act < 0 || act >= GN_ACT_COUNT) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     const size_t tot = (size_t)N * Hd;
     hipLaunchKernelGGL(gn::head_grad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       pre1, W2, scale, N, Hd, g_pre1);
+                       pre1, W2, scale, N, Hd, g_pre1, act);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }

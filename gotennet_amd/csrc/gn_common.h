@@ -18,7 +18,7 @@ int gn_htr_edge_general(const float* EQ, const float* EK, const float* rl, const
 int gn_htr_backward_general(const float* g_t_out, const float* pre_t, const float* w, const float* w_raw,
                             const float* EQ, const float* EK, const float* rl, const int* rowptr, const int* src,
                             const int* dst, const int* colptr, const int* perm, int N, int F, int lmax, int mode,
-                            float* gEQ, float* gEK, float* g_rl, float* g_pre_t, hipStream_t st);
+                            float* gEQ, float* gEK, float* g_rl, float* g_pre_t, int act, hipStream_t st);
 
 namespace gn {
 
@@ -27,6 +27,52 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float dsilu(float x) {
     const float s = 1.0f / (1.0f + expf(-x));
     return s * (1.0f + x * (1.0f - s));
+}
+// Activation kinds of the reference's `activation` argument (layers.py:596-700 str2act); GN_ACT_* in gotennet_hip.h.
+// `k` is uniform over a launch; kind 0 (SiLU / swish, the reference default) takes the short path.
+__device__ __forceinline__ float softplus_t(float x) { return x > 20.0f ? x : log1pf(expf(x)); }   // torch: threshold 20
+__device__ __forceinline__ float act_generic(float x, int k) {
+    switch (k) {
+        case GN_ACT_SSP: return softplus_t(x) - 0.69314718055994531f;         // shifted_softplus (layers.py:40-50)
+        case GN_ACT_RELU: return fmaxf(x, 0.0f);
+        case GN_ACT_TANH: return tanhf(x);
+        case GN_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+        case GN_ACT_ELU: return x > 0.0f ? x : expm1f(x);
+        case GN_ACT_SELU: return 1.0507009873554805f * (x > 0.0f ? x : 1.6732632423543772f * expm1f(x));
+        case GN_ACT_MISH: return x * tanhf(softplus_t(x));
+        case GN_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        case GN_ACT_SOFTPLUS: return softplus_t(x);
+        case GN_ACT_LEAKY: return x > 0.0f ? x : 0.01f * x;
+        default: return silu(x);
+    }
+}
+__device__ __forceinline__ float dact_generic(float x, int k) {
+    switch (k) {
+        case GN_ACT_SSP: case GN_ACT_SOFTPLUS: return x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));
+        case GN_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
+        case GN_ACT_TANH: { const float t = tanhf(x); return 1.0f - t * t; }
+        case GN_ACT_SIGMOID: { const float s = 1.0f / (1.0f + expf(-x)); return s * (1.0f - s); }
+        case GN_ACT_ELU: return x > 0.0f ? 1.0f : expf(x);
+        case GN_ACT_SELU: return 1.0507009873554805f * (x > 0.0f ? 1.0f : 1.6732632423543772f * expf(x));
+        case GN_ACT_MISH: {
+            const float t = tanhf(softplus_t(x)), s = 1.0f / (1.0f + expf(-x));
+            return t + x * s * (1.0f - t * t);
+        }
+        case GN_ACT_GELU:
+            return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * expf(-0.5f * x * x);
+        case GN_ACT_LEAKY: return x > 0.0f ? 1.0f : 0.01f;
+        default: return dsilu(x);
+    }
+}
+__device__ __forceinline__ float act1(float x, int k) { return k == GN_ACT_SILU ? silu(x) : act_generic(x, k); }
+__device__ __forceinline__ float dact1(float x, int k) { return k == GN_ACT_SILU ? dsilu(x) : dact_generic(x, k); }
+__device__ __forceinline__ float4 act4(float4 v, int k) {
+    if (k == GN_ACT_SILU) return make_float4(silu(v.x), silu(v.y), silu(v.z), silu(v.w));
+    return make_float4(act_generic(v.x, k), act_generic(v.y, k), act_generic(v.z, k), act_generic(v.w, k));
+}
+__device__ __forceinline__ float4 dact4(float4 v, int k) {
+    if (k == GN_ACT_SILU) return make_float4(dsilu(v.x), dsilu(v.y), dsilu(v.z), dsilu(v.w));
+    return make_float4(dact_generic(v.x, k), dact_generic(v.y, k), dact_generic(v.z, k), dact_generic(v.w, k));
 }
 __device__ __forceinline__ float hsum4(float4 v) { return (v.x + v.y) + (v.z + v.w); }
 

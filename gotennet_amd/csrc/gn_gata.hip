@@ -21,7 +21,7 @@ namespace gn {
 __device__ __forceinline__ void attn_phases(const float* __restrict__ q, const float* __restrict__ k, int ldqk,
                                             const float* __restrict__ ta, int ldt, const int* __restrict__ src,
                                             const int* __restrict__ outdeg, int i, int e0, int e1, int F, int H,
-                                            float inv_sqrt_f, float* __restrict__ a, float* sc, bool in_lds) {
+                                            float inv_sqrt_f, float* __restrict__ a, float* sc, bool in_lds, int act) {
     const int lps = F >> 2, ns = 256 / lps;
     const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
     const int lph = lps / H;
@@ -29,7 +29,7 @@ __device__ __forceinline__ void attn_phases(const float* __restrict__ q, const f
     for (int e = e0 + slot; e < e1; e += ns) {
         const float4 kj = ld4(k + (size_t)src[e] * ldqk + c0);
         float4 te = ld4(ta + (size_t)e * ldt + c0);
-        te = make_float4(silu(te.x), silu(te.y), silu(te.z), silu(te.w));
+        te = act4(te, act);
         float p = qi.x * kj.x * te.x;
         p += qi.y * kj.y * te.y;
         p += qi.z * kj.z * te.z;
@@ -68,18 +68,19 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_ATTN) void attn_softmax_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int ldqk,
     const float* __restrict__ ta, int ldt,
     const int* __restrict__ rowptr, const int* __restrict__ src, const int* __restrict__ outdeg,
-    int N, int F, int H, float inv_sqrt_f, float* a) {
+    int N, int F, int H, float inv_sqrt_f, float* a, int act) {
     __shared__ float sc[GN_ATTN_LDS];
     const int i = xcd_item(blockIdx.x, N);
     if (i < 0) return;
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
-    attn_phases(q, k, ldqk, ta, ldt, src, outdeg, i, e0, e1, F, H, inv_sqrt_f, a, sc, (e1 - e0) * H <= GN_ATTN_LDS);
+    attn_phases(q, k, ldqk, ta, ldt, src, outdeg, i, e0, e1, F, H, inv_sqrt_f, a, sc, (e1 - e0) * H <= GN_ATTN_LDS, act);
 }
 
 // q / k / t_attn / outdeg of the fused form (null q = the attention weights were computed by an earlier launch)
 struct AttnIn {
     const float* q; const float* k; int ldqk;
     const float* ta; const int* outdeg; float inv_sqrt_f;
+    int act;                                        // GN_ACT_*: t_attn = act(W_re t + b)
 };
 
 // ------------------------------------------------------------------ K6 message + aggregate (lmax <= 2: one launch)
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
     const int per_head = (M * F) / H;
     // FUSE: attention scores + segment softmax of this target first (gotennet.py:497-511); the weights then come from LDS
     const bool a_lds = FUSE && (e1 - e0) * H <= CH * 1024;
-    if constexpr (FUSE) attn_phases(at.q, at.k, at.ldqk, at.ta, ldt, src, at.outdeg, i, e0, e1, F, H, at.inv_sqrt_f, a, red, a_lds);
+    if constexpr (FUSE) attn_phases(at.q, at.k, at.ldqk, at.ta, ldt, src, at.outdeg, i, e0, e1, F, H, at.inv_sqrt_f, a, red, a_lds, at.act);
 
     int hb[M];
 #pragma unroll
@@ -207,7 +208,7 @@ __device__ __forceinline__ void message_aggregate_group_body(
     const int per_head = (M * F) / H;
     // FUSE (the first degree group): attention weights of this target, kept in LDS and written to a[] for the other groups
     const bool a_lds = FUSE && (e1 - e0) * H <= CH * 1024;
-    if constexpr (FUSE) attn_phases(at.q, at.k, at.ldqk, at.ta, ldt, src, at.outdeg, i, e0, e1, F, H, at.inv_sqrt_f, a, red, a_lds);
+    if constexpr (FUSE) attn_phases(at.q, at.k, at.ldqk, at.ta, ldt, src, at.outdeg, i, e0, e1, F, H, at.inv_sqrt_f, a, red, a_lds, at.act);
 
     int hb[M];                                      // attention head of this lane's channels in block b
 #pragma unroll
@@ -344,14 +345,14 @@ static bool feature_dim_ok(int F) { return F >= 16 && F <= 1024 && gn::is_pow2(F
 
 extern "C" int gn_attn_softmax(const float* q, const float* k, int ldqk, const float* t_attn, int ldt,
                                const int* rowptr, const int* src, const int* outdeg,
-                               int N, int F, int H, float* a, void* stream) {
+                               int N, int F, int H, float* a, int act, void* stream) {
     if (!feature_dim_ok(F) || N < 0 || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || (F / 4) / H > 64 ||
-        (ldqk & 3) || (ldt & 3))
+        (ldqk & 3) || (ldt & 3) || act < 0 || act >= GN_ACT_COUNT)
         return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     const float inv_sqrt_f = (float)(1.0 / sqrt((double)F));
     hipLaunchKernelGGL(gn::attn_softmax_kernel, dim3(gn::xcd_grid(N)), dim3(256), 0, (hipStream_t)stream,
-                       q, k, ldqk, t_attn, ldt, rowptr, src, outdeg, N, F, H, inv_sqrt_f, a);
+                       q, k, ldqk, t_attn, ldt, rowptr, src, outdeg, N, F, H, inv_sqrt_f, a, act);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
@@ -426,10 +427,11 @@ extern "C" int gn_message_fused(const float* q, const float* k, int ldqk, const 
                                 const int* outdeg, const float* x, const float* v, int ldxv, float* a,
                                 const float* rl, const float* cut, const int* rowptr, const int* src,
                                 const float* h_in, const float* X_in, float* h_out, float* X_out,
-                                int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream) {
-    if (!feature_dim_ok(F) || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || (F / 4) / H > 64 || (ldqk & 3) || !a)
+                                int N, int F, int H, int lmax, int sep_dir, int sep_tensor, int act, void* stream) {
+    if (!feature_dim_ok(F) || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || (F / 4) / H > 64 || (ldqk & 3) || !a ||
+        act < 0 || act >= GN_ACT_COUNT)
         return GN_ERR_BAD_ARG;
-    const gn::AttnIn at{q, k, ldqk, eproj, outdeg, (float)(1.0 / sqrt((double)F))};
+    const gn::AttnIn at{q, k, ldqk, eproj, outdeg, (float)(1.0 / sqrt((double)F)), act};
     return message_launch(x, v, ldxv, eproj + F, ldt, a, at, true, rl, cut, rowptr, src, h_in, X_in, h_out, X_out,
                           N, F, H, lmax, sep_dir, sep_tensor, stream);
 }

@@ -20,6 +20,7 @@ struct GemmArgs {
     // same row addressing): sums up to three products that share their output rows.  a_seg = 0: plain A.
     const float* A2; const float* A3; int a_seg;
     int nt_store;                   // outputs far larger than the L2s are written with non-temporal stores
+    int act_kind;                   // GN_ACT_*: the activation of the epilogue columns, of gate_mode 1 and of the prologues
 };
 
 constexpr int GN_MAX_GROUP = 4;
@@ -67,8 +68,6 @@ __device__ __forceinline__ int phys_row(const GemmArgs& p, int r) {
     return (r / p.row_cnt) * p.row_gstride + p.row_goff + (r % p.row_cnt);
 }
 
-__device__ __forceinline__ float4 silu4(float4 v) { return make_float4(silu(v.x), silu(v.y), silu(v.z), silu(v.w)); }
-__device__ __forceinline__ float4 dsilu4(float4 v) { return make_float4(dsilu(v.x), dsilu(v.y), dsilu(v.z), dsilu(v.w)); }
 
 
 }  // namespace gn

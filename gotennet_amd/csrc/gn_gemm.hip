@@ -236,7 +236,7 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
             if (aok[i] && kok) {
                 v = ld4(Ab + (size_t)prow[i] * p.lda + ka);
                 if constexpr (PRO) {
-                    if (pro) v = (p.pro_mode == 1) ? silu4(v) : v * dsilu4(ld4(p.a_pre + (size_t)prow[i] * p.ldp + kc));
+                    if (pro) v = (p.pro_mode == 1) ? act4(v, p.act_kind) : v * dact4(ld4(p.a_pre + (size_t)prow[i] * p.ldp + kc), p.act_kind);
                     if (p.a_gate) v = v * ld4(p.a_gate + (size_t)prow[i] * p.ldg + kc);
                 }
             }
@@ -507,8 +507,8 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
                         const int row = (it0 + u) * (256 / C4) + tid / C4;
                         float4 v = ld4(&smem[row * CP + cc]) + bias4;
                         if (p.pre_out) st4(p.pre_out + off[u], v);
-                        if (act) v = silu4(v);
-                        if (p.gate) v = v * (p.gate_mode ? dsilu4(gv[u]) : gv[u]);
+                        if (act) v = act4(v, p.act_kind);
+                        if (p.gate) v = v * (p.gate_mode ? dact4(gv[u], p.act_kind) : gv[u]);
                         if (p.res) v = rv[u] + v;
                         st4(p.C + off[u], v);
                     }
@@ -522,7 +522,7 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
                     float4 v = ld4(&smem[row * CP + cc]) + bias4;
                     const size_t off = (size_t)phys_row(p, gm) * p.ldc + gn;
                     if (p.pre_out) st4(p.pre_out + off, v);
-                    if (act) v = silu4(v);
+                    if (act) v = act4(v, p.act_kind);
 #if GN_SPLIT_NOSTORE
                     if (v.x == 123456.f) st4(p.C + off, v);
 #else
@@ -565,7 +565,8 @@ extern "C" int gn_gemm_ex(const float* A, int lda, const float* W, const float* 
                           int row_cnt, int row_gstride, int row_goff,
                           const float* res, const float* gate, int gate_mode, float* pre_out,
                           int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
-                          const float* a_gate, int ldg, void* stream) {
+                          const float* a_gate, int ldg, int act_kind, void* stream) {
+    if (act_kind < 0 || act_kind >= GN_ACT_COUNT) return GN_ERR_BAD_ARG;
     if (Mrows < 0 || Nout <= 0 || K <= 0 || (K & 3) || (lda & 3) || (Nout & 3) || (ldc & 3) || (act_lo & 3) ||
         (act_hi & 3) || row_cnt <= 0)
         return GN_ERR_BAD_ARG;
@@ -576,7 +577,7 @@ extern "C" int gn_gemm_ex(const float* A, int lda, const float* W, const float* 
     if (Mrows == 0) return GN_OK;
     gn::GemmArgs p{A, W, bias, C, res, gate, pre_out, a_pre, a_gate, lda, ldc, ldp, ldg, Mrows, Nout, K,
                    act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, gate_mode,
-                   nullptr, nullptr, 0};
+                   nullptr, nullptr, 0, 0, act_kind};
     return gn_gemm_launch(&p, 1, (hipStream_t)stream, 0);
 }
 
@@ -609,6 +610,8 @@ static int gemm_group_impl(const gn_gemm_desc* d, int n, void* stream, int split
         g[m++] = gn::GemmArgs{q.A, q.W, q.bias, q.C, q.res, q.gate, q.pre_out, q.a_pre, q.a_gate, q.lda, q.ldc, q.ldp,
                               q.ldg, q.M, q.N, q.K, q.act_lo, q.act_hi, q.pro_mode, q.pro_lo, q.pro_hi, q.row_cnt,
                               q.row_gstride, q.row_goff, q.gate_mode, q.A2, q.A3, q.a_seg};
+        if (q.act_kind < 0 || q.act_kind >= GN_ACT_COUNT) return GN_ERR_BAD_ARG;
+        g[m - 1].act_kind = q.act_kind;
     }
     if (m == 0) return GN_OK;
     return gn_gemm_launch(g, m, (hipStream_t)stream, split);
@@ -702,14 +705,14 @@ extern "C" int gn_gemm_split(const float* A, int lda, const unsigned short* W3, 
                              int row_cnt, int row_gstride, int row_goff,
                              const float* res, const float* gate, int gate_mode, float* pre_out,
                              int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
-                             const float* a_gate, int ldg, void* stream) {
+                             const float* a_gate, int ldg, int act_kind, void* stream) {
     if (!gemm_args_ok(Mrows, Nout, K, lda, ldc, act_lo, act_hi, row_cnt, res, gate, gate_mode, pro_mode, pro_lo, pro_hi,
-                      a_pre, ldp, a_gate, ldg) || !W3)
+                      a_pre, ldp, a_gate, ldg) || !W3 || act_kind < 0 || act_kind >= GN_ACT_COUNT)
         return GN_ERR_BAD_ARG;
     if (Mrows == 0) return GN_OK;
     gn::GemmArgs p{A, reinterpret_cast<const float*>(W3), bias, C, res, gate, pre_out, a_pre, a_gate, lda, ldc, ldp, ldg,
                    Mrows, Nout, K, act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, gate_mode,
-                   nullptr, nullptr, 0};
+                   nullptr, nullptr, 0, 0, act_kind};
     return gn_gemm_launch(&p, 1, (hipStream_t)stream, 1);
 }
 
@@ -718,5 +721,5 @@ extern "C" int gn_gemm(const float* A, int lda, const float* W, const float* bia
                        int row_cnt, int row_gstride, int row_goff,
                        const float* res, const float* gate, void* stream) {
     return gn_gemm_ex(A, lda, W, bias, C, ldc, Mrows, Nout, K, act_lo, act_hi, row_cnt, row_gstride, row_goff,
-                      res, gate, 0, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, stream);
+                      res, gate, 0, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, GN_ACT_SILU, stream);
 }

@@ -304,6 +304,7 @@ __device__ __forceinline__ void gemm_ws_body(const GroupArgs ga) {
     int d_rows = 0;                                                // rows it with it * 8 < d_rows are stored (0: none)
     float4 d_bias = zero4();
     bool d_act = false, d_nt = false, d_dsilu = false;
+    int d_kind = 0;
     auto set_drain_tile = [&](int t) {
         int gi, local;
         ws_locate(0, t, gi, local);
@@ -324,14 +325,15 @@ __device__ __forceinline__ void gemm_ws_body(const GroupArgs ga) {
         d_act = gn >= p.act_lo && gn < p.act_hi;
         d_nt = p.nt_store != 0;
         d_dsilu = p.gate_mode != 0;
+        d_kind = p.act_kind;
     };
     auto drain_store = [&](int it, float4 rv, float4 gv) {
         if (it * 8 >= d_rows) return;
         float4 v = ld4(&Cst[(it * 8 + drow) * WS_CP + dcc]) + d_bias;
         const size_t o = (size_t)it * d_step;
         if (d_pre) st4(d_pre + o, v);
-        if (d_act) v = silu4(v);
-        if (d_gate) v = v * (d_dsilu ? dsilu4(gv) : gv);
+        if (d_act) v = act4(v, d_kind);
+        if (d_gate) v = v * (d_dsilu ? dact4(gv, d_kind) : gv);
         if (d_res) v = rv + v;
         if (d_nt) st4_nt(d_C + o, v); else st4(d_C + o, v);
     };

@@ -7,7 +7,7 @@ namespace gn {
 template <bool SILU>
 __global__ __launch_bounds__(256) void layernorm_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float eps, int N, int F, float* __restrict__ y) {
+    float eps, int N, int F, float* __restrict__ y, int act) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= N) return;
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)F + eps);
     for (int f = lane; f < F; f += 64) {
         const float v = (xr[f] - mean) * rstd * gamma[f] + beta[f];
-        y[(size_t)row * F + f] = SILU ? silu(v) : v;
+        y[(size_t)row * F + f] = SILU ? act1(v, act) : v;
     }
 }
 
@@ -61,11 +61,11 @@ __global__ void eqff_update_kernel(const float* __restrict__ mm, const float* __
 }  // namespace gn
 
 extern "C" int gn_layernorm_silu(const float* x, const float* gamma, const float* beta, float eps,
-                                 int N, int F, float* y, void* stream) {
-    if (N < 0 || F <= 0) return GN_ERR_BAD_ARG;
+                                 int N, int F, float* y, int act, void* stream) {
+    if (N < 0 || F <= 0 || act < 0 || act >= GN_ACT_COUNT) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipLaunchKernelGGL(gn::layernorm_kernel<true>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       x, gamma, beta, eps, N, F, y);
+                       x, gamma, beta, eps, N, F, y, act);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
@@ -75,7 +75,7 @@ extern "C" int gn_layernorm(const float* x, const float* gamma, const float* bet
     if (N < 0 || F <= 0) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipLaunchKernelGGL(gn::layernorm_kernel<false>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       x, gamma, beta, eps, N, F, y);
+                       x, gamma, beta, eps, N, F, y, 0);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }

@@ -9,8 +9,6 @@
 
 namespace gn {
 
-__device__ __forceinline__ float4 silu4o(float4 v) { return make_float4(silu(v.x), silu(v.y), silu(v.z), silu(v.w)); }
-__device__ __forceinline__ float4 dsilu4o(float4 v) { return make_float4(dsilu(v.x), dsilu(v.y), dsilu(v.z), dsilu(v.w)); }
 
 // gamma_w (gotennet.py:285-291): 0 identity, 1 nn.Sigmoid ("gated"), 2 nn.Tanh ("gatedt"), 3 nn.SiLU ("act")
 __device__ __forceinline__ float gate1(float x, int kind) {
@@ -96,7 +94,7 @@ __global__ __launch_bounds__(256) void htr_bwd_target_general_kernel(
     const float* __restrict__ w_raw, const float* __restrict__ EQ, const float* __restrict__ EK,
     const float* __restrict__ rl, const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F,
     int joint, int rej, int gate, int direct, float* __restrict__ gEQ, float* __restrict__ g_rl,
-    float* __restrict__ g_pre_t) {
+    float* __restrict__ g_pre_t, int act) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     __shared__ __attribute__((aligned(16))) float red[1024];
     const int i = xcd_item(blockIdx.x, N);
@@ -111,8 +109,8 @@ __global__ __launch_bounds__(256) void htr_bwd_target_general_kernel(
         float4 gw = ld4(gtp + (size_t)e * F + c0);       // direct: this already is dL/dw
         if (!direct) {
             const float4 pte = ld4(pre_t + (size_t)e * F + c0);
-            st4(g_pre_t + (size_t)e * F + c0, gw * ld4(w + (size_t)e * F + c0) * dsilu4o(pte));
-            gw = gw * silu4o(pte);
+            st4(g_pre_t + (size_t)e * F + c0, gw * ld4(w + (size_t)e * F + c0) * dact4(pte, act));
+            gw = gw * act4(pte, act);
             if (gate) gw = gw * dgate4(ld4(w_raw + (size_t)e * F + c0), gate);
         }
         const float* kj = EK + (size_t)src[e] * D * F + c0;
@@ -167,7 +165,7 @@ __global__ __launch_bounds__(256) void htr_bwd_source_general_kernel(
     const float* __restrict__ gtp, const float* __restrict__ pre_t, const float* __restrict__ w_raw,
     const float* __restrict__ EQ, const float* __restrict__ rl,
     const int* __restrict__ colptr, const int* __restrict__ perm, const int* __restrict__ dst, int N, int F,
-    int joint, int rej, int gate, int direct, float* __restrict__ gEK) {
+    int joint, int rej, int gate, int direct, float* __restrict__ gEK, int act) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     __shared__ __attribute__((aligned(16))) float red[1024];
     const int j = xcd_item(blockIdx.x, N);
@@ -182,7 +180,7 @@ __global__ __launch_bounds__(256) void htr_bwd_source_general_kernel(
         const int e = perm[pp];
         float4 gw = ld4(gtp + (size_t)e * F + c0);
         if (!direct) {
-            gw = gw * silu4o(ld4(pre_t + (size_t)e * F + c0));
+            gw = gw * act4(ld4(pre_t + (size_t)e * F + c0), act);
             if (gate) gw = gw * dgate4(ld4(w_raw + (size_t)e * F + c0), gate);
         }
         const float* qi = EQ + (size_t)dst[pp] * D * F + c0;
@@ -342,15 +340,15 @@ __global__ void gate_bwd_kernel(const float* __restrict__ g, const float* __rest
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n4) st4(gx + 4 * i, ld4(g + 4 * i) * dgate4(ld4(x + 4 * i), kind));
 }
-// t' = t + act(pre) * wg:  g_pre = g act'(pre) wg,  g_wg = g act(pre)      (act: 0 identity, 3 SiLU)
+// t' = t + act(pre) * wg:  g_pre = g act'(pre) wg,  g_wg = g act(pre)      (act: -1 identity, else GN_ACT_*)
 __global__ void edge_gate_bwd_kernel(const float* __restrict__ g, const float* __restrict__ pre, int act,
                                      const float* __restrict__ wg, size_t n4, float* __restrict__ g_pre,
                                      float* __restrict__ g_wg) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     const float4 gv = ld4(g + 4 * i), p = ld4(pre + 4 * i);
-    st4(g_pre + 4 * i, gv * dgate4(p, act) * ld4(wg + 4 * i));
-    st4(g_wg + 4 * i, gv * gate4(p, act));
+    st4(g_pre + 4 * i, (act < 0 ? gv : gv * dact4(p, act)) * ld4(wg + 4 * i));
+    st4(g_wg + 4 * i, act < 0 ? gv : gv * act4(p, act));
 }
 
 }  // namespace gn
@@ -377,16 +375,16 @@ int gn_htr_edge_general(const float* EQ, const float* EK, const float* rl, const
 int gn_htr_backward_general(const float* g_t_out, const float* pre_t, const float* w, const float* w_raw,
                             const float* EQ, const float* EK, const float* rl, const int* rowptr, const int* src,
                             const int* dst, const int* colptr, const int* perm, int N, int F, int lmax, int mode,
-                            float* gEQ, float* gEK, float* g_rl, float* g_pre_t, hipStream_t st) {
+                            float* gEQ, float* gEK, float* g_rl, float* g_pre_t, int act, hipStream_t st) {
     const int joint = mode & GN_HTR_JOINT ? 1 : 0, rej = mode & GN_HTR_NOREJ ? 0 : 1, gate = (mode >> 2) & 3;
     const int direct = mode & GN_HTR_DIRECT ? 1 : 0;
     if (!direct && gate && !w_raw) return GN_ERR_BAD_ARG;
     const dim3 grid(gn::xcd_grid(N)), block(256);
     GN_OPT_SWITCH(htr_bwd_target_general_kernel, grid, block, st, g_t_out, pre_t, w, w_raw, EQ, EK, rl, rowptr, src,
-                  N, F, joint, rej, gate, direct, gEQ, g_rl, g_pre_t);
+                  N, F, joint, rej, gate, direct, gEQ, g_rl, g_pre_t, act);
     GN_LAUNCH_CHECK();
     GN_OPT_SWITCH(htr_bwd_source_general_kernel, grid, block, st, g_t_out, pre_t, w_raw, EQ, rl, colptr, perm, dst,
-                  N, F, joint, rej, gate, direct, gEK);
+                  N, F, joint, rej, gate, direct, gEK, act);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
@@ -434,7 +432,7 @@ extern "C" int gn_gate_backward(const float* g, const float* x, int kind, long n
 
 extern "C" int gn_edge_gate_backward(const float* g, const float* pre, int act, const float* wg, long n,
                                      float* g_pre, float* g_wg, void* stream) {
-    if (n < 0 || (n & 3) || (act != 0 && act != 3)) return GN_ERR_BAD_ARG;
+    if (n < 0 || (n & 3) || act < -1 || act >= GN_ACT_COUNT) return GN_ERR_BAD_ARG;
     if (n == 0) return GN_OK;
     hipLaunchKernelGGL(gn::edge_gate_bwd_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, g, pre, act,
                        wg, (size_t)n / 4, g_pre, g_wg);

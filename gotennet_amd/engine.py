@@ -78,9 +78,10 @@ class Config:
     steerable_norm: bool = False   # TensorLayerNorm on X at the GATA input (gotennet.py:398)
     composed_update: bool = False  # gamma_t 2-layer MLP and/or W_edp in gamma_w: sequenced by _edge_update_composed
     gate_kind: int = 0        # gamma_w's final element-wise gate: 0 none, 1 sigmoid, 2 tanh, 3 SiLU
-    t_last_act: int = 3       # activation of gamma_t's last layer: 3 SiLU, 0 none ("mlp")
+    t_last_act: int = 3       # gamma_t's last layer: 3 = activated (with ``act``), 0 = linear ("mlp")
     lin_w: int = 0            # 0 no W_edp, 1 "linw", 2 "linwa" (SiLU before W_edp)
     lin_ln: int = 0           # 0 none, 1 "ln" (LayerNorm before W_edp), 2 "postln" (inside the W_edp Dense)
+    act: int = 0              # GN_ACT_* kind of the ``activation`` argument (0 = SiLU / swish, the reference default)
     evec: int = 0             # evec_dim: width of EQ / EK / w (0 = F; != F needs W_edp to map back to F)
     emlp: int = 0             # emlp_dim: hidden width of the 2-layer gamma_t (0 = F)
 
@@ -123,8 +124,8 @@ def split_weight(W: torch.Tensor) -> torch.Tensor:
 
 def gemm(A, lda, W, bias, C, ldc, rows, nout, K, act=(0, 0), rowmap=(1, 1, 0), res=None, gate=None,
          a_off=0, c_off=0, pre_out=None, pro=(0, 0, 0), a_pre=None, ldp=0, p_off=0, a_gate=None, ldg=0,
-         dgate=None, g_off=0):
-    """C = epi(pro(A) W^T + bias).  ``a_off`` / ``c_off`` / ``p_off`` / ``g_off``: float offsets of the first
+         dgate=None, g_off=0, kind=None):
+    """C = epi(pro(A) W^T + bias); ``kind``: GN_ACT_* of the activated columns / SiLU' gates / prologues.  ``a_off`` / ``c_off`` / ``p_off`` / ``g_off``: float offsets of the first
     column.  ``dgate``: multiply the output by SiLU'(dgate) (same addressing as C)."""
     name = "gn_gemm_ex"
     if GEMM_MODE == "split":
@@ -133,7 +134,7 @@ def gemm(A, lda, W, bias, C, ldc, rows, nout, K, act=(0, 0), rowmap=(1, 1, 0), r
          rows, nout, K, act[0], act[1], rowmap[0], rowmap[1], rowmap[2], ptr(res),
          (dgate.data_ptr() + 4 * g_off) if dgate is not None else ptr(gate), 1 if dgate is not None else 0, ptr(pre_out),
          pro[0], pro[1], pro[2], (a_pre.data_ptr() + 4 * p_off) if a_pre is not None else None, ldp,
-         ptr(a_gate), ldg, _stream())
+         ptr(a_gate), ldg, ACT if kind is None else kind, _stream())
 
 
 def gemm_group(problems):
@@ -164,7 +165,26 @@ def gemm_group(problems):
             d.ldp = g("ldp", 0)
             d.a_gate = ptr(g("a_gate")); d.ldg = g("ldg", 0)
             d.A2, d.A3, d.a_seg = ptr(g("A2")), ptr(g("A3")), g("a_seg", 0)
+            d.act_kind = g("kind", ACT)
         call("gn_gemm_group_split" if split else "gn_gemm_group", arr, len(chunk), _stream())
+
+
+#: GN_ACT_* kind the grouped GEMM descriptors default to: set by ``forward`` / ``backward`` / ``gata_layer`` / ``eqff_layer``
+#: from ``cfg.act`` for the duration of the call (one model's activation applies to every projection of its step)
+ACT = 0
+
+
+class _act_scope:
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __enter__(self):
+        global ACT
+        self.old, ACT = ACT, self.kind
+
+    def __exit__(self, *exc):
+        global ACT
+        ACT = self.old
 
 
 #: GN_FUSE_ATTENTION=1: attention scores + segment softmax run inside the message kernel (gn_message_fused, one launch,
@@ -272,7 +292,7 @@ class Tape:
     layers: List[LayerTape] = field(default_factory=list)
 
 
-def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: bool = False,
+def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: bool = False,
             trace: Optional[list] = None):
     """-> (h [N,F], X [N,D,F], tape or None).  ``save`` keeps what ``backward`` needs;
     ``trace`` (tests only) collects per-layer clones of (h, X, t)."""
@@ -293,7 +313,7 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
     y_pre = new(N, F_)
     gemm(ctx0, 2 * F_, pw.Wa, pw.ba, y_pre, F_, N, F_, 2 * F_)
     y = new(N, F_)
-    call("gn_layernorm_silu", ptr(y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, N, F_, ptr(y), _stream())
+    call("gn_layernorm_silu", ptr(y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, N, F_, ptr(y), cfg.act, _stream())
     h = new(N, F_)
     gemm(y, F_, pw.Wb, pw.bb, h, F_, N, F_, F_)
     t = new(E, F_)
@@ -390,7 +410,7 @@ def forward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: b
     return h, X, tape
 
 
-def gata_layer(cfg: Config, lw: LayerWeights, g: "Graph", h: torch.Tensor, X: torch.Tensor, t: torch.Tensor):
+def _gata_layer_impl(cfg: Config, lw: LayerWeights, g: "Graph", h: torch.Tensor, X: torch.Tensor, t: torch.Tensor):
     """ONE GATA layer (gotennet.py:366-450) on its own, inference only: what ``GATA.forward`` of the mirror module runs
     when a caller composes layers directly.  Same kernels as ``forward`` (which additionally fuses the neighbouring EQFF
     launches into the grouped GEMMs).  ``g`` carries the CSR view, rl and the cosine cutoff.  -> (h', X', t')."""
@@ -440,7 +460,7 @@ def gata_layer(cfg: Config, lw: LayerWeights, g: "Graph", h: torch.Tensor, X: to
     return h, X, t2
 
 
-def eqff_layer(cfg: Config, lw: LayerWeights, h: torch.Tensor, X: torch.Tensor):
+def _eqff_layer_impl(cfg: Config, lw: LayerWeights, h: torch.Tensor, X: torch.Tensor):
     """ONE EQFF block (gotennet.py:716-748) on its own, inference only (``EQFF.forward`` of the mirror module).
     Returns NEW tensors (h', X')."""
     F_, D = cfg.F, cfg.D
@@ -465,10 +485,10 @@ def message_stage(cfg: Config, g: "Graph", nact, xs, vs, eproj, attn, h, X, h2, 
     if FUSE_ATTENTION:
         call("gn_message_fused", ptr(nact), nact.data_ptr() + 4 * F_, 4 * F_, ptr(eproj), lde, ptr(g.outdeg),
              ptr(xs), ptr(vs), M * F_, ptr(attn), ptr(g.rl), ptr(g.cut), ptr(g.rowptr), ptr(g.src),
-             ptr(h), ptr(X), ptr(h2), ptr(X2), g.N, F_, H, cfg.lmax, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
+             ptr(h), ptr(X), ptr(h2), ptr(X2), g.N, F_, H, cfg.lmax, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act, _stream())
         return
     call("gn_attn_softmax", ptr(nact), nact.data_ptr() + 4 * F_, 4 * F_, ptr(eproj), lde,
-         ptr(g.rowptr), ptr(g.src), ptr(g.outdeg), g.N, F_, H, ptr(attn), _stream())
+         ptr(g.rowptr), ptr(g.src), ptr(g.outdeg), g.N, F_, H, ptr(attn), cfg.act, _stream())
     call("gn_message_aggregate", ptr(xs), ptr(vs), M * F_, eproj.data_ptr() + 4 * F_, lde,
          ptr(attn), ptr(g.rl), ptr(g.cut), ptr(g.rowptr), ptr(g.src),
          ptr(h), ptr(X), ptr(h2), ptr(X2), g.N, F_, H, cfg.lmax, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
@@ -525,7 +545,7 @@ def _edge_update_composed_backward(cfg: Config, lw: LayerWeights, lt, gt, gt_a, 
     st = _stream()
     u = lt.upd
     g_pre, g_wg = new(), new()
-    call("gn_edge_gate_backward", ptr(gt), ptr(lt.pre_t), cfg.t_last_act, ptr(u["wg"]), E * F_, ptr(g_pre), ptr(g_wg), st)
+    call("gn_edge_gate_backward", ptr(gt), ptr(lt.pre_t), cfg.act if cfg.t_last_act else -1, ptr(u["wg"]), E * F_, ptr(g_pre), ptr(g_wg), st)
     if lw.Wt0 is not None:
         g_u = new(Fm)
         gemm(g_pre, F_, _T(lw, "Wt"), None, g_u, Fm, E, Fm, F_, dgate=u["u_in"])
@@ -556,7 +576,7 @@ def _edge_update_composed_backward(cfg: Config, lw: LayerWeights, lt, gt, gt_a, 
     return gq
 
 
-def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: Tape,
+def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: Tape,
              gh: torch.Tensor, gX: Optional[torch.Tensor]):
     """Input-gradients of ``forward``: given dL/dh [N,F] and dL/dX [N,D,F] (or None = 0)
     returns (g_edge_vec [E,3], g_edge_diff [E]) in the CSR edge order of ``g``."""
@@ -602,12 +622,12 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
                 g_w = _edge_update_composed_backward(cfg, lw, lt, gt, gt_a, E)
                 call("gn_htr_backward", ptr(g_w), None, None, None, ptr(lt.EQ), ptr(lt.EK), ptr(g.rl),
                      ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm), N, Fe, lmax, cfg.htr_mode | 16,
-                     ptr(gEQ), ptr(gEK), rl_slice(L + li), None, _stream())
+                     ptr(gEQ), ptr(gEK), rl_slice(L + li), None, cfg.act, _stream())
                 gemm_group([m1])
             else:
                 call("gn_htr_backward", ptr(gt), ptr(lt.pre_t), ptr(lt.w), ptr(lt.w_raw), ptr(lt.EQ), ptr(lt.EK),
                      ptr(g.rl), ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm), N, Fe, lmax,
-                     cfg.htr_mode, ptr(gEQ), ptr(gEK), rl_slice(L + li), ptr(g_pre_t), _stream())
+                     cfg.htr_mode, ptr(gEQ), ptr(gEK), rl_slice(L + li), ptr(g_pre_t), cfg.act, _stream())
                 # gt_a = gt + ((gt * w) * SiLU'(pre_t)) Wt; the atom-sized gamma_m product rides in its launch
                 gemm_group([dict(A=g_pre_t, lda=F_, W=_T(lw, "Wt"), C=gt_a, ldc=F_, rows=E, nout=F_, K=F_, res=gt), m1])
             gt_in = gt_a
@@ -656,7 +676,7 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
              ptr(gh1), ptr(gX1), ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm),
              ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), ptr(gX2), rl_slice(li), cut_slice(G * li),
              ptr(ga_parts), E,
-             N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
+             N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act, _stream())
         # the edge-sized W_e^T product leaves 0.7 of its last tile round idle: the two K-heavy atom-sized products
         # (g_x W_s2, g_v W_v2; 60 us as a launch of their own) ride there; W_n1^T needs their output and follows alone
         gemm_group([dict(A=g_eproj, lda=lde, W=_T(lw, "We"), C=gt_b, ldc=F_, rows=E, nout=F_, K=lde, res=gt_in),
@@ -687,7 +707,7 @@ def backward(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, tape: 
     gy = new(N, F_)
     gemm(gh, F_, _T(pw, "Wb"), None, gy, F_, N, F_, F_)
     gy1 = new(N, F_)
-    call("gn_layernorm_silu_backward", ptr(tape.y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, ptr(gy), N, F_, ptr(gy1), _stream())
+    call("gn_layernorm_silu_backward", ptr(tape.y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, ptr(gy), N, F_, ptr(gy1), cfg.act, _stream())
     gemm(gy1, F_, _T(pw, "Wa"), None, g_ctx, 2 * F_, N, 2 * F_, F_)
     call("gn_node_init_backward", ptr(g_ctx), ptr(z32), ptr(tape.feat), 2 * F_, ptr(g.cut), ptr(pw.A_nbr),
          ptr(g.rowptr), ptr(g.src), N, F_, ptr(g_feat), cut_slice(G * L), _stream())
@@ -707,3 +727,18 @@ def pos_gradient(g: Graph, g_vec: torch.Tensor, g_diff: torch.Tensor, sign: floa
     call("gn_pos_scatter", ptr(g_vec), ptr(g_diff), ptr(g.edge_vec), ptr(g.rowptr), ptr(colptr), ptr(perm),
          g.N, float(sign), ptr(out), _stream())
     return out
+
+
+def _scoped(impl):
+    def run(cfg, *args, **kwargs):
+        with _act_scope(cfg.act):                   # cfg.act: the GN_ACT_* kind every projection of this call uses
+            return impl(cfg, *args, **kwargs)
+    run.__doc__ = impl.__doc__
+    run.__name__ = impl.__name__.strip("_").replace("_impl", "")
+    return run
+
+
+forward = _scoped(_forward_impl)
+backward = _scoped(_backward_impl)
+gata_layer = _scoped(_gata_layer_impl)
+eqff_layer = _scoped(_eqff_layer_impl)

@@ -19,8 +19,8 @@ from torch import Tensor
 
 from . import engine
 from ._lib import GotenNetHipError
-from .layers import (BASIS_CODE, MLP, CosineCutoff, Dense, EdgeInit, NodeInit, get_weight_init_by_string,
-                     resolve_activation, str2basis)
+from .layers import (BASIS_CODE, MLP, CosineCutoff, Dense, EdgeInit, NodeInit, activation_kind,
+                     get_weight_init_by_string, resolve_activation, str2basis)
 
 
 class _RepresentationFn(torch.autograd.Function):
@@ -171,6 +171,7 @@ class GATA(_LayerPackCache, nn.Module):
         self.last_layer, self.edge_updates, self.scale_edge = last_layer, edge_updates, scale_edge
         self.sep_htr, self.sep_dir, self.sep_tensor = sep_htr, sep_dir, sep_tensor
         self.dropout, self.epsilon, self.cutoff = dropout, epsilon, cutoff
+        self.act_kind = activation_kind(activation)
         multiplier = 3 + (lmax - 1 if sep_dir else 0) + (lmax - 1 if sep_tensor else 0)
         self.multiplier = multiplier
         D_ = partial(Dense, weight_init=weight_init, bias_init=bias_init)
@@ -242,7 +243,8 @@ class GATA(_LayerPackCache, nn.Module):
                              layernorm=bool(self.layernorm_), steerable_norm=bool(self.steerable_norm_),
                              composed_update=self.composed_update, gate_kind=self.gate_kind,
                              t_last_act=0 if self.update_info["mlp"] else 3, lin_w=self.update_info["lin_w"],
-                             lin_ln=self.update_info["lin_ln"], evec=self.edge_vec_dim, emlp=self.edge_mlp_dim)
+                             lin_ln=self.update_info["lin_ln"], evec=self.edge_vec_dim, emlp=self.edge_mlp_dim,
+                             act=self.act_kind)
 
     @torch.no_grad()
     def forward(self, edge_index: Tensor, h: Tensor, X: Tensor, rl_ij: Tensor, t_ij: Tensor, r_ij: Tensor,
@@ -306,6 +308,7 @@ class EQFF(_LayerPackCache, nn.Module):
                  weight_init=nn.init.xavier_uniform_, bias_init=nn.init.zeros_):
         super().__init__()
         self.lmax, self.n_atom_basis, self.epsilon = lmax, n_atom_basis, epsilon
+        self.act_kind = activation_kind(activation)
         D_ = partial(Dense, weight_init=weight_init, bias_init=bias_init)
         self.gamma_m = nn.Sequential(D_(2 * n_atom_basis, n_atom_basis, activation=activation),
                                      D_(n_atom_basis, 2 * n_atom_basis, activation=None))
@@ -324,7 +327,7 @@ class EQFF(_LayerPackCache, nn.Module):
         N, F_ = h.shape[0], self.n_atom_basis
         D = (self.lmax + 1) ** 2 - 1
         cfg = engine.Config(F=F_, L=1, R=0, H=1, lmax=self.lmax, M=1, cutoff=0.0, eps=float(self.epsilon),
-                            scale_edge=False, sep_dir=False, sep_tensor=False)
+                            scale_edge=False, sep_dir=False, sep_tensor=False, act=self.act_kind)
         lw = self._layer_pack(_pack_eqff)
         ho, Xo = engine.eqff_layer(cfg, lw, h.reshape(N, F_).to(torch.float32).contiguous(),
                                    X.to(torch.float32).contiguous())
@@ -356,6 +359,7 @@ class GotenNet(nn.Module):
             weight_init = get_weight_init_by_string(weight_init)
         if type(bias_init) == str:
             bias_init = get_weight_init_by_string(bias_init)
+        self.act_kind = activation_kind(activation)
         activation = resolve_activation(activation)
         if not 1 <= lmax <= 4:
             raise NotImplementedError("the MI355X kernels are instantiated for 1 <= lmax <= 4")
@@ -456,7 +460,7 @@ class GotenNet(nn.Module):
                              composed_update=g0.composed_update, gate_kind=g0.gate_kind,
                              t_last_act=0 if g0.update_info["mlp"] else 3,
                              lin_w=g0.update_info["lin_w"], lin_ln=g0.update_info["lin_ln"],
-                             evec=g0.edge_vec_dim, emlp=g0.edge_mlp_dim)
+                             evec=g0.edge_vec_dim, emlp=g0.edge_mlp_dim, act=self.act_kind)
 
     def packed_weights(self) -> engine.PackedWeights:
         """Concatenate the projections that share an input into single GEMM operands

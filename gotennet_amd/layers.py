@@ -26,20 +26,56 @@ class CosineCutoff(nn.Module):
         self.cutoff = cutoff
 
 
-def _is_silu(act) -> bool:
+#: activation kinds of libgotennet_hip (GN_ACT_* in include/gotennet_hip.h): the element-wise activations the reference's
+#: ``str2act`` (layers.py:596-700) can name, or a caller can pass as callable / nn.Module
+ACT_KINDS = {"silu": 0, "swish": 0, "softplus": 1, "shiftedsoftplus": 1, "ssp": 1, "relu": 2, "tanh": 3, "sigmoid": 4,
+             "elu": 5, "selu": 6, "mish": 7, "gelu": 8, "leakyrelu": 10}
+_ACT_TORCH = {0: F.silu, 2: F.relu, 3: torch.tanh, 4: torch.sigmoid, 5: F.elu, 6: F.selu, 7: F.mish, 8: F.gelu,
+              10: F.leaky_relu}
+_ACT_MODULES = {nn.SiLU: 0, nn.ReLU: 2, nn.Tanh: 3, nn.Sigmoid: 4, nn.ELU: 5, nn.SELU: 6, nn.Mish: 7, nn.GELU: 8,
+                nn.LeakyReLU: 10}
+
+
+def shifted_softplus(x: torch.Tensor) -> torch.Tensor:
+    """Reference layers.py:40-50 (the default activation of the reference's Atomwise head)."""
+    return F.softplus(x) - 0.6931471805599453
+
+
+_ACT_TORCH[1] = shifted_softplus
+
+
+def activation_kind(act) -> int:
+    """GN_ACT_* code of an activation given the way the reference accepts it: a name (``str2act``: case-insensitive,
+    '-', '_' and spaces ignored; 'softplus' is the reference's shifted softplus), a torch functional, an nn.Module
+    instance or class.  Parameterised variants (ELU alpha != 1, LeakyReLU slope != 0.01, GELU tanh) are rejected."""
     if act is None:
-        return False
+        raise NotImplementedError("activation=None: the reference needs an activation here")
     if isinstance(act, str):
-        return act.lower().replace("-", "").replace("_", "").replace(" ", "") in ("silu", "swish")
-    return act is F.silu or isinstance(act, nn.SiLU) or act is nn.SiLU
+        key = act.lower().replace("-", "").replace("_", "").replace(" ", "")
+        if key in ACT_KINDS:
+            return ACT_KINDS[key]
+        raise NotImplementedError(f"activation {act!r} is not on the MI355X path (have: {sorted(ACT_KINDS)})")
+    if act is shifted_softplus or getattr(act, "__name__", "") == "shifted_softplus" or \
+            type(act).__name__ == "ShiftedSoftplus":
+        return 1
+    for k, fn in _ACT_TORCH.items():
+        if act is fn:
+            return k
+    for cls, k in _ACT_MODULES.items():
+        if act is cls:
+            return k
+        if isinstance(act, cls):
+            if (cls is nn.ELU and act.alpha != 1.0) or (cls is nn.LeakyReLU and act.negative_slope != 0.01) or \
+                    (cls is nn.GELU and act.approximate != "none"):
+                break
+            return k
+    raise NotImplementedError(f"activation {act!r} is not on the MI355X path (have: {sorted(ACT_KINDS)})")
 
 
 def resolve_activation(act):
-    """The HIP kernels fuse SiLU (= 'swish', the reference yaml default and class default)."""
-    if _is_silu(act):
-        return F.silu
-    raise NotImplementedError(
-        f"activation {act!r}: the MI355X path implements SiLU/swish only (reference default)")
+    """-> the torch functional of a supported activation (kept on the mirror modules as ``.activation``; the HIP
+    kernels take its GN_ACT_* code, ``activation_kind``)."""
+    return _ACT_TORCH[activation_kind(act)]
 
 
 def glorot_orthogonal_(tensor: torch.Tensor, scale: float = 2.0) -> torch.Tensor:

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from . import engine
 from ._lib import GotenNetHipError, call, ptr
-from .layers import Dense, resolve_activation
+from .layers import Dense, activation_kind, resolve_activation, shifted_softplus
 
 
 class _Identity(nn.Module):
@@ -53,14 +53,15 @@ def molecule_ptr(batch: torch.Tensor, n_mol: int) -> torch.Tensor:
 
 class Atomwise(nn.Module):
     def __init__(self, n_in: int, n_out: int = 1, aggregation_mode: Optional[str] = "sum", n_layers: int = 2,
-                 n_hidden: Optional[int] = None, activation=F.silu, property: str = "y",
+                 n_hidden: Optional[int] = None, activation=shifted_softplus, property: str = "y",
                  contributions: Optional[str] = None, derivative: Optional[str] = None, negative_dr: bool = True,
                  create_graph: bool = True, mean=None, stddev=None, atomref=None, outnet=None,
                  return_vector: Optional[str] = None, standardize: bool = True):
         super().__init__()
         if n_out != 1 or aggregation_mode != "sum" or outnet is not None or return_vector:
             raise NotImplementedError("accelerated Atomwise: n_out=1, aggregation_mode='sum', default out_net")
-        resolve_activation(activation)
+        self.act_kind = activation_kind(activation)      # (reference default: shifted_softplus, outputs.py:246)
+        activation = resolve_activation(activation)
         self.property, self.contributions, self.derivative = property, contributions, derivative
         self.negative_dr = negative_dr
         self.out_net = nn.Sequential(_Identity(), SchnetMLP(n_in, n_out, n_hidden, n_layers, activation))
@@ -119,7 +120,7 @@ class Atomwise(nn.Module):
         e = torch.empty((n_mol, 1), dtype=torch.float32, device=h.device)
         call("gn_head_energy", ptr(pre1), ptr(d1.weight.detach()), b2, scale, shift,
              ptr(self.atomref.weight.detach()) if self.atomref is not None else None, ptr(z32), ptr(mol_ptr),
-             n_mol, Hd, ptr(y), ptr(e), engine._stream())
+             n_mol, Hd, ptr(y), ptr(e), self.act_kind, engine._stream())
         return e, y, pre1
 
     def grad_h_raw(self, pre1: torch.Tensor, Fd: int) -> torch.Tensor:
@@ -127,7 +128,7 @@ class Atomwise(nn.Module):
         d0, d1, c = self._packed()
         N, Hd = pre1.shape
         g1 = torch.empty_like(pre1)
-        call("gn_head_grad", ptr(pre1), ptr(d1.weight.detach()), c["scale"], N, Hd, ptr(g1), engine._stream())
+        call("gn_head_grad", ptr(pre1), ptr(d1.weight.detach()), c["scale"], N, Hd, ptr(g1), self.act_kind, engine._stream())
         gh = torch.empty((N, Fd), dtype=torch.float32, device=pre1.device)
         engine.gemm(g1, Hd, c["w1t"], None, gh, Fd, N, Fd, Hd)
         return gh

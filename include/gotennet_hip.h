@@ -34,7 +34,14 @@ extern "C" {
 
 #define GN_OK 0
 #define GN_ERR_BAD_ARG 10001     /* shape/flag combination the kernels do not implement */
-#define GN_ABI_VERSION 2
+#define GN_ABI_VERSION 3
+
+/* `act`: the element-wise activation of the reference's `activation` constructor argument (str2act, layers.py:596-700;
+ * shifted_softplus layers.py:40-50).  Wherever an entry point below says SiLU, it means this kind. */
+enum {
+    GN_ACT_SILU = 0, GN_ACT_SSP = 1, GN_ACT_RELU = 2, GN_ACT_TANH = 3, GN_ACT_SIGMOID = 4, GN_ACT_ELU = 5,
+    GN_ACT_SELU = 6, GN_ACT_MISH = 7, GN_ACT_GELU = 8, GN_ACT_SOFTPLUS = 9, GN_ACT_LEAKY = 10, GN_ACT_COUNT = 11
+};
 
 /* Library identity: returns GN_ABI_VERSION; *arch_out (if non-NULL) receives "gfx950". */
 int gn_abi_version(const char** arch_out);
@@ -86,7 +93,7 @@ int gn_edge_init(const float* h, const int* rowptr, const int* src, const float*
 /* y = SiLU(LayerNorm(x) * gamma + beta) row-wise over F (Dense with norm='layer',
  * layers.py:518-529, inside NodeInit's W_nrd_nru).  In place allowed (y == x). */
 int gn_layernorm_silu(const float* x, const float* gamma, const float* beta, float eps,
-                      int N, int F, float* y, void* stream);
+                      int N, int F, float* y, int act /* GN_ACT_* */, void* stream);
 
 /* ---- optional GATA input norms (gotennet.py:305-315, 397-398; off by default) ----------- */
 /* y = LayerNorm(x) * gamma + beta (nn.LayerNorm(F), `layernorm != ""`). */
@@ -122,7 +129,7 @@ int gn_gemm_ex(const float* A, int lda, const float* W, const float* bias, float
                int row_cnt, int row_gstride, int row_goff,
                const float* res, const float* gate, int gate_mode, float* pre_out,
                int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
-               const float* a_gate, int ldg, void* stream);
+               const float* a_gate, int ldg, int act_kind /* GN_ACT_* */, void* stream);
 
 /* Several INDEPENDENT gn_gemm_ex problems (Dense products, layers.py:457-529; call sites gotennet.py:400-407, 432-441,
  * 611, 728, 738) in one launch (no problem may read what another writes).  The atom-sized
@@ -145,6 +152,7 @@ typedef struct gn_gemm_desc {
      * same lda and row addressing; a_seg % 32 == 0; no prologue): C = res + A W_0^T + A2 W_1^T + A3 W_2^T with the
      * three weights concatenated along K.  Used for gX = gX + gXp W_vu + gEQ W_vq + gEK_l W_vk_l. */
     const float* A2; const float* A3; int a_seg;
+    int act_kind;                /* GN_ACT_*: activation of the [act_lo, act_hi) columns, of gate_mode 1 and of the prologues */
 } gn_gemm_desc;
 int gn_gemm_group(const gn_gemm_desc* problems, int n, void* stream);
 
@@ -162,7 +170,7 @@ int gn_gemm_split(const float* A, int lda, const unsigned short* W3, const float
                   int row_cnt, int row_gstride, int row_goff,
                   const float* res, const float* gate, int gate_mode, float* pre_out,
                   int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
-                  const float* a_gate, int ldg, void* stream);
+                  const float* a_gate, int ldg, int act_kind, void* stream);
 /* gn_gemm_group on the split path: every problems[i].W points to gn_split_bf16x3 planes (cast to const float*). */
 int gn_gemm_group_split(const gn_gemm_desc* problems, int n, void* stream);
 
@@ -174,7 +182,7 @@ int gn_gemm_group_split(const gn_gemm_desc* problems, int n, void* stream);
  * (the kernel applies SiLU while loading). */
 int gn_attn_softmax(const float* q, const float* k, int ldqk, const float* t_attn, int ldt,
                     const int* rowptr, const int* src, const int* outdeg,
-                    int N, int F, int H, float* a, void* stream);
+                    int N, int F, int H, float* a, int act /* GN_ACT_*: t_attn = act(.) */, void* stream);
 
 /* Message + segmented reduction + residual (gotennet.py:516-559, 613-640, 426-427):
  *   o[c]   = t_filter[e,c] * x[j,c] * cut[e] + a[e, c / (M F / H)] * v[j,c],  c in [0, M F)
@@ -197,7 +205,7 @@ int gn_message_fused(const float* q, const float* k, int ldqk, const float* epro
                      const int* outdeg, const float* x, const float* v, int ldxv, float* a,
                      const float* rl, const float* cut, const int* rowptr, const int* src,
                      const float* h_in, const float* X_in, float* h_out, float* X_out,
-                     int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream);
+                     int N, int F, int H, int lmax, int sep_dir, int sep_tensor, int act, void* stream);
 
 /* ---- K7 HTR edge weights -------------------------------------------------------------- */
 /* w[e,f] = sum_l sum_m P(EQ[i])_m * P(EK[j])_m with P(a) = a - (a . rl_l) rl_l per degree block
@@ -236,7 +244,7 @@ int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* w, co
                     const float* EQ, const float* EK,
                     const float* rl, const int* rowptr, const int* src, const int* tgt_by_src,
                     const int* colptr, const int* perm, int N, int F, int lmax, int mode,
-                    float* gEQ, float* gEK, float* g_rl, float* g_pre_t, void* stream);
+                    float* gEQ, float* gEK, float* g_rl, float* g_pre_t, int act /* GN_ACT_* of gamma_t */, void* stream);
 
 /* GATA message/softmax/aggregate (gotennet.py:452-559, 613-640) backward.  Inputs: saved x, v [N,MF];
  * eproj [E,(1+M)F] = (pre-activation of t_attn | t_filter); a [E,H]; qk rows with q at column 0 and k at
@@ -249,7 +257,7 @@ int gn_message_backward(const float* x, const float* v, int ldxv, const float* e
                         const int* rowptr, const int* src, const int* tgt_by_src, const int* colptr, const int* perm,
                         float* g_eproj, float* g_s, float* g_nproj, int ldn, float* g_x, float* g_v,
                         float* g_X_out, float* g_rl, float* g_cut, float* ga_parts, long E,
-                        int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream);
+                        int N, int F, int H, int lmax, int sep_dir, int sep_tensor, int act, void* stream);
 /* Number of degree groups G the message backward uses for these flags (1 = monolithic kernels; lmax >= 3 with
  * sep_dir and sep_tensor: {scalar,1,2}, {3}, {4}).  g_cut must then hold G consecutive [E] slices and ga_parts
  * G x [E,H] floats of workspace. */
@@ -272,7 +280,7 @@ int gn_node_init_backward(const float* g_ctx, const int* z, const float* feat, i
                           const float* A_nbr, const int* rowptr, const int* src, int N, int F,
                           float* g_feat, float* g_cut, void* stream);
 int gn_layernorm_silu_backward(const float* x, const float* gamma, const float* beta, float eps,
-                               const float* g_out, int N, int F, float* g_x, void* stream);
+                               const float* g_out, int N, int F, float* g_x, int act, void* stream);
 /* input-gradients of gn_layernorm / gn_tensor_norm (x / X are the un-normalised inputs).  torch.max / torch.min
  * route their gradient to one channel: the first extremal one. */
 int gn_layernorm_backward(const float* x, const float* gamma, float eps,
@@ -307,8 +315,8 @@ int gn_pos_scatter(const float* g_vec, const float* g_diff, const float* edge_ve
  * pre1 = W1 h + b1 comes from gn_gemm.  mol_ptr [n_mol+1] int32.  head_grad: g_pre1 = scale W2 SiLU'(pre1). */
 int gn_head_energy(const float* pre1, const float* W2, float b2, float scale, float shift,
                    const float* atomref, const int* z, const int* mol_ptr, int n_mol, int Hd,
-                   float* y, float* energy, void* stream);
-int gn_head_grad(const float* pre1, const float* W2, float scale, int N, int Hd, float* g_pre1, void* stream);
+                   float* y, float* energy, int act /* GN_ACT_* of the head MLP */, void* stream);
+int gn_head_grad(const float* pre1, const float* W2, float scale, int N, int Hd, float* g_pre1, int act, void* stream);
 
 /* ---- adjacent: radius graph (Distance.forward, layers.py:1588-1604) ----------------------- */
 /* torch_cluster.radius_graph(pos, r, batch, loop=True, max_num_neighbors) semantics: edges j->i with

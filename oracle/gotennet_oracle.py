@@ -32,6 +32,26 @@ import torch.nn.functional as F
 Tensor = torch.Tensor
 
 
+# --------------------------------------------------------------------------- activations
+def shifted_softplus(x: Tensor) -> Tensor:
+    """layers.py:40-50."""
+    return F.softplus(x) - math.log(2.0)
+
+
+#: the names the reference's str2act resolves (layers.py:596-700), normalised (lower case, no '-', '_', ' ')
+ACTIVATIONS = {"silu": F.silu, "swish": F.silu, "softplus": shifted_softplus, "relu": F.relu, "tanh": torch.tanh,
+               "sigmoid": torch.sigmoid, "elu": F.elu, "selu": F.selu, "mish": F.mish, "gelu": F.gelu,
+               "leakyrelu": F.leaky_relu}
+
+
+def activation_of(cfg_or_name):
+    """The activation function of a config (key ``activation``, default SiLU = the reference default) or of a name."""
+    name = cfg_or_name.get("activation", "silu") if isinstance(cfg_or_name, dict) else cfg_or_name
+    if callable(name):
+        return name
+    return ACTIVATIONS[str(name).lower().replace("-", "").replace("_", "").replace(" ", "")]
+
+
 # --------------------------------------------------------------------------- config
 def default_config(**kw) -> dict:
     """Hyper-parameters with the reference *class* defaults (gotennet.py:767-793)."""
@@ -216,7 +236,7 @@ def node_init(sd, cfg, z, h0, edge_index, edge_diff, phi) -> Tensor:
     y = linear(torch.cat([h0, m], dim=1), sd, "node_init.W_nrd_nru.dense_layers.0")
     y = F.layer_norm(y, (y.shape[-1],), sd["node_init.W_nrd_nru.dense_layers.0.norm.weight"],
                      sd["node_init.W_nrd_nru.dense_layers.0.norm.bias"], 1e-5)
-    y = F.silu(y)
+    y = activation_of(cfg)(y)
     return linear(y, sd, "node_init.W_nrd_nru.dense_layers.1")
 
 
@@ -228,9 +248,9 @@ def edge_init(sd, edge_index, phi, h) -> Tensor:
 
 
 # --------------------------------------------------------------------------- GATA
-def _mlp2(x, sd, key):
-    """nn.Sequential(Dense(act=SiLU), Dense(act=None)) -- gotennet.py:209-224."""
-    return linear(F.silu(linear(x, sd, key + ".0")), sd, key + ".1")
+def _mlp2(x, sd, key, act=F.silu):
+    """nn.Sequential(Dense(act), Dense(act=None)) -- gotennet.py:209-224."""
+    return linear(act(linear(x, sd, key + ".0")), sd, key + ".1")
 
 
 def tensor_layernorm(X: Tensor, lmax: int, weight: Tensor, eps: float = 1e-12) -> Tensor:
@@ -270,9 +290,10 @@ def gata_message_aggregate(sd, cfg, p, edge_index, h, X, rl, t, r, n_edges):
     j, i = edge_index[0], edge_index[1]
     q = linear(h, sd, p + "W_q").reshape(-1, H, Fd // H)
     k = linear(h, sd, p + "W_k").reshape(-1, H, Fd // H)
-    x = _mlp2(h, sd, p + "gamma_s")                              # [N, M F]
-    v = _mlp2(h, sd, p + "gamma_v")
-    t_attn = F.silu(linear(t, sd, p + "W_re")).reshape(-1, H, Fd // H)
+    act = activation_of(cfg)
+    x = _mlp2(h, sd, p + "gamma_s", act)                         # [N, M F]
+    v = _mlp2(h, sd, p + "gamma_v", act)
+    t_attn = act(linear(t, sd, p + "W_re")).reshape(-1, H, Fd // H)
     t_filter = linear(t, sd, p + "W_rs")                         # [E, M F]
 
     attn = (q.index_select(0, i) * k.index_select(0, j) * t_attn).sum(dim=-1, keepdim=True)  # [E,H,1]
@@ -340,7 +361,7 @@ def gata_htr(sd, cfg, p, edge_index, X, rl, t):
             ek = _rejection(ek, -rl_s[a])
         wl = (eq * ek).sum(dim=1)
         w = wl if w is None else w + wl
-    return t + gamma_t(sd, cfg, p, info, t) * gamma_w(sd, p, info, w)
+    return t + gamma_t(sd, cfg, p, info, t) * gamma_w(sd, p, info, w, activation_of(cfg))
 
 
 def _layer_norm(x, sd, key):
@@ -351,22 +372,23 @@ def gamma_t(sd, cfg, p, info, t):
     """gotennet.py:236-251: MLP([F, F]) with SiLU, or with "mlp"/"mlpa" MLP([F, emlp, F]) whose hidden Dense
     carries the optional ``edge_ln`` LayerNorm (layers.py:518-529) and whose last activation is None for "mlp"."""
     k = p + "gamma_t.dense_layers."
+    act = activation_of(cfg)
     if info["mlp"] or info["mlpa"]:
         u = linear(t, sd, k + "0")
         if (k + "0.norm.weight") in sd:
             u = _layer_norm(u, sd, k + "0.norm")
-        y = linear(F.silu(u), sd, k + "1")
-        return y if info["mlp"] else F.silu(y)
-    return F.silu(linear(t, sd, k + "0"))
+        y = linear(act(u), sd, k + "1")
+        return y if info["mlp"] else act(y)
+    return act(linear(t, sd, k + "0"))
 
 
-def gamma_w(sd, p, info, w):
+def gamma_w(sd, p, info, w, act=F.silu):
     """gotennet.py:270-291: nn.Sequential([LayerNorm "ln"], [act "linwa"], W_edp [with norm "postln"], [gate])."""
     if info["lin_w"] > 0:
         if info["lin_ln"] == 1:
             w = _layer_norm(w, sd, p + "gamma_w.0")
         if info["lin_w"] == 2:
-            w = F.silu(w)
+            w = act(w)                                            # "linwa": self.activation (gotennet.py:275)
         w = linear(w, sd, p + "W_edp")
         if info["lin_ln"] == 2:
             w = _layer_norm(w, sd, p + "W_edp.norm")
@@ -385,7 +407,7 @@ def eqff(sd, cfg, p, h, X):
     X_p = F.linear(X, sd[p + "W_vu.weight"])
     X_pn = torch.sqrt(torch.sum(X_p ** 2, dim=-2) + cfg["epsilon"])
     ctx = torch.cat([h, X_pn], dim=-1)
-    m = _mlp2(ctx, sd, p + "gamma_m")
+    m = _mlp2(ctx, sd, p + "gamma_m", activation_of(cfg))
     m1, m2 = torch.split(m, Fd, dim=-1)
     return h + m1, X + m2.unsqueeze(1) * X_p
 
@@ -456,15 +478,10 @@ def distance(pos: Tensor, batch: Tensor, cutoff: float, max_num_neighbors: int =
 
 
 # --------------------------------------------------------------------------- energy / forces
-def shifted_softplus(x: Tensor) -> Tensor:
-    """layers.py:40-50."""
-    return F.softplus(x) - math.log(2.0)
-
-
 def atomwise_contributions(head: Dict[str, Tensor], h: Tensor, z: Optional[Tensor] = None,
                            activation: str = "silu") -> Tensor:
     """outputs.py:323-346: y_i = stddev * (W2 act(W1 h_i + b1) + b2) + mean [+ atomref[z_i]]."""
-    act = F.silu if activation == "silu" else shifted_softplus
+    act = activation_of(activation)
     y = F.linear(act(F.linear(h, head["out_net.1.out_net.0.weight"], head["out_net.1.out_net.0.bias"])),
                  head["out_net.1.out_net.1.weight"], head["out_net.1.out_net.1.bias"])
     if "standardize.stddev" in head:

@@ -43,7 +43,7 @@ def seeded_modules(cfg):
     hp = {k: cfg[k] for k in ("n_atom_basis", "n_interactions", "n_rbf", "lmax", "num_heads", "scale_edge", "sep_dir",
                               "sep_tensor", "max_z")}
     net = gotennet_amd.GotenNet(cutoff_fn=gotennet_amd.CosineCutoff(cfg["cutoff"]), **hp)
-    head = Atomwise(n_in=cfg["n_atom_basis"], n_hidden=cfg["head_hidden"], property="property", derivative="forces")
+    head = Atomwise(n_in=cfg["n_atom_basis"], n_hidden=cfg["head_hidden"], property="property", derivative="forces", activation="silu")
     seeded_fill(net, cfg["seeded"])
     seeded_fill(head, cfg["seeded"] + 1)
     return net, head

@@ -166,7 +166,7 @@ def test_head_scale_shift_atomref_against_reference():
     t, hsd = _head_kat()
     F_, Hd = t["h"].shape[1], hsd["out_net.1.out_net.0.weight"].shape[0]
     head = Atomwise(n_in=F_, n_hidden=Hd, property="property", contributions="contrib", mean=hsd["standardize.mean"],
-                    stddev=hsd["standardize.stddev"], atomref=t["atomref"])
+                    stddev=hsd["standardize.stddev"], atomref=t["atomref"], activation="silu")
     head.load_state_dict(hsd, strict=True)
     head = head.cuda().eval()
     n_mol = int(t["n_mol"])
@@ -187,7 +187,7 @@ def test_head_scale_shift_atomref_against_reference():
     plain = _head_from_case(cfg, head_sd)
     atomref = torch.linspace(-2.0, 3.0, cfg["max_z"]).reshape(-1, 1)
     scaled = Atomwise(n_in=cfg["n_atom_basis"], n_hidden=16, property="property", derivative="forces",
-                      mean=torch.tensor([1.7]), stddev=torch.tensor([0.35]), atomref=atomref)
+                      mean=torch.tensor([1.7]), stddev=torch.tensor([0.35]), atomref=atomref, activation="silu")
     scaled.load_state_dict({**head_sd, "standardize.mean": torch.tensor([1.7]), "standardize.stddev": torch.tensor([0.35]),
                             "atomref.weight": atomref}, strict=True)
     scaled = scaled.cuda().eval()

@@ -15,7 +15,7 @@ FORCE_CASES = [n for n in case_names() if "shuffled" not in n]
 
 def _head_from_case(cfg, head_sd):
     from gotennet_amd.outputs import Atomwise
-    head = Atomwise(n_in=cfg["n_atom_basis"], n_hidden=cfg.get("head_hidden", 16), property="property", derivative="forces")
+    head = Atomwise(n_in=cfg["n_atom_basis"], n_hidden=cfg.get("head_hidden", 16), property="property", derivative="forces", activation="silu")
     head.load_state_dict(head_sd, strict=True)
     return head.cuda().eval()
 
@@ -91,7 +91,7 @@ def test_forces_match_oracle_wide(F, L, lmax):
     torch.manual_seed(F + lmax)
     net = gotennet_amd.GotenNet(n_atom_basis=F, n_interactions=L, n_rbf=32, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
                                 num_heads=8, scale_edge=False, lmax=lmax, sep_dir=True, sep_tensor=True)
-    head = Atomwise(n_in=F, n_hidden=64, derivative="forces")
+    head = Atomwise(n_in=F, n_hidden=64, derivative="forces", activation="silu")
     with torch.no_grad():
         for m in (net, head):
             for n, p in m.named_parameters():
@@ -140,7 +140,8 @@ def _random_flag_cases(n=16):
             radial_basis=rng.choice(["expnorm", "expnorm", "BesselBasis", "GaussianRBF"]), edge_updates=eu,
             layernorm=rng.choice(["", "", "layer"]), steerable_norm=rng.choice(["", "", "tensor"]),
             edge_ln=rng.choice(["", "layer"]), evec_dim=(16 if lin and rng.random() < 0.4 else None),
-            emlp_dim=rng.choice([None, 48]), seed=100 + i))
+            emlp_dim=rng.choice([None, 48]), seed=100 + i,
+            activation=rng.choice(["silu", "silu", "softplus", "tanh", "elu", "selu", "mish", "gelu", "sigmoid"])))
     return cases
 
 
@@ -157,8 +158,8 @@ def test_random_flag_combinations_match_oracle(hp):
     seed = hp.pop("seed")
     torch.manual_seed(seed)
     F = hp["n_atom_basis"]
-    net = gotennet_amd.GotenNet(cutoff_fn=gotennet_amd.CosineCutoff(5.0), activation="silu", max_z=10, **hp)
-    head = Atomwise(n_in=F, n_hidden=32, derivative="forces")
+    net = gotennet_amd.GotenNet(cutoff_fn=gotennet_amd.CosineCutoff(5.0), max_z=10, **hp)
+    head = Atomwise(n_in=F, n_hidden=32, derivative="forces")             # reference default head activation: shifted softplus
     with torch.no_grad():
         for m in (net, head):
             for n, p in m.named_parameters():
@@ -175,7 +176,8 @@ def test_random_flag_combinations_match_oracle(hp):
     ei, w, vec = orc.distance(pos, batch, 5.0)
     h_ref, X_ref = orc.gotennet_forward({k: v.double() for k, v in sd.items()}, cfg, z, ei, w.double(), vec.double())
     e_ref, f_ref, _ = orc.energy_and_forces({k: v.double() for k, v in sd.items()}, cfg,
-                                            {k: v.double() for k, v in hsd.items()}, z, pos.double(), batch, 2)
+                                            {k: v.double() for k, v in hsd.items()}, z, pos.double(), batch, 2,
+                                            activation="softplus")
     net, head = net.cuda().eval(), head.cuda().eval()
     eic, wc, vecc = distance(pos.cuda(), batch.cuda(), 5.0, 32)
     assert torch.equal(eic.cpu(), ei)
@@ -234,7 +236,7 @@ def test_full_size_properties():
     torch.manual_seed(0)
     rep = gotennet_amd.GotenNet(n_atom_basis=256, n_interactions=6, n_rbf=32, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
                                 num_heads=8, scale_edge=False, lmax=2, sep_dir=True, sep_tensor=True).to(dev).eval()
-    head = Atomwise(n_in=256, n_hidden=256, derivative="forces").to(dev).eval()
+    head = Atomwise(n_in=256, n_hidden=256, derivative="forces", activation="silu").to(dev).eval()
     run = EnergyForces(rep, head)
     B, na = 128, 21
     pos, batch, z = synthetic.make_batch("rmd17_aspirin", B, seed=0)
@@ -281,7 +283,7 @@ def test_captured_step_replays_bit_identical(n_mol, lmax):
     torch.manual_seed(3)
     rep = gotennet_amd.GotenNet(n_atom_basis=64, n_interactions=3, n_rbf=16, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
                                 num_heads=8, scale_edge=True, lmax=lmax, sep_dir=True, sep_tensor=True).to(dev).eval()
-    head = Atomwise(n_in=64, n_hidden=32, derivative="forces").to(dev).eval()
+    head = Atomwise(n_in=64, n_hidden=32, derivative="forces", activation="silu").to(dev).eval()
     ef = EnergyForces(rep, head)
     pos, batch, z = synthetic.make_batch("rmd17_aspirin", n_mol, seed=4)
     pos, batch, z = pos.to(dev), batch.to(dev), z.to(dev)
@@ -312,7 +314,7 @@ def test_forces_asymmetric_graph_neighbor_cap():
     F, L, lmax, cap = 64, 2, 2, 8
     net = gotennet_amd.GotenNet(n_atom_basis=F, n_interactions=L, n_rbf=16, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
                                 num_heads=8, scale_edge=True, lmax=lmax, sep_dir=True, sep_tensor=True)
-    head = Atomwise(n_in=F, n_hidden=32, derivative="forces")
+    head = Atomwise(n_in=F, n_hidden=32, derivative="forces", activation="silu")
     sd = {k: v.clone() for k, v in net.state_dict().items()}
     hsd = {k: v.clone() for k, v in head.state_dict().items()}
     cfg = orc.default_config(n_atom_basis=F, n_interactions=L, n_rbf=16, num_heads=8, scale_edge=True, lmax=lmax,

@@ -82,7 +82,11 @@ def test_unsupported_flags_raise_before_launch():
     import gotennet_amd
     cut = gotennet_amd.CosineCutoff(5.0)
     with pytest.raises(NotImplementedError):
-        gotennet_amd.GotenNet(cutoff_fn=cut, activation="relu")
+        gotennet_amd.GotenNet(cutoff_fn=cut, activation="hardswish")      # not one of the GN_ACT_* kinds
+    with pytest.raises(NotImplementedError):
+        gotennet_amd.GotenNet(cutoff_fn=cut, activation=torch.nn.ELU(alpha=0.5))
+    for act in ("relu", "tanh", "softplus", "Swish", "leaky_relu", torch.nn.functional.gelu, torch.nn.Mish()):
+        assert gotennet_amd.GotenNet(cutoff_fn=cut, n_atom_basis=32, n_interactions=1, n_rbf=8, activation=act).act_kind >= 0
     with pytest.raises(NotImplementedError):
         gotennet_amd.GotenNet(cutoff_fn=cut, lmax=5)
     with pytest.raises(NotImplementedError):

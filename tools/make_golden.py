@@ -85,6 +85,19 @@ CASES = {
     "opt_linw_act_l3": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=3, num_heads=8, scale_edge=False,
                              sep_dir=True, sep_tensor=True, max_z=10, activation="silu", edge_updates="linw_act"),
                         dict(mols=[5, 4], box=2.8, seed=23)),
+    # non-SiLU activations (str2act names, layers.py:596-700); "softplus" is the reference's shifted softplus
+    "opt_act_ssp": (dict(n_atom_basis=32, n_interactions=3, n_rbf=8, lmax=2, num_heads=8, scale_edge=False,
+                         sep_dir=True, sep_tensor=True, max_z=10, activation="softplus"),
+                    dict(mols=[6, 5], box=3.0, seed=31)),
+    "opt_act_tanh_l3_gated": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=3, num_heads=8, scale_edge=True,
+                                   sep_dir=True, sep_tensor=True, max_z=10, activation="tanh", edge_updates="gated",
+                                   layernorm="layer"), dict(mols=[5, 4], box=2.8, seed=32)),
+    "opt_act_gelu_mlpa_linwa": (dict(n_atom_basis=32, n_interactions=3, n_rbf=8, lmax=2, num_heads=8, scale_edge=False,
+                                     sep_dir=True, sep_tensor=True, max_z=10, activation="gelu",
+                                     edge_updates="mlpa_linwa", edge_ln="layer"), dict(mols=[6, 4], box=3.0, seed=33)),
+    "opt_act_mish_l4": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=4, num_heads=8, scale_edge=False,
+                             sep_dir=True, sep_tensor=True, max_z=10, activation="mish"),
+                        dict(mols=[6], box=2.6, seed=34)),
     "opt_evec16_emlp48": (dict(n_atom_basis=32, n_interactions=3, n_rbf=8, lmax=2, num_heads=8, scale_edge=False,
                                sep_dir=True, sep_tensor=True, max_z=10, activation="silu",
                                edge_updates="mlpa_linwa_postln_gatedt", edge_ln="layer", evec_dim=16, emlp_dim=48),

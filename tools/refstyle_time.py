@@ -10,7 +10,7 @@ from gotennet_amd.pipeline import EnergyForces
 torch.manual_seed(0)
 net = gotennet_amd.GotenNetWrapper(n_atom_basis=256, n_interactions=6, n_rbf=32, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
                                    num_heads=8, scale_edge=False, lmax=2, sep_dir=True, sep_tensor=True).cuda().eval()
-head = Atomwise(n_in=256, n_hidden=256, property="property", derivative="forces").cuda().eval()
+head = Atomwise(n_in=256, n_hidden=256, property="property", derivative="forces", activation="silu").cuda().eval()
 pos, batch, z = synthetic.make_batch("rmd17_aspirin", 128, seed=0)
 pos, batch, z = pos.cuda(), batch.cuda(), z.cuda()
 
