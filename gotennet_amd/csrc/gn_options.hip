@@ -348,7 +348,7 @@ __global__ void edge_gate_bwd_kernel(const float* __restrict__ g, const float* _
     if (i >= n4) return;
     const float4 gv = ld4(g + 4 * i), p = ld4(pre + 4 * i);
     st4(g_pre + 4 * i, (act < 0 ? gv : gv * dact4(p, act)) * ld4(wg + 4 * i));
-    st4(g_wg + 4 * i, act < 0 ? gv : gv * act4(p, act));
+    st4(g_wg + 4 * i, gv * (act < 0 ? p : act4(p, act)));
 }
 
 }  // namespace gn
