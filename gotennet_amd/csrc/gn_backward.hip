@@ -962,7 +962,7 @@ __global__ void pos_scatter_kernel(const float* __restrict__ g_vec, const float*
 __global__ __launch_bounds__(256) void head_energy_kernel(
     const float* __restrict__ pre1, const float* __restrict__ W2, float b2, float scale, float shift,
     const float* __restrict__ atomref, const int* __restrict__ z, const int* __restrict__ mol_ptr,
-    int Hd, float* __restrict__ y, float* __restrict__ energy, int act) {
+    int Hd, float* __restrict__ y, float* __restrict__ energy, int mean, float* __restrict__ atom_scale, int act) {
     const int b = blockIdx.x;
     const int n0 = mol_ptr[b], n1 = mol_ptr[b + 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -977,15 +977,18 @@ __global__ __launch_bounds__(256) void head_energy_kernel(
         float s = 0.f;
         for (int n = n0 + lane; n < n1; n += 64) s += y[n];
         s = wave_sum(s);
-        if (lane == 0) energy[b] = s;
+        if (lane == 0) energy[b] = (mean && n1 > n0) ? s / (float)(n1 - n0) : s;     // aggregation_mode "mean" / "sum"
     }
+    if (atom_scale)                                  // d(aggregate) / d(y_n): what gn_head_grad multiplies by
+        for (int n = n0 + (int)threadIdx.x; n < n1; n += 256) atom_scale[n] = mean ? 1.0f / (float)(n1 - n0) : 1.0f;
 }
 
 __global__ void head_grad_kernel(const float* __restrict__ pre1, const float* __restrict__ W2, float scale,
-                                 int N, int Hd, float* __restrict__ gpre1, int act) {
+                                 const float* __restrict__ atom_scale, int N, int Hd, float* __restrict__ gpre1, int act) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)N * Hd) return;
-    gpre1[idx] = scale * W2[idx % Hd] * dact1(pre1[idx], act);
+    const float sc = atom_scale ? scale * atom_scale[idx / Hd] : scale;
+    gpre1[idx] = sc * W2[idx % Hd] * dact1(pre1[idx], act);
 }
 
 }  // namespace gn
@@ -1191,22 +1194,22 @@ extern "C" int gn_pos_scatter(const float* g_vec, const float* g_diff, const flo
 
 extern "C" int gn_head_energy(const float* pre1, const float* W2, float b2, float scale, float shift,
                               const float* atomref, const int* z, const int* mol_ptr, int n_mol, int Hd,
-                              float* y, float* energy, int act, void* stream) {
+                              float* y, float* energy, int mean, float* atom_scale, int act, void* stream) {
     if (n_mol < 0 || Hd <= 0 || act < 0 || act >= GN_ACT_COUNT) return GN_ERR_BAD_ARG;
     if (n_mol == 0) return GN_OK;
     hipLaunchKernelGGL(gn::head_energy_kernel, dim3(n_mol), dim3(256), 0, (hipStream_t)stream,
-                       pre1, W2, b2, scale, shift, atomref, z, mol_ptr, Hd, y, energy, act);
+                       pre1, W2, b2, scale, shift, atomref, z, mol_ptr, Hd, y, energy, mean, atom_scale, act);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
 
-extern "C" int gn_head_grad(const float* pre1, const float* W2, float scale, int N, int Hd, float* g_pre1, int act,
-                            void* stream) {
+extern "C" int gn_head_grad(const float* pre1, const float* W2, float scale, const float* atom_scale, int N, int Hd,
+                            float* g_pre1, int act, void* stream) {
     if (N < 0 || Hd <= 0 || act < 0 || act >= GN_ACT_COUNT) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     const size_t tot = (size_t)N * Hd;
     hipLaunchKernelGGL(gn::head_grad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       pre1, W2, scale, N, Hd, g_pre1, act);
+                       pre1, W2, scale, atom_scale, N, Hd, g_pre1, act);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }

@@ -43,6 +43,7 @@ __device__ __forceinline__ float act_generic(float x, int k) {
         case GN_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
         case GN_ACT_SOFTPLUS: return softplus_t(x);
         case GN_ACT_LEAKY: return x > 0.0f ? x : 0.01f * x;
+        case GN_ACT_NONE: return x;
         default: return silu(x);
     }
 }
@@ -61,6 +62,7 @@ __device__ __forceinline__ float dact_generic(float x, int k) {
         case GN_ACT_GELU:
             return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * expf(-0.5f * x * x);
         case GN_ACT_LEAKY: return x > 0.0f ? 1.0f : 0.01f;
+        case GN_ACT_NONE: return 1.0f;
         default: return dsilu(x);
     }
 }

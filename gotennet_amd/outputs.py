@@ -26,14 +26,26 @@ class _Identity(nn.Module):
 
 
 class SchnetMLP(nn.Module):
-    def __init__(self, n_in, n_out, n_hidden=None, n_layers=2, activation=F.silu):
+    """Reference layers.py:225-273: ``n_layers - 1`` activated Dense layers and a linear output layer; ``n_hidden`` an
+    int (every hidden layer), a list, or None (pyramid: each layer half the width of the one before)."""
+
+    def __init__(self, n_in, n_out, n_hidden=None, n_layers=2, activation=shifted_softplus):
         super().__init__()
-        if n_layers != 2:
-            raise NotImplementedError("the accelerated head implements n_layers=2 (the reference default)")
-        n_hidden = n_in // 2 if n_hidden is None else n_hidden
-        if not isinstance(n_hidden, int):
-            (n_hidden,) = n_hidden
-        self.out_net = nn.Sequential(Dense(n_in, n_hidden, activation=activation), Dense(n_hidden, n_out, activation=None))
+        if n_layers < 1:
+            raise ValueError("n_layers >= 1")
+        if n_hidden is None:
+            neurons, c = [], n_in
+            for _ in range(n_layers):
+                neurons.append(c)
+                c = c // 2
+            neurons.append(n_out)
+        else:
+            hidden = [n_hidden] * (n_layers - 1) if isinstance(n_hidden, int) else list(n_hidden)
+            neurons = [n_in] + hidden + [n_out]
+        self.n_neurons = neurons
+        layers = [Dense(neurons[i], neurons[i + 1], activation=activation) for i in range(n_layers - 1)]
+        layers.append(Dense(neurons[-2], neurons[-1], activation=None))
+        self.out_net = nn.Sequential(*layers)
 
 
 class ScaleShift(nn.Module):
@@ -58,8 +70,11 @@ class Atomwise(nn.Module):
                  create_graph: bool = True, mean=None, stddev=None, atomref=None, outnet=None,
                  return_vector: Optional[str] = None, standardize: bool = True):
         super().__init__()
-        if n_out != 1 or aggregation_mode != "sum" or outnet is not None or return_vector:
-            raise NotImplementedError("accelerated Atomwise: n_out=1, aggregation_mode='sum', default out_net")
+        if n_out != 1 or outnet is not None or return_vector:
+            raise NotImplementedError("accelerated Atomwise: n_out=1, default out_net, no return_vector")
+        if aggregation_mode not in ("sum", "add", "mean", None):
+            raise NotImplementedError(f"aggregation_mode={aggregation_mode!r}: 'sum', 'mean' or None on the accelerated path")
+        self.aggregation_mode = aggregation_mode
         self.act_kind = activation_kind(activation)      # (reference default: shifted_softplus, outputs.py:246)
         activation = resolve_activation(activation)
         self.property, self.contributions, self.derivative = property, contributions, derivative
@@ -88,9 +103,9 @@ class Atomwise(nn.Module):
 
     def _packed(self):
         """Host copies of the kernel's scalar arguments (a read-back per step would synchronise the stream, and is not
-        allowed inside a hipGraph capture) and the transposed first-layer weight, rebuilt when any parameter changes."""
-        d0, d1 = self.out_net[1].out_net[0], self.out_net[1].out_net[1]
-        ts = [d0.weight, d0.bias, d1.weight, d1.bias]
+        allowed inside a hipGraph capture) and the transposed hidden-layer weights, rebuilt when any parameter changes."""
+        layers = list(self.out_net[1].out_net)
+        ts = [t for d in layers for t in (d.weight, d.bias)]
         if isinstance(self.standardize, ScaleShift):
             ts += [self.standardize.stddev, self.standardize.mean]
         key = tuple((t._version, t.data_ptr()) for t in ts)
@@ -99,39 +114,61 @@ class Atomwise(nn.Module):
             scale, shift = 1.0, 0.0
             if isinstance(self.standardize, ScaleShift):
                 scale, shift = float(self.standardize.stddev[0]), float(self.standardize.mean[0])
-            c = dict(key=key, scale=scale, shift=shift, b2=float(d1.bias.detach().cpu()[0]),
-                     w1=d0.weight.detach(), w1t=d0.weight.detach().t().contiguous())
+            c = dict(key=key, scale=scale, shift=shift, b2=float(layers[-1].bias.detach().cpu()[0]),
+                     w=[d.weight.detach() for d in layers], b=[d.bias.detach() for d in layers],
+                     wt=[d.weight.detach().t().contiguous() for d in layers[:-1]])
             self._cache = c
-        return d0, d1, c
+        return layers, c
 
     def _weights(self):
-        d0, d1, c = self._packed()
-        return d0, d1, c["scale"], c["shift"]
+        _, c = self._packed()
+        return c["scale"], c["shift"]
 
     def energy_raw(self, h: torch.Tensor, z32: torch.Tensor, mol_ptr: torch.Tensor, n_mol: int):
-        """-> (energy [n_mol,1], y [N], pre1 [N,Hd])."""
-        d0, d1, c = self._packed()
-        scale, shift, b2 = c["scale"], c["shift"], c["b2"]
-        N, Fd = h.shape
-        Hd = d0.out_features
-        pre1 = torch.empty((N, Hd), dtype=torch.float32, device=h.device)
-        engine.gemm(h, Fd, c["w1"], d0.bias.detach(), pre1, Hd, N, Hd, Fd)
-        y = torch.empty(N, dtype=torch.float32, device=h.device)
-        e = torch.empty((n_mol, 1), dtype=torch.float32, device=h.device)
-        call("gn_head_energy", ptr(pre1), ptr(d1.weight.detach()), b2, scale, shift,
+        """-> (energy [n_mol,1] (sum or mean over the molecule's atoms), y [N] per-atom contributions, tape).
+        ``tape`` (pre-activations of the hidden layers + the aggregation's per-atom weights) goes to ``grad_h_raw``."""
+        layers, c = self._packed()
+        N = h.shape[0]
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=h.device)
+        x, pres = h, []
+        hidden = layers[:-1]
+        for k, d in enumerate(hidden):
+            pre = new(N, d.out_features)
+            if k + 1 < len(hidden):                  # activated output feeds the next layer; the pre-activation is kept
+                xa = new(N, d.out_features)
+                engine.gemm(x, d.in_features, c["w"][k], c["b"][k], xa, d.out_features, N, d.out_features, d.in_features,
+                            act=(0, d.out_features), pre_out=pre, kind=self.act_kind)
+                x = xa
+            else:                                    # last hidden layer: gn_head_energy applies the activation itself
+                engine.gemm(x, d.in_features, c["w"][k], c["b"][k], pre, d.out_features, N, d.out_features, d.in_features,
+                            kind=self.act_kind)
+            pres.append(pre)
+        last_in = pres[-1] if pres else h.contiguous()
+        act = self.act_kind if pres else 11          # GN_ACT_NONE: n_layers = 1, y = W h + b
+        y, e = new(N), new(n_mol, 1)
+        mean = self.aggregation_mode == "mean"
+        atom_scale = new(N) if mean else None
+        call("gn_head_energy", ptr(last_in), ptr(c["w"][-1]), c["b2"], c["scale"], c["shift"],
              ptr(self.atomref.weight.detach()) if self.atomref is not None else None, ptr(z32), ptr(mol_ptr),
-             n_mol, Hd, ptr(y), ptr(e), self.act_kind, engine._stream())
-        return e, y, pre1
+             n_mol, last_in.shape[1], ptr(y), ptr(e), int(mean), ptr(atom_scale), act, engine._stream())
+        return e, y, (pres, last_in, atom_scale)
 
-    def grad_h_raw(self, pre1: torch.Tensor, Fd: int) -> torch.Tensor:
-        """d(sum of energies)/dh [N,F]."""
-        d0, d1, c = self._packed()
-        N, Hd = pre1.shape
-        g1 = torch.empty_like(pre1)
-        call("gn_head_grad", ptr(pre1), ptr(d1.weight.detach()), c["scale"], N, Hd, ptr(g1), self.act_kind, engine._stream())
-        gh = torch.empty((N, Fd), dtype=torch.float32, device=pre1.device)
-        engine.gemm(g1, Hd, c["w1t"], None, gh, Fd, N, Fd, Hd)
-        return gh
+    def grad_h_raw(self, tape, Fd: int) -> torch.Tensor:
+        """d(sum over molecules of the aggregated property)/dh [N,F]."""
+        layers, c = self._packed()
+        pres, last_in, atom_scale = tape
+        N, Hd = last_in.shape
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=last_in.device)
+        g = new(N, Hd)
+        call("gn_head_grad", ptr(last_in), ptr(c["w"][-1]), c["scale"], ptr(atom_scale), N, Hd, ptr(g),
+             self.act_kind if pres else 11, engine._stream())
+        for k in range(len(pres) - 1, -1, -1):       # g is d/d(pre_k); through layer k's weight, then act'(pre_{k-1})
+            d = layers[k]
+            gi = new(N, d.in_features)
+            engine.gemm(g, d.out_features, c["wt"][k], None, gi, d.in_features, N, d.in_features, d.out_features,
+                        dgate=pres[k - 1] if k > 0 else None, kind=self.act_kind)
+            g = gi
+        return g
 
     # ---- reference-style call --------------------------------------------------------
     def forward(self, inputs):
@@ -146,7 +183,7 @@ class Atomwise(nn.Module):
             raise GotenNetHipError("gotennet_amd.outputs.Atomwise runs on a ROCm device only")
         n_mol = int(batch[-1].item()) + 1 if batch.numel() else 0
         y = _AtomwiseFn.apply(h, self, z.to(torch.int32), molecule_ptr(batch, n_mol), n_mol)
-        result = {self.property: y}
+        result = {self.property: y}                  # [n_mol,1], or the per-atom values [N,1] for aggregation_mode=None
         if self.contributions:
             result[self.contributions] = self._last_y.reshape(-1, 1)
         if self.derivative:
@@ -159,16 +196,16 @@ class Atomwise(nn.Module):
 class _AtomwiseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, head, z32, mol_ptr, n_mol):
-        e, y, pre1 = head.energy_raw(h.detach().contiguous(), z32, mol_ptr, n_mol)
+        e, y, tape = head.energy_raw(h.detach().contiguous(), z32, mol_ptr, n_mol)
         head._last_y = y
-        ctx.head, ctx.mol_ptr, ctx.n_mol, ctx.F = head, mol_ptr, n_mol, h.shape[1]
-        ctx.save_for_backward(pre1)
-        return e
+        ctx.head, ctx.mol_ptr, ctx.n_mol, ctx.F, ctx.tape = head, mol_ptr, n_mol, h.shape[1], tape
+        return y.reshape(-1, 1).clone() if head.aggregation_mode is None else e
 
     @staticmethod
     def backward(ctx, ge):
-        (pre1,) = ctx.saved_tensors
-        gh = ctx.head.grad_h_raw(pre1, ctx.F)
+        gh = ctx.head.grad_h_raw(ctx.tape, ctx.F)
+        if ctx.head.aggregation_mode is None:        # per-atom outputs: upstream gradient per atom
+            return gh * ge.reshape(-1, 1), None, None, None, None
         # per-molecule upstream gradient (ones for energies -> forces): row scale by ge[molecule]
         mp = ctx.mol_ptr.long()
         per_atom = torch.repeat_interleave(ge.reshape(-1), mp[1:] - mp[:-1])

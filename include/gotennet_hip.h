@@ -40,7 +40,8 @@ extern "C" {
  * shifted_softplus layers.py:40-50).  Wherever an entry point below says SiLU, it means this kind. */
 enum {
     GN_ACT_SILU = 0, GN_ACT_SSP = 1, GN_ACT_RELU = 2, GN_ACT_TANH = 3, GN_ACT_SIGMOID = 4, GN_ACT_ELU = 5,
-    GN_ACT_SELU = 6, GN_ACT_MISH = 7, GN_ACT_GELU = 8, GN_ACT_SOFTPLUS = 9, GN_ACT_LEAKY = 10, GN_ACT_COUNT = 11
+    GN_ACT_SELU = 6, GN_ACT_MISH = 7, GN_ACT_GELU = 8, GN_ACT_SOFTPLUS = 9, GN_ACT_LEAKY = 10,
+    GN_ACT_NONE = 11 /* identity: a head without hidden layer */, GN_ACT_COUNT = 12
 };
 
 /* Library identity: returns GN_ABI_VERSION; *arch_out (if non-NULL) receives "gfx950". */
@@ -315,8 +316,11 @@ int gn_pos_scatter(const float* g_vec, const float* g_diff, const float* edge_ve
  * pre1 = W1 h + b1 comes from gn_gemm.  mol_ptr [n_mol+1] int32.  head_grad: g_pre1 = scale W2 SiLU'(pre1). */
 int gn_head_energy(const float* pre1, const float* W2, float b2, float scale, float shift,
                    const float* atomref, const int* z, const int* mol_ptr, int n_mol, int Hd,
-                   float* y, float* energy, int act /* GN_ACT_* of the head MLP */, void* stream);
-int gn_head_grad(const float* pre1, const float* W2, float scale, int N, int Hd, float* g_pre1, int act, void* stream);
+                   float* y, float* energy, int mean /* aggregation_mode "mean": energy / atoms of the molecule */,
+                   float* atom_scale /* [N] or NULL: d energy / d y_n (1 or 1 / atoms) for gn_head_grad */,
+                   int act /* GN_ACT_* of the head MLP (GN_ACT_NONE: no hidden layer) */, void* stream);
+int gn_head_grad(const float* pre1, const float* W2, float scale, const float* atom_scale /* [N] or NULL */, int N, int Hd,
+                 float* g_pre1, int act, void* stream);
 
 /* ---- adjacent: radius graph (Distance.forward, layers.py:1588-1604) ----------------------- */
 /* torch_cluster.radius_graph(pos, r, batch, loop=True, max_num_neighbors) semantics: edges j->i with

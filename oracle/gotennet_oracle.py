@@ -480,10 +480,17 @@ def distance(pos: Tensor, batch: Tensor, cutoff: float, max_num_neighbors: int =
 # --------------------------------------------------------------------------- energy / forces
 def atomwise_contributions(head: Dict[str, Tensor], h: Tensor, z: Optional[Tensor] = None,
                            activation: str = "silu") -> Tensor:
-    """outputs.py:323-346: y_i = stddev * (W2 act(W1 h_i + b1) + b2) + mean [+ atomref[z_i]]."""
+    """outputs.py:323-346 over SchnetMLP (layers.py:225-273): every layer but the last is activated;
+    y_i = stddev * MLP(h_i) + mean [+ atomref[z_i]]."""
     act = activation_of(activation)
-    y = F.linear(act(F.linear(h, head["out_net.1.out_net.0.weight"], head["out_net.1.out_net.0.bias"])),
-                 head["out_net.1.out_net.1.weight"], head["out_net.1.out_net.1.bias"])
+    n = 0
+    while f"out_net.1.out_net.{n}.weight" in head:
+        n += 1
+    y = h
+    for k in range(n):
+        y = F.linear(y, head[f"out_net.1.out_net.{k}.weight"], head[f"out_net.1.out_net.{k}.bias"])
+        if k + 1 < n:
+            y = act(y)
     if "standardize.stddev" in head:
         y = y * head["standardize.stddev"] + head["standardize.mean"]
     if "atomref.weight" in head:
@@ -492,19 +499,22 @@ def atomwise_contributions(head: Dict[str, Tensor], h: Tensor, z: Optional[Tenso
 
 
 def atomwise_energy(head: Dict[str, Tensor], h: Tensor, batch: Tensor, n_mol: int,
-                    activation: str = "silu", z: Optional[Tensor] = None) -> Tensor:
-    """outputs.py:323-376 (Atomwise, aggregation "sum"): y = sum_{i in molecule} y_i."""
+                    activation: str = "silu", z: Optional[Tensor] = None, aggregation: str = "sum") -> Tensor:
+    """outputs.py:348-358: scatter of the per-atom values by molecule, reduce "sum" or "mean"."""
     y = atomwise_contributions(head, h, z, activation)
-    return torch.zeros((n_mol, y.shape[1]), dtype=y.dtype).index_add_(0, batch, y)
+    out = torch.zeros((n_mol, y.shape[1]), dtype=y.dtype).index_add_(0, batch, y)
+    if aggregation == "mean":
+        out = out / torch.bincount(batch, minlength=n_mol).clamp(min=1).to(y.dtype).unsqueeze(1)
+    return out
 
 
 def energy_and_forces(sd, cfg, head, z, pos, batch, n_mol, max_num_neighbors: int = 32,
-                      activation: str = "silu"):
+                      activation: str = "silu", aggregation: str = "sum"):
     """GotenNetWrapper.forward (gotennet.py:1043-1045) + Atomwise with
     derivative (outputs.py:365-375): F = -dE/dpos."""
     pos = pos.detach().clone().requires_grad_(True)
     ei, w, vec = distance(pos, batch, cfg["cutoff"], max_num_neighbors)
     h, X = gotennet_forward(sd, cfg, z, ei, w, vec)
-    e = atomwise_energy(head, h, batch, n_mol, activation, z=z)
+    e = atomwise_energy(head, h, batch, n_mol, activation, z=z, aggregation=aggregation)
     (g,) = torch.autograd.grad(e.sum(), pos)
     return e.detach(), -g, (h.detach(), X.detach(), ei)

@@ -31,6 +31,23 @@ def test_oracle_head_matches_reference_kat():
     assert rel_err(e, t["energy"]) < 1e-6
 
 
+def _head_kat3():
+    k = np.load(os.path.join(GOLDEN_DIR, "kat_head_l3_mean_ssp.npz"))
+    t = {n: torch.from_numpy(k[n]) for n in k.files if not n.startswith("head/")}
+    hsd = {n[5:]: torch.from_numpy(k[n]) for n in k.files if n.startswith("head/")}
+    return t, hsd
+
+
+def test_oracle_deep_head_matches_reference_kat():
+    """Three-layer pyramid head, the reference's default activation (shifted softplus), aggregation "mean"."""
+    from oracle import gotennet_oracle as orc
+    t, hsd = _head_kat3()
+    y = orc.atomwise_contributions(hsd, t["h"], t["z"], activation="softplus")
+    e = orc.atomwise_energy(hsd, t["h"], t["batch"], int(t["n_mol"]), activation="softplus", z=t["z"], aggregation="mean")
+    assert rel_err(y, t["contrib"]) < 1e-6
+    assert rel_err(e, t["energy"]) < 1e-6
+
+
 def test_weight_init_names_of_the_reference():
     """Every init name the reference accepts (layers.py:426-452) builds a module (checkpoints carry them as strings)."""
     import gotennet_amd
@@ -219,3 +236,70 @@ def test_training_mode_warns_once_and_stale_pack_is_refreshed():
         net(*args, ev)
         net(*args, ev)
     assert sum("inference" in str(x.message) for x in w) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.usefixtures("gemm_mode")
+def test_deep_head_mean_aggregation_against_reference():
+    """Atomwise(n_layers=3, aggregation_mode="mean") with the reference's default activation on the HIP path against the
+    reference's own head (tests/golden/kat_head_l3_mean_ssp.npz): per-atom contributions and per-molecule means."""
+    from gotennet_amd.outputs import Atomwise, molecule_ptr
+    t, hsd = _head_kat3()
+    head = Atomwise(n_in=t["h"].shape[1], n_layers=3, aggregation_mode="mean", property="property", contributions="contrib",
+                    mean=hsd["standardize.mean"], stddev=hsd["standardize.stddev"])
+    head.load_state_dict(hsd, strict=True)
+    head = head.cuda().eval()
+    n_mol = int(t["n_mol"])
+    e, y, _ = head.energy_raw(t["h"].cuda(), t["z"].cuda().to(torch.int32), molecule_ptr(t["batch"].cuda(), n_mol), n_mol)
+    assert rel_err(y.cpu(), t["contrib"].reshape(-1)) < 1e-5
+    assert rel_err(e.cpu(), t["energy"]) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_layers,n_hidden,agg,act", [(1, None, "sum", "silu"), (3, None, "mean", "softplus"),
+                                                     (3, [48, 24], "sum", "tanh"), (2, 40, None, "gelu"),
+                                                     (4, 32, "mean", "elu")])
+def test_head_shapes_energy_and_forces_match_oracle(n_layers, n_hidden, agg, act):
+    """Every SchnetMLP shape / aggregation the head accepts: energies (or per-atom values) and forces through the fused
+    pipeline and through the reference-style autograd call, against the oracle's autograd."""
+    import types
+    import gotennet_amd
+    from gotennet_amd.outputs import Atomwise
+    from gotennet_amd.pipeline import EnergyForces
+    from oracle import gotennet_oracle as orc
+    cfg, sd, _, t = load_case("l2_sep_f32")
+    F = cfg["n_atom_basis"]
+    torch.manual_seed(n_layers * 7 + len(act))
+    head = Atomwise(n_in=F, n_layers=n_layers, n_hidden=n_hidden, aggregation_mode=agg, activation=act, property="y",
+                    derivative="forces", mean=torch.tensor([0.3]), stddev=torch.tensor([1.7]))
+    with torch.no_grad():
+        for p in head.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.1, 0.1)
+    hsd = {k: v.clone() for k, v in head.state_dict().items()}
+    e_ref, f_ref, _ = orc.energy_and_forces({k: v.double() for k, v in sd.items()}, cfg, {k: v.double() for k, v in hsd.items()},
+                                            t["z"], t["pos"].double(), t["batch"], cfg["n_mol"], activation=act,
+                                            aggregation="mean" if agg == "mean" else "sum")
+    net = gotennet_amd.GotenNetWrapper(
+        n_atom_basis=F, n_interactions=cfg["n_interactions"], n_rbf=cfg["n_rbf"], cutoff_fn=gotennet_amd.CosineCutoff(cfg["cutoff"]),
+        max_z=cfg["max_z"], num_heads=cfg["num_heads"], scale_edge=cfg["scale_edge"], lmax=cfg["lmax"],
+        sep_dir=cfg["sep_dir"], sep_tensor=cfg["sep_tensor"])
+    net.load_state_dict(sd, strict=True)
+    net, head = net.cuda().eval(), head.cuda().eval()
+    e, f = EnergyForces(net, head)(t["z"].cuda(), t["edge_index"].cuda(), t["edge_diff"].cuda(), t["edge_vec"].cuda(),
+                                   t["batch"].cuda(), cfg["n_mol"])
+    assert rel_err(e.cpu(), e_ref) < TOL and rel_err(f.cpu(), f_ref) < TOL
+    # reference-style: representation + head.forward with autograd.grad inside
+    pos = t["pos"].cuda().requires_grad_(True)
+    inp = types.SimpleNamespace(z=t["z"].cuda(), pos=pos, batch=t["batch"].cuda())
+    inp.representation, inp.vector_representation = net(inp)
+    out = head(inp)
+    if agg is None:                                  # per-atom values, no scatter (outputs.py:354-358)
+        y_ref = orc.atomwise_contributions({k: v.double() for k, v in hsd.items()},
+                                           orc.gotennet_forward({k: v.double() for k, v in sd.items()}, cfg, t["z"], t["edge_index"],
+                                                                t["edge_diff"].double(), t["edge_vec"].double())[0],
+                                           t["z"], activation=act)
+        assert out["y"].shape == (t["z"].shape[0], 1) and rel_err(out["y"].detach().cpu(), y_ref) < TOL
+    else:
+        assert rel_err(out["y"].detach().cpu(), e_ref) < TOL
+    assert rel_err(out["forces"].detach().cpu(), f_ref) < TOL

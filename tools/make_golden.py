@@ -501,6 +501,18 @@ def head_kat():
         out["head/" + k] = v.numpy()
     np.savez_compressed(os.path.join(OUT, "kat_head.npz"), **out)
     print("kat_head written:", sorted(k for k in out if k.startswith("head/")))
+    # a deeper head with the reference's DEFAULT activation (shifted softplus), a pyramid of hidden widths and "mean"
+    head3 = ref_out.Atomwise(n_in=F_, n_layers=3, aggregation_mode="mean", property="property", contributions="contrib",
+                             mean=torch.tensor([-0.4]), stddev=torch.tensor([2.5]))
+    randomise(head3, 4200)
+    with torch.no_grad():
+        res3 = head3(_D(z=z, batch=batch, representation=h, vector_representation=None))
+    out3 = dict(h=h.numpy(), z=z.numpy(), batch=batch.numpy(), n_mol=np.array(n_mol), energy=res3["property"].numpy(),
+                contrib=res3["contrib"].numpy())
+    for k, v in head3.state_dict().items():
+        out3["head/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "kat_head_l3_mean_ssp.npz"), **out3)
+    print("kat_head_l3_mean_ssp written:", [tuple(v.shape) for k, v in head3.state_dict().items() if k.endswith("weight")])
 
 
 if __name__ == "__main__":
