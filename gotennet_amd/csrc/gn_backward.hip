@@ -16,25 +16,11 @@
 #include "gn_common.h"
 #include "gn_tune.h"
 #include "gn_sh.h"
+#include "gn_highl.h"
 
 namespace gn {
 
 
-// cross-slot fixed-order reduction of ROWS float4 accumulators; `wr(row, sum)` is called by
-// exactly one slot per row.  red: >= min(ROWS, 9) * 1024 floats of LDS.
-template <int ROWS, typename Writer>
-__device__ __forceinline__ void reduce_rows(float4 (&acc)[ROWS], float* red, int slot, int c0, int F, int ns, Writer wr) {
-    constexpr int CH = ROWS < 9 ? ROWS : 9;
-#pragma unroll
-    for (int base = 0; base < ROWS; base += CH) {
-        if (base) __syncthreads();
-#pragma unroll
-        for (int r = 0; r < CH; ++r)
-            if (base + r < ROWS) st4(&red[r * 1024 + slot * F + c0], acc[base + r]);
-        __syncthreads();
-        for (int r = slot; r < CH && base + r < ROWS; r += ns) wr(base + r, red4(red + r * 1024, c0, F, ns));
-    }
-}
 
 // =========================================================================== HTR backward
 // w = sum_l [ A.B - (2 - r.r)(A.r)(B.r) ],  A = EQ_i block, B = EK_j block, r = rl block
@@ -166,31 +152,6 @@ struct MsgShape {
     __host__ __device__ static constexpr int first_row(int l) { return l * l - 1; }     // first m of degree l
 };
 
-struct MsgBwdArgs {
-    // saved forward tensors
-    const float* x; const float* v; int ldxv;          // [N, M F]
-    const float* eproj; int lde;                       // [E, (1+M) F]: pre_ta | t_filter
-    const float* a;                                    // [E, H] attention weights (softmax * norm)
-    const float* qk; int ldqk;                         // q at col 0, k at col F
-    const float* X_in;                                 // [N, D, F] layer input X
-    const float* rl; const float* cut;
-    const int* outdeg;                                 // scale_edge (or NULL)
-    // upstream gradients
-    const float* g_h1; const float* g_X1;              // [N,F], [N,D,F]
-    // graph
-    const int* rowptr; const int* src; const int* dst;   // dst: target of the pp-th BY-SOURCE entry (= CSR dst[perm[pp]])
-    const int* colptr; const int* perm;
-    // outputs
-    float* g_eproj;                                    // [E, (1+M) F]: d/d(W_re t + b) | d/d t_filter
-    float* g_s;                                        // [E, H] scratch: g_a then g_s
-    float* g_nproj; int ldn;                           // [N, 4F]: g_q at col 0, g_k at col F
-    float* g_x; float* g_v;                            // [N, M F]
-    float* g_X_out;                                    // [N, D, F] = g_X1 + source part
-    float* g_rl; float* g_cut;                         // this call's slice (written, not accumulated)
-    int N, F, H;
-    float inv_sqrt_f;
-    int act;                                           // GN_ACT_*: t_attn = act(W_re t + b)
-};
 
 // by-target pass: g_tf, g_cut, g_rl, attention backward (g_a -> g_s), g_ta, g_q
 // (body in a forceinline function with __restrict__ parameters: with the pointers read from the argument struct the
@@ -1004,15 +965,30 @@ static bool bwd_dim_ok(int F) { return F >= 16 && F <= 256 && gn::is_pow2(F); }
         default: hipLaunchKernelGGL(gn::KERNEL<4>, grid, block, 0, st, __VA_ARGS__); break;            \
     }
 
+#define GN_SWITCH_LMAX8(KERNEL, grid, block, st, ...)                                                  \
+    switch (lmax) {                                                                                    \
+        case 1: hipLaunchKernelGGL(gn::KERNEL<1>, grid, block, 0, st, __VA_ARGS__); break;             \
+        case 2: hipLaunchKernelGGL(gn::KERNEL<2>, grid, block, 0, st, __VA_ARGS__); break;             \
+        case 3: hipLaunchKernelGGL(gn::KERNEL<3>, grid, block, 0, st, __VA_ARGS__); break;             \
+        case 4: hipLaunchKernelGGL(gn::KERNEL<4>, grid, block, 0, st, __VA_ARGS__); break;             \
+        case 5: hipLaunchKernelGGL(gn::KERNEL<5>, grid, block, 0, st, __VA_ARGS__); break;             \
+        case 6: hipLaunchKernelGGL(gn::KERNEL<6>, grid, block, 0, st, __VA_ARGS__); break;             \
+        case 7: hipLaunchKernelGGL(gn::KERNEL<7>, grid, block, 0, st, __VA_ARGS__); break;             \
+        default: hipLaunchKernelGGL(gn::KERNEL<8>, grid, block, 0, st, __VA_ARGS__); break;            \
+    }
+
 extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* w, const float* w_raw,
                                const float* EQ,
                                const float* EK, const float* rl, const int* rowptr, const int* src, const int* dst,
                                const int* colptr, const int* perm, int N, int F, int lmax, int mode,
                                float* gEQ, float* gEK, float* g_rl, float* g_pre_t, int act, void* stream) {
-    if (!bwd_dim_ok(F) || N < 0 || lmax < 1 || lmax > 4 || mode < 0 || mode > 31 || act < 0 || act >= GN_ACT_COUNT)
+    if (!bwd_dim_ok(F) || N < 0 || lmax < 1 || lmax > 8 || mode < 0 || mode > 31 || act < 0 || act >= GN_ACT_COUNT)
         return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (gn_use_highl(lmax))
+        return gn_highl_htr_backward(g_t_out, pre_t, w, w_raw, EQ, EK, rl, rowptr, src, dst, colptr, perm, N, F, lmax,
+                                     mode, gEQ, gEK, g_rl, g_pre_t, act, st);
     if (mode)
         return gn_htr_backward_general(g_t_out, pre_t, w, w_raw, EQ, EK, rl, rowptr, src, dst, colptr, perm, N, F, lmax,
                                        mode, gEQ, gEK, g_rl, g_pre_t, act, st);
@@ -1042,6 +1018,7 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
     } while (0)
 
 extern "C" int gn_message_backward_groups(int lmax, int sep_dir, int sep_tensor) {
+    if (gn_use_highl(lmax)) return 1;                  // degree-sliced kernels (gn_highl.hip): one slice
     return (lmax >= 3 && sep_dir && sep_tensor) ? lmax - 1 : 1;
 }
 
@@ -1053,7 +1030,7 @@ extern "C" int gn_message_backward(
     float* g_eproj, float* g_s, float* g_nproj, int ldn, float* g_x, float* g_v, float* g_X_out,
     float* g_rl, float* g_cut, float* ga_parts, long E,
     int N, int F, int H, int lmax, int sep_dir, int sep_tensor, int act, void* stream) {
-    if (!bwd_dim_ok(F) || N < 0 || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || lmax < 1 || lmax > 4 ||
+    if (!bwd_dim_ok(F) || N < 0 || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || lmax < 1 || lmax > 8 ||
         (ldxv & 3) || (lde & 3) || (ldqk & 3) || (ldn & 3) || g_X_out == g_X1 || act < 0 || act >= GN_ACT_COUNT)
         return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
@@ -1062,6 +1039,7 @@ extern "C" int gn_message_backward(
                      N, F, H, (float)(1.0 / sqrt((double)F)), act};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(gn::xcd_grid(N)), block(256);
+    if (gn_use_highl(lmax)) return gn_highl_message_backward(p, lmax, sep_dir, sep_tensor, st);
     if (gn_message_backward_groups(lmax, sep_dir, sep_tensor) > 1) {
         // degree groups: target passes (head sums and cut slices per group) -> attention backward -> source passes
         if (ga_parts == nullptr || E <= 0) return GN_ERR_BAD_ARG;
@@ -1171,11 +1149,11 @@ extern "C" int gn_edge_geometry_backward(const float* edge_vec, const float* edg
                                          int E, int lmax, int R, int basis, const float* means, const float* betas,
                                          float cutoff, const float* g_rl, int n_rl, const float* g_cut, int n_cut,
                                          const float* g_phi, float* g_vec, float* g_diff, void* stream) {
-    if (E < 0 || lmax < 1 || lmax > 4 || R <= 0 || n_rl < 0 || n_cut < 0 || basis < 0 || basis > 2) return GN_ERR_BAD_ARG;
+    if (E < 0 || lmax < 1 || lmax > 8 || R <= 0 || n_rl < 0 || n_cut < 0 || basis < 0 || basis > 2) return GN_ERR_BAD_ARG;
     if (E == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((E + 127) / 128), block(128);
-    GN_SWITCH_LMAX(edge_geometry_bwd_kernel, grid, block, st, edge_vec, edge_diff, src, dst, E, R, basis, means, betas,
+    GN_SWITCH_LMAX8(edge_geometry_bwd_kernel, grid, block, st, edge_vec, edge_diff, src, dst, E, R, basis, means, betas,
                    cutoff, 5.0f / cutoff, g_rl, n_rl, g_cut, n_cut, g_phi, g_vec, g_diff);
     GN_LAUNCH_CHECK();
     return GN_OK;

@@ -197,7 +197,7 @@ extern "C" int gn_out_degree(const int* src, int E, int* outdeg, void* stream) {
 extern "C" int gn_edge_geometry(const float* edge_vec, const float* edge_diff, const int* src, const int* dst, int E,
                                 int lmax, int R, int basis, const float* means, const float* betas, float cutoff,
                                 float* rl, float* phi, float* cut, void* stream) {
-    if (E < 0 || lmax < 1 || lmax > 4 || R <= 0 || basis < 0 || basis > 2) return GN_ERR_BAD_ARG;
+    if (E < 0 || lmax < 1 || lmax > 8 || R <= 0 || basis < 0 || basis > 2) return GN_ERR_BAD_ARG;
     if (E == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((E + 255) / 256), block(256);
@@ -205,7 +205,11 @@ extern "C" int gn_edge_geometry(const float* edge_vec, const float* edge_diff, c
         case 1: hipLaunchKernelGGL(gn::edge_sh_kernel<1>, grid, block, 0, st, edge_vec, edge_diff, src, dst, E, cutoff, rl, cut); break;
         case 2: hipLaunchKernelGGL(gn::edge_sh_kernel<2>, grid, block, 0, st, edge_vec, edge_diff, src, dst, E, cutoff, rl, cut); break;
         case 3: hipLaunchKernelGGL(gn::edge_sh_kernel<3>, grid, block, 0, st, edge_vec, edge_diff, src, dst, E, cutoff, rl, cut); break;
-        default: hipLaunchKernelGGL(gn::edge_sh_kernel<4>, grid, block, 0, st, edge_vec, edge_diff, src, dst, E, cutoff, rl, cut); break;
+        case 4: hipLaunchKernelGGL(gn::edge_sh_kernel<4>, grid, block, 0, st, edge_vec, edge_diff, src, dst, E, cutoff, rl, cut); break;
+        case 5: hipLaunchKernelGGL(gn::edge_sh_kernel<5>, grid, block, 0, st, edge_vec, edge_diff, src, dst, E, cutoff, rl, cut); break;
+        case 6: hipLaunchKernelGGL(gn::edge_sh_kernel<6>, grid, block, 0, st, edge_vec, edge_diff, src, dst, E, cutoff, rl, cut); break;
+        case 7: hipLaunchKernelGGL(gn::edge_sh_kernel<7>, grid, block, 0, st, edge_vec, edge_diff, src, dst, E, cutoff, rl, cut); break;
+        default: hipLaunchKernelGGL(gn::edge_sh_kernel<8>, grid, block, 0, st, edge_vec, edge_diff, src, dst, E, cutoff, rl, cut); break;
     }
     GN_LAUNCH_CHECK();
     const size_t tot = (size_t)E * R;

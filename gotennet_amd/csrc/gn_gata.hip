@@ -9,6 +9,7 @@
 // molecule are re-read through a single XCD's L2.
 #include "gn_common.h"
 #include "gn_tune.h"
+#include "gn_highl.h"
 
 namespace gn {
 
@@ -389,11 +390,20 @@ static int message_launch(const float* x, const float* v, int ldxv, const float*
                           gn::AttnIn at, bool fuse, const float* rl, const float* cut, const int* rowptr, const int* src,
                           const float* h_in, const float* X_in, float* h_out, float* X_out,
                           int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream) {
-    if (!feature_dim_ok(F) || N < 0 || H <= 0 || lmax < 1 || lmax > 4 || (ldxv & 3) || (ldt & 3) || X_in == X_out)
+    if (!feature_dim_ok(F) || N < 0 || H <= 0 || lmax < 1 || lmax > 8 || (ldxv & 3) || (ldt & 3) || X_in == X_out)
         return GN_ERR_BAD_ARG;
     const int M = 1 + (sep_dir ? lmax : 1) + (sep_tensor ? lmax : 1);
     if ((M * F) % H || ((M * F) / H) % 4) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
+    if (gn_use_highl(lmax)) {                          // degrees 5..8: one launch per degree (gn_highl.hip)
+        if (fuse) {                                    // attention weights first, as a launch of their own
+            hipLaunchKernelGGL(gn::attn_softmax_kernel, dim3(gn::xcd_grid(N)), dim3(256), 0, (hipStream_t)stream,
+                               at.q, at.k, at.ldqk, at.ta, ldt, rowptr, src, at.outdeg, N, F, H, at.inv_sqrt_f, a, at.act);
+            GN_LAUNCH_CHECK();
+        }
+        return gn_highl_message(x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in, h_out, X_out, N, F, H,
+                                lmax, sep_dir, sep_tensor, (hipStream_t)stream);
+    }
     const int key = lmax * 4 + (sep_dir ? 2 : 0) + (sep_tensor ? 1 : 0);
     switch (key) {
         case 4: case 5: case 6: case 7: GN_MSG_LAUNCH(1, false, false); break;   // lmax = 1: flags are no-ops
@@ -438,9 +448,10 @@ extern "C" int gn_message_fused(const float* q, const float* k, int ldqk, const 
 
 extern "C" int gn_htr_edge(const float* EQ, const float* EK, const float* rl, const int* rowptr, const int* src,
                            int N, int F, int lmax, int mode, float* w_raw, float* w, void* stream) {
-    if (!feature_dim_ok(F) || N < 0 || lmax < 1 || lmax > 4 || mode < 0 || mode > 15) return GN_ERR_BAD_ARG;
+    if (!feature_dim_ok(F) || N < 0 || lmax < 1 || lmax > 8 || mode < 0 || mode > 15) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (gn_use_highl(lmax)) return gn_highl_htr_edge(EQ, EK, rl, rowptr, src, N, F, lmax, mode, w_raw, w, st);
     if (mode) return gn_htr_edge_general(EQ, EK, rl, rowptr, src, N, F, lmax, mode, w_raw, w, st);
     const dim3 grid(gn::xcd_grid(N)), block(256);
     switch (lmax) {

@@ -6,29 +6,11 @@
 // variants trade a second pass over the [D, F] rows (L1/L2 hits) for lower register pressure, the default
 // configuration never reaches them.
 #include "gn_common.h"
+#include "gn_highl.h"
 
 namespace gn {
 
 
-// gamma_w (gotennet.py:285-291): 0 identity, 1 nn.Sigmoid ("gated"), 2 nn.Tanh ("gatedt"), 3 nn.SiLU ("act")
-__device__ __forceinline__ float gate1(float x, int kind) {
-    switch (kind) {
-        case 1: return 1.0f / (1.0f + expf(-x));
-        case 2: return tanhf(x);
-        case 3: return silu(x);
-        default: return x;
-    }
-}
-__device__ __forceinline__ float dgate1(float x, int kind) {
-    switch (kind) {
-        case 1: { const float s = 1.0f / (1.0f + expf(-x)); return s * (1.0f - s); }
-        case 2: { const float t = tanhf(x); return 1.0f - t * t; }
-        case 3: return dsilu(x);
-        default: return 1.0f;
-    }
-}
-__device__ __forceinline__ float4 gate4(float4 v, int k) { return make_float4(gate1(v.x, k), gate1(v.y, k), gate1(v.z, k), gate1(v.w, k)); }
-__device__ __forceinline__ float4 dgate4(float4 v, int k) { return make_float4(dgate1(v.x, k), dgate1(v.y, k), dgate1(v.z, k), dgate1(v.w, k)); }
 
 // row m (0-based, l = 0 omitted) closes degree l when m + 2 = (l + 1)^2
 __host__ __device__ constexpr bool closes_degree(int m) {
@@ -225,10 +207,10 @@ __global__ __launch_bounds__(256) void htr_bwd_source_general_kernel(
 // (denominator 1 when max = min), out = relu(n_f) * X / c_f * weight_f.
 __device__ __forceinline__ float wave_min(float v) { return -wave_max(-v); }
 
-template <int LMAX>
 __global__ __launch_bounds__(256) void tensor_norm_kernel(
-    const float* __restrict__ X, const float* __restrict__ weight, float eps, int N, int F, float* __restrict__ Y) {
-    constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
+    const float* __restrict__ X, const float* __restrict__ weight, float eps, int N, int F, int LMAX,
+    float* __restrict__ Y) {
+    const int D = (LMAX + 1) * (LMAX + 1) - 1;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (item >= N * LMAX) return;
@@ -261,11 +243,10 @@ __global__ __launch_bounds__(256) void tensor_norm_kernel(
 // d_delta = -(sum_f dn_f (c_f - mn)) / delta^2 (0 when max = min), d_mx = d_delta, d_mn = -(sum_f dn_f) / delta - d_delta;
 // g_x[m,f] = g_out[m,f] w_f relu(n_f) / c_f + d c_f * [s_f >= eps] x[m,f] / s_f      (torch.max/min route the
 // gradient to ONE index: the first extremal channel, as the CPU oracle does.)
-template <int LMAX>
 __global__ __launch_bounds__(256) void tensor_norm_bwd_kernel(
     const float* __restrict__ X, const float* __restrict__ weight, const float* __restrict__ gY, float eps,
-    int N, int F, float* __restrict__ gX) {
-    constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
+    int N, int F, int LMAX, float* __restrict__ gX) {
+    const int D = (LMAX + 1) * (LMAX + 1) - 1;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (item >= N * LMAX) return;
@@ -391,22 +372,22 @@ int gn_htr_backward_general(const float* g_t_out, const float* pre_t, const floa
 
 extern "C" int gn_tensor_norm(const float* X, const float* weight, float eps, int N, int F, int lmax, float* Y,
                               void* stream) {
-    if (N < 0 || F <= 0 || lmax < 1 || lmax > 4) return GN_ERR_BAD_ARG;
+    if (N < 0 || F <= 0 || lmax < 1 || lmax > 8) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((N * lmax + 3) / 4), block(256);
-    GN_OPT_SWITCH(tensor_norm_kernel, grid, block, st, X, weight, eps, N, F, Y);
+    hipLaunchKernelGGL(gn::tensor_norm_kernel, grid, block, 0, st, X, weight, eps, N, F, lmax, Y);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
 
 extern "C" int gn_tensor_norm_backward(const float* X, const float* weight, const float* g_Y, float eps, int N, int F,
                                        int lmax, float* g_X, void* stream) {
-    if (N < 0 || F <= 0 || lmax < 1 || lmax > 4) return GN_ERR_BAD_ARG;
+    if (N < 0 || F <= 0 || lmax < 1 || lmax > 8) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((N * lmax + 3) / 4), block(256);
-    GN_OPT_SWITCH(tensor_norm_bwd_kernel, grid, block, st, X, weight, g_Y, eps, N, F, g_X);
+    hipLaunchKernelGGL(gn::tensor_norm_bwd_kernel, grid, block, 0, st, X, weight, g_Y, eps, N, F, lmax, g_X);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }

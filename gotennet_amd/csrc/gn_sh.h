@@ -1,11 +1,17 @@
-// gn_sh.h -- real harmonics of a unit vector, degrees 1..LMAX (LMAX <= 4), l = 0 omitted.
+// gn_sh.h -- real harmonics of a unit vector, degrees 1..LMAX (LMAX <= 8), l = 0 omitted.
 //
-// Restates TensorInit._calculate_components (reference layers.py:805-902): the
+// Restates TensorInit._calculate_components (reference layers.py:805-1494): the
 // degree-1 block is (x, y, z); degree 2 uses the closed polynomials; degrees 3 and 4
-// are the e3nn-style recursions on the degree below.  The same literal expression
-// order is kept so fp32 rounding stays close to the reference.  Templated on the
-// scalar type so the backward pass can push dual numbers through the same code.
+// are the e3nn-style recursions on the degree below, and so are degrees 5..8
+// (gn_sh_high.h, generated: tools/gen_sh_table.py derives the coupling coefficients).
+// The same literal expression order is kept for degrees <= 4 so fp32 rounding stays
+// close to the reference.  NOTE the reference's degree 3 mixes the recursion (rows
+// 0, 1, 5, 6) with closed polynomials in another normalisation (rows 2, 3, 4), so its
+// degrees >= 3 are NOT rotation-covariant harmonics: sum_m Y_3m^2 varies between 2.5 and
+// 7 over the sphere.  This file follows the reference, not the textbook.  Templated on
+// the scalar type so the backward pass can push dual numbers through the same code.
 #pragma once
+#include "gn_sh_high.h"
 
 namespace gn {
 
@@ -56,6 +62,10 @@ __host__ __device__ inline void real_harmonics(const T x, const T y, const T z, 
                 s4[6] = -k3 * s3[0] * x - k5 * s3[2] * x + k5 * s3[4] * z + k4 * s3[5] * y - k3 * s3[6] * z;
                 s4[7] = -k2 * s3[1] * x + k2 * s3[5] * z + k1 * s3[6] * y;
                 s4[8] = k0 * (-s3[0] * x + s3[6] * z);
+                if constexpr (LMAX >= 5) sh_raise_5(o + 15, x, y, z, o + 24);
+                if constexpr (LMAX >= 6) sh_raise_6(o + 24, x, y, z, o + 35);
+                if constexpr (LMAX >= 7) sh_raise_7(o + 35, x, y, z, o + 48);
+                if constexpr (LMAX >= 8) sh_raise_8(o + 48, x, y, z, o + 63);
             }
         }
     }

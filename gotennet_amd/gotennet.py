@@ -361,8 +361,8 @@ class GotenNet(nn.Module):
             bias_init = get_weight_init_by_string(bias_init)
         self.act_kind = activation_kind(activation)
         activation = resolve_activation(activation)
-        if not 1 <= lmax <= 4:
-            raise NotImplementedError("the MI355X kernels are instantiated for 1 <= lmax <= 4")
+        if not 1 <= lmax <= 8:                       # TensorInit is defined up to l = 8 (reference layers.py:805-1494)
+            raise NotImplementedError("TensorInit (and the MI355X kernels) cover 1 <= lmax <= 8")
 
         self.n_atom_basis = self.hidden_dim = n_atom_basis
         self.n_interactions = n_interactions

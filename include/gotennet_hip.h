@@ -20,8 +20,11 @@
  *
  * Symbols: N atoms, E directed edges in CSR-by-target order (edge e runs
  * src[e] = j  ->  dst = i, rowptr[i] <= e < rowptr[i+1]), F = n_atom_basis,
- * H = num_heads, lmax in [1,4], D = (lmax+1)^2 - 1, M = multiplier (number of
- * F-wide blocks in the value vector, gotennet.py:197-203), R = n_rbf.
+ * H = num_heads, lmax in [1,8] (the range of the reference's TensorInit, layers.py:805-1494), D = (lmax+1)^2 - 1,
+ * M = multiplier (number of F-wide blocks in the value vector, gotennet.py:197-203), R = n_rbf.
+ * lmax <= 4 runs the register-tiled kernels (the benchmarked configurations); lmax 5..8 the degree-sliced ones
+ * (gn_highl.hip: one launch per degree, same arithmetic per row, same fixed-order reductions) behind the SAME
+ * entry points.
  */
 #ifndef GOTENNET_HIP_H
 #define GOTENNET_HIP_H
@@ -259,8 +262,8 @@ int gn_message_backward(const float* x, const float* v, int ldxv, const float* e
                         float* g_eproj, float* g_s, float* g_nproj, int ldn, float* g_x, float* g_v,
                         float* g_X_out, float* g_rl, float* g_cut, float* ga_parts, long E,
                         int N, int F, int H, int lmax, int sep_dir, int sep_tensor, int act, void* stream);
-/* Number of degree groups G the message backward uses for these flags (1 = monolithic kernels; lmax >= 3 with
- * sep_dir and sep_tensor: {scalar,1,2}, {3}, {4}).  g_cut must then hold G consecutive [E] slices and ga_parts
+/* Number of degree groups G the message backward uses for these flags (1 = monolithic kernels, and lmax >= 5;
+ * lmax 3..4 with sep_dir and sep_tensor: {scalar,1,2}, {3}, {4}).  g_cut must then hold G consecutive [E] slices and ga_parts
  * G x [E,H] floats of workspace. */
 int gn_message_backward_groups(int lmax, int sep_dir, int sep_tensor);
 

@@ -23,9 +23,11 @@ checkpoint can be fed to the oracle unchanged.
 """
 from __future__ import annotations
 
+import functools
 import math
 from typing import Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -155,11 +157,58 @@ def radial_basis(sd: Dict[str, Tensor], cfg: dict, d: Tensor) -> Tensor:
     raise ValueError(f"Unknown radial basis: {kind}")
 
 
+def _proper_harmonics(l: int, x, y, z):
+    """Component-normalised real harmonics of degree l (numpy, homogeneous closed form): polar axis y, azimuth from z
+    towards x, index m + l -- the basis the reference's degree-raising recursion couples in."""
+    X, Y, Z = z, x, y
+    r2 = X * X + Y * Y + Z * Z
+    A, B = [np.ones_like(X)], [np.zeros_like(X)]
+    for _ in range(l):
+        A, B = A + [X * A[-1] - Y * B[-1]], B + [X * B[-1] + Y * A[-1]]
+    out = [None] * (2 * l + 1)
+    for m in range(l + 1):
+        q0 = float(np.prod(np.arange(1, 2 * m, 2))) * np.ones_like(X)
+        Q = q0
+        if l > m:
+            q1 = (2 * m + 1) * Z * q0
+            for ll in range(m + 2, l + 1):
+                q0, q1 = q1, ((2 * ll - 1) * Z * q1 - (ll + m - 1) * r2 * q0) / (ll - m)
+            Q = q1
+        if m == 0:
+            out[l] = math.sqrt(2 * l + 1) * Q
+        else:
+            n = math.sqrt(2.0 * math.factorial(l - m) / math.factorial(l + m) * (2 * l + 1))
+            out[l + m], out[l - m] = n * Q * A[m], n * Q * B[m]
+    return np.stack(out, -1)
+
+
+@functools.lru_cache(maxsize=None)
+def harmonic_raise_table(l: int):
+    """T_l [2l+1, 2l-1, 3] of the reference's recursion  sh_l[i] = sum_{j,a} T_l[i,j,a] sh_{l-1}[j] r_a
+    (layers.py:934-1494, degrees 5..8; degree 4, layers.py:869-902, is the same construction and is the check in
+    tests/test_oracle_golden.py).  T_l is the (l-1) x 1 -> l coupling of the real harmonics: computed here as the Gaunt
+    integral  Int Y_l,i Y_{l-1},j r_a dOmega  (Gauss-Legendre x uniform quadrature, exact for these polynomials), scaled
+    to the reference's leading coefficient T_l[0, 0, z] = sqrt((2l+1) / (2l)).  Pinned by the reference KAT
+    tests/golden/kat_sh_l8.npz."""
+    ct, wt = np.polynomial.legendre.leggauss(24)
+    phi = (np.arange(48) + 0.5) * 2 * np.pi / 48
+    CT, PH = np.meshgrid(ct, phi, indexing="ij")
+    W = (np.repeat(wt[:, None], 48, 1) * (2 * np.pi / 48) / (4 * np.pi)).ravel()
+    st = np.sqrt(1 - CT ** 2)
+    x, y, z = (st * np.cos(PH)).ravel(), (st * np.sin(PH)).ravel(), CT.ravel()
+    T = np.einsum("p,pi,pj,pa->ija", W, _proper_harmonics(l, x, y, z), _proper_harmonics(l - 1, x, y, z),
+                  np.stack([x, y, z], -1))
+    T[np.abs(T) < 1e-12] = 0.0
+    return T * (math.sqrt((2 * l + 1) / (2 * l)) / T[0, 0, 2])
+
+
 def real_harmonics(lmax: int, u: Tensor) -> Tensor:
-    """layers.py:805-902 for lmax <= 4: literal polynomial formulas on the unit
-    vector ``u[..., 3]``, l = 0 omitted, order (x, y, z) for l = 1."""
-    if not 1 <= lmax <= 4:
-        raise NotImplementedError("oracle restates TensorInit for 1 <= lmax <= 4")
+    """layers.py:805-1494: literal polynomial formulas for degrees <= 4 on the unit vector ``u[..., 3]``, l = 0
+    omitted, order (x, y, z) for l = 1; degrees 5..8 by the reference's recursion on the degree below with the
+    coefficient tables of ``harmonic_raise_table``."""
+    if not 1 <= lmax <= 8:
+        raise NotImplementedError("TensorInit is defined for 1 <= lmax <= 8")
+    full_lmax, lmax = lmax, min(lmax, 4)
     x, y, z = u[..., 0], u[..., 1], u[..., 2]
     out = [x, y, z]
     if lmax >= 2:
@@ -201,6 +250,21 @@ def real_harmonics(lmax: int, u: Tensor) -> Tensor:
             (3 / 4) * q2 * (-s3[0] * x + s3[6] * z),
         ]
         out += s4
+    prev = out[15:24] if full_lmax > 4 else None
+    for l in range(5, full_lmax + 1):
+        T = torch.as_tensor(harmonic_raise_table(l), dtype=u.dtype)
+        r = (x, y, z)
+        cur = []
+        for i in range(2 * l + 1):
+            acc = None
+            for j in range(2 * l - 1):
+                for a in range(3):
+                    if T[i, j, a] != 0:
+                        term = T[i, j, a] * (prev[j] * r[a])
+                        acc = term if acc is None else acc + term
+            cur.append(acc)
+        out += cur
+        prev = cur
     return torch.stack(out, dim=-1)
 
 

@@ -88,7 +88,8 @@ def test_unsupported_flags_raise_before_launch():
     for act in ("relu", "tanh", "softplus", "Swish", "leaky_relu", torch.nn.functional.gelu, torch.nn.Mish()):
         assert gotennet_amd.GotenNet(cutoff_fn=cut, n_atom_basis=32, n_interactions=1, n_rbf=8, activation=act).act_kind >= 0
     with pytest.raises(NotImplementedError):
-        gotennet_amd.GotenNet(cutoff_fn=cut, lmax=5)
+        gotennet_amd.GotenNet(cutoff_fn=cut, lmax=9)          # the reference's TensorInit stops at l = 8
+    assert gotennet_amd.GotenNet(cutoff_fn=cut, n_atom_basis=32, n_interactions=1, n_rbf=8, lmax=8).config().D == 80
     with pytest.raises(NotImplementedError):
         gotennet_amd.GotenNet(cutoff_fn=cut, edge_ln="batch")
     with pytest.raises(NotImplementedError):

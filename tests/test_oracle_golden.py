@@ -1,4 +1,5 @@
 """CPU: the oracle (oracle/gotennet_oracle.py) against the reference's golden vectors."""
+import math
 import os
 
 import numpy as np
@@ -68,6 +69,26 @@ def test_basis_known_answers():
     # d = 0 (self-loop): C = 1, phi_k = exp(-beta (1 - mu_k)^2); d >= cutoff: 0
     assert float(orc.cosine_cutoff(d, 5.0)[0]) == 1.0
     assert float(orc.cosine_cutoff(d, 5.0)[-2]) == 0.0
+
+
+def test_high_degree_harmonics_known_answers():
+    """Degrees 5..8: the oracle's derived coupling tables against the reference's own formulas (layers.py:934-1494) on
+    unit, axis, zero and NON-unit vectors; the same derivation reproduces the hand-restated degree-4 constants."""
+    k = np.load(os.path.join(GOLDEN_DIR, "kat_sh_l8.npz"))
+    v = torch.from_numpy(k["vec"])
+    for l in (5, 6, 7, 8):
+        got = orc.real_harmonics(l, v)
+        want = torch.from_numpy(k[f"sh{l}"])
+        assert got.shape == want.shape == (v.shape[0], (l + 1) ** 2 - 1)
+        assert torch.allclose(got, want, rtol=1e-12, atol=1e-13), l
+    assert float(orc.real_harmonics(8, v)[-1].abs().max()) == 0.0          # zero vector (self-loop direction)
+    T4 = orc.harmonic_raise_table(4)
+    assert abs(T4[0, 0, 2] - 0.75 * math.sqrt(2)) < 1e-12 and abs(T4[4, 3, 1] - 3 / 7 * math.sqrt(7)) < 1e-12
+    assert abs(T4[2, 2, 2] - 3 / 56 * math.sqrt(210)) < 1e-12 and np.count_nonzero(T4) == 31
+    # the reference's degrees >= 3 are not rotation-covariant (degree 3 mixes two normalisations): documented quirk
+    u = v[:32]
+    n3 = orc.real_harmonics(3, u)[:, 8:15].pow(2).sum(1)
+    assert float(n3.max() - n3.min()) > 1.0
 
 
 def test_segment_softmax_single_edge_and_empty():

@@ -98,6 +98,17 @@ CASES = {
     "opt_act_mish_l4": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=4, num_heads=8, scale_edge=False,
                              sep_dir=True, sep_tensor=True, max_z=10, activation="mish"),
                         dict(mols=[6], box=2.6, seed=34)),
+    # degrees 5..8 (TensorInit's recursion beyond l = 4, layers.py:934-1494; every per-degree structure at its widest)
+    "l5_sep_f32": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=5, num_heads=8, scale_edge=False,
+                        sep_dir=True, sep_tensor=True, max_z=10), dict(mols=[5], box=2.6, seed=41)),
+    "l6_nosep_scale_f32": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=6, num_heads=4, scale_edge=True,
+                                sep_dir=False, sep_tensor=False, max_z=10), dict(mols=[4, 3], box=2.6, seed=42)),
+    "l7_mixed_jointhtr_gated": (dict(n_atom_basis=32, n_interactions=3, n_rbf=8, lmax=7, num_heads=8, scale_edge=False,
+                                     sep_dir=True, sep_tensor=False, max_z=10, sep_htr=False, edge_updates="gated"),
+                                dict(mols=[5], box=2.6, seed=43)),
+    "l8_sep_tln_f32": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=8, num_heads=8, scale_edge=True,
+                            sep_dir=True, sep_tensor=True, max_z=10, steerable_norm="tensor"),
+                       dict(mols=[4], box=2.4, seed=44)),
     "opt_evec16_emlp48": (dict(n_atom_basis=32, n_interactions=3, n_rbf=8, lmax=2, num_heads=8, scale_edge=False,
                                sep_dir=True, sep_tensor=True, max_z=10, activation="silu",
                                edge_updates="mlpa_linwa_postln_gatedt", edge_ln="layer", evec_dim=16, emlp_dim=48),
@@ -469,6 +480,20 @@ def sh_kat():
     print("kat_basis written")
 
 
+def sh_kat_high():
+    """Known-answer table for TensorInit at l = 5..8 (layers.py:934-1494) on unit vectors, the axes, a zero vector
+    and a few NON-unit vectors (the formulas are polynomials; the recursion must match off the sphere too)."""
+    g = torch.Generator().manual_seed(8)
+    v = torch.randn((40, 3), generator=g, dtype=torch.float64)
+    v[:32] = v[:32] / v[:32].norm(dim=1, keepdim=True)
+    v = torch.cat([v, torch.eye(3, dtype=torch.float64), torch.zeros((1, 3), dtype=torch.float64)])
+    out = {"vec": v.numpy()}
+    for l in (5, 6, 7, 8):
+        out[f"sh{l}"] = ref_layers.TensorInit(l=l)(v).numpy()
+    np.savez_compressed(os.path.join(OUT, "kat_sh_l8.npz"), **out)
+    print("kat_sh_l8 written")
+
+
 def head_kat():
     """Known-answer test for the reference Atomwise head (outputs.py:323-376) with NON-trivial mean / stddev / atomref:
     random atom features in, per-molecule property and per-atom contributions out."""
@@ -531,5 +556,7 @@ if __name__ == "__main__":
             build_workload(name, *spec)
     if not only:
         sh_kat()
+    if not only or "kat_sh_l8" in only:
+        sh_kat_high()
     if not only or "kat_head" in only:
         head_kat()
