@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GN_LIB_PATH") or os.path.join(_PKG, "libgotennet_hip.so")
 
 GN_ERR_BAD_ARG = 10001
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 
@@ -58,7 +58,7 @@ SIGNATURES = {
     "gn_htr_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "gn_message_backward": [_P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                             _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.c_long, _I, _I, _I, _I, _I, _I, _I, _P],
-    "gn_message_backward_groups": [_I, _I, _I],
+    "gn_message_backward_groups": [_I, _I, _I, _I],
     "gn_eqff_backward_a": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "gn_eqff_backward_b": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "gn_edge_init_backward": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P],

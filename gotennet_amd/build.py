@@ -5,6 +5,8 @@ import glob
 import os
 import shutil
 import subprocess
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
@@ -30,10 +32,24 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
     if not force and not needs_build() and out == LIB:
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + list(extra_flags) + sources() + ["-o", out]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    compile_flags = [f for f in FLAGS if f != "-shared"] + list(extra_flags)
+    srcs = sources()
+    with tempfile.TemporaryDirectory(prefix="gn_build_") as td:
+        objs = [os.path.join(td, os.path.basename(s_)[:-4] + ".o") for s_ in srcs]
+
+        def one(job):
+            cmd = [hipcc] + compile_flags + ["-c", job[0], "-o", job[1]]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+
+        # one translation unit per worker: the files are independent and the largest takes about a minute
+        with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as pool:
+            list(pool.map(one, zip(srcs, objs)))
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+        if verbose:
+            print(" ".join(link), flush=True)
+        subprocess.run(link, check=True)
     return LIB
 
 

@@ -22,6 +22,10 @@ namespace gn {
 
 
 
+// The register-tiled kernels of this file are compiled for SiLU (the reference's default activation, and what every
+// benchmarked configuration uses): with the activation kind as a run-time switch the other eleven kinds' code cost
+// 4..22 VGPRs and a spill in msg_bwd_source (+4.5 % on the whole step).  Models with another activation take the
+// degree-sliced kernels of gn_highl.hip, which carry the kind as a run-time value.
 // =========================================================================== HTR backward
 // w = sum_l [ A.B - (2 - r.r)(A.r)(B.r) ],  A = EQ_i block, B = EK_j block, r = rl block
 template <int LMAX>
@@ -29,7 +33,8 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT) void htr_bwd_target_kerne
     const float* __restrict__ gtp, const float* __restrict__ pre_t, const float* __restrict__ w,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
     const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F,
-    float* __restrict__ gEQ, float* __restrict__ g_rl, float* __restrict__ g_pre_t, int act) {
+    float* __restrict__ gEQ, float* __restrict__ g_rl, float* __restrict__ g_pre_t, int /* act: GN_ACT_SILU on this path, see gn_htr_backward */) {
+    constexpr int act = GN_ACT_SILU;
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int KP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));
     constexpr int CH = D < 9 ? D : 9;
@@ -97,7 +102,8 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_SRC) void htr_bwd_source_kerne
     const float* __restrict__ gtp, const float* __restrict__ pre_t,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
     const int* __restrict__ colptr, const int* __restrict__ perm, const int* __restrict__ dst, int N, int F,
-    float* __restrict__ gEK, int act) {
+    float* __restrict__ gEK, int /* act: GN_ACT_SILU on this path, see gn_htr_backward */) {
+    constexpr int act = GN_ACT_SILU;
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int CH = D < 9 ? D : 9;
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
@@ -275,8 +281,8 @@ __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, const f
         const float gs = g_s_[(size_t)e * H + hq];
         const float4 kj = ld4(qk_ + (size_t)src_[e] * p.ldqk + F + c0);
         const float4 pta = ld4_nt(eproj_ + (size_t)e * p.lde + c0);
-        gq = fma4(gs, kj * act4(pta, p.act), gq);
-        st4_nt(g_eproj_ + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dact4(pta, p.act));   // d/d(pre-activation of t_attn)
+        gq = fma4(gs, kj * act4(pta, GN_ACT_SILU), gq);
+        st4_nt(g_eproj_ + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dact4(pta, GN_ACT_SILU));   // d/d(pre-activation of t_attn)
     }
     st4(&red[slot * F + c0], gq);
     __syncthreads();
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kerne
         }
         const float gs = p.g_s[(size_t)e * H + hq];
         const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
-        const float4 ta = act4(ld4_nt(p.eproj + (size_t)e * p.lde + c0), p.act);
+        const float4 ta = act4(ld4_nt(p.eproj + (size_t)e * p.lde + c0), GN_ACT_SILU);
         acc[2 * M + D] = fma4(gs, qi * ta, acc[2 * M + D]);
     }
     reduce_rows<ROWS>(acc, red, slot, c0, F, ns, [&](int row, float4 s) {
@@ -493,8 +499,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const MsgBwdArgs p, const
         const float gs = p.g_s[(size_t)e * H + hq];
         const float4 kj = ld4(p.qk + (size_t)p.src[e] * p.ldqk + F + c0);
         const float4 pta = ld4_nt(p.eproj + (size_t)e * p.lde + c0);
-        gq = fma4(gs, kj * act4(pta, p.act), gq);
-        st4_nt(p.g_eproj + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dact4(pta, p.act));
+        gq = fma4(gs, kj * act4(pta, GN_ACT_SILU), gq);
+        st4_nt(p.g_eproj + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dact4(pta, GN_ACT_SILU));
     }
     st4(&red[slot * F + c0], gq);
     __syncthreads();
@@ -567,7 +573,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC_G) void msg_bwd_source_gro
         if (SCALAR) {
             const float gs = p.g_s[(size_t)e * H + hq];
             const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
-            const float4 ta = act4(ld4_nt(p.eproj + (size_t)e * p.lde + c0), p.act);
+            const float4 ta = act4(ld4_nt(p.eproj + (size_t)e * p.lde + c0), GN_ACT_SILU);
             acc[2 * NB + XR] = fma4(gs, qi * ta, acc[2 * NB + XR]);
         }
     }
@@ -587,7 +593,8 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT_G) void htr_bwd_target_gro
     const float* __restrict__ gtp, const float* __restrict__ pre_t, const float* __restrict__ w,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
     const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F,
-    float* __restrict__ gEQ, float* __restrict__ g_rl, float* __restrict__ g_pre_t, int act) {
+    float* __restrict__ gEQ, float* __restrict__ g_rl, float* __restrict__ g_pre_t, int /* act: GN_ACT_SILU on this path, see gn_htr_backward */) {
+    constexpr int act = GN_ACT_SILU;
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int XR = (LHI + 1) * (LHI + 1) - LLO * LLO, M0 = LLO * LLO - 1;
     constexpr int KP = XR <= 4 ? 4 : (XR <= 8 ? 8 : 16);
@@ -652,7 +659,8 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_SRC_G) void htr_bwd_source_gro
     const float* __restrict__ gtp, const float* __restrict__ pre_t,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
     const int* __restrict__ colptr, const int* __restrict__ perm, const int* __restrict__ dst, int N, int F,
-    float* __restrict__ gEK, int act) {
+    float* __restrict__ gEK, int /* act: GN_ACT_SILU on this path, see gn_htr_backward */) {
+    constexpr int act = GN_ACT_SILU;
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int XR = (LHI + 1) * (LHI + 1) - LLO * LLO, M0 = LLO * LLO - 1;
     constexpr int CH = XR < 9 ? XR : 9;
@@ -986,7 +994,7 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
         return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (gn_use_highl(lmax))
+    if (gn_use_highl(lmax) || (!mode && act != GN_ACT_SILU))
         return gn_highl_htr_backward(g_t_out, pre_t, w, w_raw, EQ, EK, rl, rowptr, src, dst, colptr, perm, N, F, lmax,
                                      mode, gEQ, gEK, g_rl, g_pre_t, act, st);
     if (mode)
@@ -1017,8 +1025,8 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
         hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST>), grid, block, 0, st, p);                \
     } while (0)
 
-extern "C" int gn_message_backward_groups(int lmax, int sep_dir, int sep_tensor) {
-    if (gn_use_highl(lmax)) return 1;                  // degree-sliced kernels (gn_highl.hip): one slice
+extern "C" int gn_message_backward_groups(int lmax, int sep_dir, int sep_tensor, int act) {
+    if (gn_use_highl(lmax) || act != GN_ACT_SILU) return 1;      // degree-sliced kernels (gn_highl.hip): one slice
     return (lmax >= 3 && sep_dir && sep_tensor) ? lmax - 1 : 1;
 }
 
@@ -1039,8 +1047,8 @@ extern "C" int gn_message_backward(
                      N, F, H, (float)(1.0 / sqrt((double)F)), act};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(gn::xcd_grid(N)), block(256);
-    if (gn_use_highl(lmax)) return gn_highl_message_backward(p, lmax, sep_dir, sep_tensor, st);
-    if (gn_message_backward_groups(lmax, sep_dir, sep_tensor) > 1) {
+    if (gn_use_highl(lmax) || act != GN_ACT_SILU) return gn_highl_message_backward(p, lmax, sep_dir, sep_tensor, st);
+    if (gn_message_backward_groups(lmax, sep_dir, sep_tensor, act) > 1) {
         // degree groups: target passes (head sums and cut slices per group) -> attention backward -> source passes
         if (ga_parts == nullptr || E <= 0) return GN_ERR_BAD_ARG;
         const size_t gs = (size_t)E * H;

@@ -63,18 +63,52 @@ __device__ __forceinline__ void attn_phases(const float* __restrict__ q, const f
     __syncthreads();
 }
 
-// reference gotennet.py:497-511 + PyG softmax.  Scores and weights of a target stay in LDS between the phases (up to
-// 512 incoming edges at H = 8; longer rows go through their a[] entries in global memory).
+// reference gotennet.py:497-511 + PyG softmax, stand-alone launch: a[e,h] holds the raw scores between the two phases
+// (L2-resident: the target's rows were just written by this workgroup).  Keeping them in LDS like the fused form does
+// was measured SLOWER here (37-39 us vs 31 us at C2): the `in_lds` selects sit in every inner loop.
+// ASILU: activation fixed to SiLU at compile time (the run-time switch over twelve kinds costs registers and branches).
+template <bool ASILU>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_ATTN) void attn_softmax_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int ldqk,
     const float* __restrict__ ta, int ldt,
     const int* __restrict__ rowptr, const int* __restrict__ src, const int* __restrict__ outdeg,
-    int N, int F, int H, float inv_sqrt_f, float* a, int act) {
-    __shared__ float sc[GN_ATTN_LDS];
+    int N, int F, int H, float inv_sqrt_f, float* __restrict__ a, int act_rt) {
+    const int act = ASILU ? (int)GN_ACT_SILU : act_rt;
     const int i = xcd_item(blockIdx.x, N);
     if (i < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
+    const int lph = lps / H;                       // lanes per head (power of two, >= 1)
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
-    attn_phases(q, k, ldqk, ta, ldt, src, outdeg, i, e0, e1, F, H, inv_sqrt_f, a, sc, (e1 - e0) * H <= GN_ATTN_LDS, act);
+    const float4 qi = ld4(q + (size_t)i * ldqk + c0);
+    for (int e = e0 + slot; e < e1; e += ns) {
+        const float4 kj = ld4(k + (size_t)src[e] * ldqk + c0);
+        const float4 te = act4(ld4(ta + (size_t)e * ldt + c0), act);      // stored pre-activation: t_attn = act(.)
+        float p = qi.x * kj.x * te.x;
+        p += qi.y * kj.y * te.y;
+        p += qi.z * kj.z * te.z;
+        p += qi.w * kj.w * te.w;
+        p = group_sum(p, lph);
+        if ((lp & (lph - 1)) == 0) a[(size_t)e * H + lp / lph] = p;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int h = wave; h < H; h += 4) {
+        float mx = -INFINITY;
+        for (int e = e0 + lane; e < e1; e += 64) mx = fmaxf(mx, a[(size_t)e * H + h]);
+        mx = wave_max(mx);
+        float sm = 0.f;
+        for (int e = e0 + lane; e < e1; e += 64) {
+            const float ex = expf(a[(size_t)e * H + h] - mx);
+            a[(size_t)e * H + h] = ex;
+            sm += ex;
+        }
+        sm = wave_sum(sm) + 1e-16f;
+        for (int e = e0 + lane; e < e1; e += 64) {
+            const float nrm = outdeg ? sqrtf((float)outdeg[src[e]]) * inv_sqrt_f : inv_sqrt_f;
+            a[(size_t)e * H + h] = a[(size_t)e * H + h] / sm * nrm;
+        }
+    }
 }
 
 // q / k / t_attn / outdeg of the fused form (null q = the attention weights were computed by an earlier launch)
@@ -111,7 +145,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
     const int per_head = (M * F) / H;
     // FUSE: attention scores + segment softmax of this target first (gotennet.py:497-511); the weights then come from LDS
     const bool a_lds = FUSE && (e1 - e0) * H <= CH * 1024;
-    if constexpr (FUSE) attn_phases(at.q, at.k, at.ldqk, at.ta, ldt, src, at.outdeg, i, e0, e1, F, H, at.inv_sqrt_f, a, red, a_lds, at.act);
+    if constexpr (FUSE) attn_phases(at.q, at.k, at.ldqk, at.ta, ldt, src, at.outdeg, i, e0, e1, F, H, at.inv_sqrt_f, a, red, a_lds, GN_ACT_SILU);
 
     int hb[M];
 #pragma unroll
@@ -209,7 +243,7 @@ __device__ __forceinline__ void message_aggregate_group_body(
     const int per_head = (M * F) / H;
     // FUSE (the first degree group): attention weights of this target, kept in LDS and written to a[] for the other groups
     const bool a_lds = FUSE && (e1 - e0) * H <= CH * 1024;
-    if constexpr (FUSE) attn_phases(at.q, at.k, at.ldqk, at.ta, ldt, src, at.outdeg, i, e0, e1, F, H, at.inv_sqrt_f, a, red, a_lds, at.act);
+    if constexpr (FUSE) attn_phases(at.q, at.k, at.ldqk, at.ta, ldt, src, at.outdeg, i, e0, e1, F, H, at.inv_sqrt_f, a, red, a_lds, GN_ACT_SILU);
 
     int hb[M];                                      // attention head of this lane's channels in block b
 #pragma unroll
@@ -352,8 +386,12 @@ extern "C" int gn_attn_softmax(const float* q, const float* k, int ldqk, const f
         return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     const float inv_sqrt_f = (float)(1.0 / sqrt((double)F));
-    hipLaunchKernelGGL(gn::attn_softmax_kernel, dim3(gn::xcd_grid(N)), dim3(256), 0, (hipStream_t)stream,
-                       q, k, ldqk, t_attn, ldt, rowptr, src, outdeg, N, F, H, inv_sqrt_f, a, act);
+    if (act == GN_ACT_SILU)
+        hipLaunchKernelGGL(gn::attn_softmax_kernel<true>, dim3(gn::xcd_grid(N)), dim3(256), 0, (hipStream_t)stream,
+                           q, k, ldqk, t_attn, ldt, rowptr, src, outdeg, N, F, H, inv_sqrt_f, a, act);
+    else
+        hipLaunchKernelGGL(gn::attn_softmax_kernel<false>, dim3(gn::xcd_grid(N)), dim3(256), 0, (hipStream_t)stream,
+                           q, k, ldqk, t_attn, ldt, rowptr, src, outdeg, N, F, H, inv_sqrt_f, a, act);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
@@ -395,12 +433,13 @@ static int message_launch(const float* x, const float* v, int ldxv, const float*
     const int M = 1 + (sep_dir ? lmax : 1) + (sep_tensor ? lmax : 1);
     if ((M * F) % H || ((M * F) / H) % 4) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
-    if (gn_use_highl(lmax)) {                          // degrees 5..8: one launch per degree (gn_highl.hip)
-        if (fuse) {                                    // attention weights first, as a launch of their own
-            hipLaunchKernelGGL(gn::attn_softmax_kernel, dim3(gn::xcd_grid(N)), dim3(256), 0, (hipStream_t)stream,
-                               at.q, at.k, at.ldqk, at.ta, ldt, rowptr, src, at.outdeg, N, F, H, at.inv_sqrt_f, a, at.act);
-            GN_LAUNCH_CHECK();
-        }
+    const bool highl = gn_use_highl(lmax);
+    if (fuse && (highl || at.act != GN_ACT_SILU)) {    // attention weights first, as a launch of their own
+        const int rc = gn_attn_softmax(at.q, at.k, at.ldqk, at.ta, ldt, rowptr, src, at.outdeg, N, F, H, a, at.act, stream);
+        if (rc != GN_OK) return rc;
+        fuse = false;
+    }
+    if (highl) {                                       // degrees 5..8: one launch per degree (gn_highl.hip)
         return gn_highl_message(x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in, h_out, X_out, N, F, H,
                                 lmax, sep_dir, sep_tensor, (hipStream_t)stream);
     }

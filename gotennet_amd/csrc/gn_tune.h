@@ -44,9 +44,6 @@
 #define GN_W_ATTN 0        // 2: 29 -> 55 us; 4: 37 us
 #endif
 
-#ifndef GN_ATTN_LDS
-#define GN_ATTN_LDS 4096   // attn_softmax_kernel: floats of LDS for a target's scores (deg * H); 0-sized rows use global memory
-#endif
 #ifndef GN_K6_MERGE34
 #define GN_K6_MERGE34 1    // lmax = 4: degrees 3 and 4 of the message kernel in ONE launch (16 accumulator rows):
 #endif                     // C2 message stage 245.9 -> ~235 us (two launches: 60 + 64 us for 111 MB of t_filter each)

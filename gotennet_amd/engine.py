@@ -590,7 +590,7 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
 
     # every contributing kernel writes its own slice; the geometry backward sums them in a fixed order
     L = len(pw.layers)
-    G = _lib.load().gn_message_backward_groups(lmax, int(cfg.sep_dir), int(cfg.sep_tensor))
+    G = _lib.load().gn_message_backward_groups(lmax, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act)
     n_rl, n_cut = L + sum(lw.Wt is not None for lw in pw.layers), G * L + 1
     g_rl_parts, g_cut_parts = new(n_rl, E, D), new(n_cut, E)
     ga_parts = new(G, E, H) if G > 1 else None

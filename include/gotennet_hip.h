@@ -37,7 +37,7 @@ extern "C" {
 
 #define GN_OK 0
 #define GN_ERR_BAD_ARG 10001     /* shape/flag combination the kernels do not implement */
-#define GN_ABI_VERSION 3
+#define GN_ABI_VERSION 4
 
 /* `act`: the element-wise activation of the reference's `activation` constructor argument (str2act, layers.py:596-700;
  * shifted_softplus layers.py:40-50).  Wherever an entry point below says SiLU, it means this kind. */
@@ -262,10 +262,11 @@ int gn_message_backward(const float* x, const float* v, int ldxv, const float* e
                         float* g_eproj, float* g_s, float* g_nproj, int ldn, float* g_x, float* g_v,
                         float* g_X_out, float* g_rl, float* g_cut, float* ga_parts, long E,
                         int N, int F, int H, int lmax, int sep_dir, int sep_tensor, int act, void* stream);
-/* Number of degree groups G the message backward uses for these flags (1 = monolithic kernels, and lmax >= 5;
- * lmax 3..4 with sep_dir and sep_tensor: {scalar,1,2}, {3}, {4}).  g_cut must then hold G consecutive [E] slices and ga_parts
+/* Number of degree groups G the message backward uses for these flags (1 = monolithic kernels, lmax >= 5, and every
+ * activation other than GN_ACT_SILU -- those run the degree-sliced kernels; lmax 3..4 with sep_dir and sep_tensor
+ * and SiLU: {scalar,1,2}, {3}, {4}).  g_cut must then hold G consecutive [E] slices and ga_parts
  * G x [E,H] floats of workspace. */
-int gn_message_backward_groups(int lmax, int sep_dir, int sep_tensor);
+int gn_message_backward_groups(int lmax, int sep_dir, int sep_tensor, int act);
 
 /* EQFF (gotennet.py:716-748) backward, node-local halves around the two gamma_m GEMMs:
  * a: g_m = [g_h | sum_m g_X Xp], g_Xp = g_X * m2;   b: g_Xp += g_ctx[:,F:] Xp / n, g_h1 = g_h + g_ctx[:, :F]. */
