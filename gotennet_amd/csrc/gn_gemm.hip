@@ -75,7 +75,7 @@ namespace gn {
 // tile is (32 TM WM) x (32 TN WN).  Exact fp32: 2 x 2 waves.  SPLIT, 128 x 128 tile: 1 x 4 waves of 4 x 1 tiles -- every
 // wave then needs ONE 32-column block of the weight per k-step (3 KiB from L2 through the 64 B/clk L1 path instead of
 // 6 KiB with 2 x 2 tiles per wave) and re-reads the whole A slab from LDS, which has the bandwidth to spare.
-template <int TM, int TN, int WM, int WN, bool PRO, int PF, bool SPLIT>
+template <int TM, int TN, int WM, int WN, bool PRO, int PF, bool SPLIT, bool ASILU>
 __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -236,7 +236,7 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
             if (aok[i] && kok) {
                 v = ld4(Ab + (size_t)prow[i] * p.lda + ka);
                 if constexpr (PRO) {
-                    if (pro) v = (p.pro_mode == 1) ? act4(v, p.act_kind) : v * dact4(ld4(p.a_pre + (size_t)prow[i] * p.ldp + kc), p.act_kind);
+                    if (pro) v = (p.pro_mode == 1) ? act4(v, ASILU ? (int)GN_ACT_SILU : p.act_kind) : v * dact4(ld4(p.a_pre + (size_t)prow[i] * p.ldp + kc), ASILU ? (int)GN_ACT_SILU : p.act_kind);
                     if (p.a_gate) v = v * ld4(p.a_gate + (size_t)prow[i] * p.ldg + kc);
                 }
             }
@@ -507,8 +507,8 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
                         const int row = (it0 + u) * (256 / C4) + tid / C4;
                         float4 v = ld4(&smem[row * CP + cc]) + bias4;
                         if (p.pre_out) st4(p.pre_out + off[u], v);
-                        if (act) v = act4(v, p.act_kind);
-                        if (p.gate) v = v * (p.gate_mode ? dact4(gv[u], p.act_kind) : gv[u]);
+                        if (act) v = act4(v, ASILU ? (int)GN_ACT_SILU : p.act_kind);
+                        if (p.gate) v = v * (p.gate_mode ? dact4(gv[u], ASILU ? (int)GN_ACT_SILU : p.act_kind) : gv[u]);
                         if (p.res) v = rv[u] + v;
                         st4(p.C + off[u], v);
                     }
@@ -522,7 +522,7 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
                     float4 v = ld4(&smem[row * CP + cc]) + bias4;
                     const size_t off = (size_t)phys_row(p, gm) * p.ldc + gn;
                     if (p.pre_out) st4(p.pre_out + off, v);
-                    if (act) v = act4(v, p.act_kind);
+                    if (act) v = act4(v, ASILU ? (int)GN_ACT_SILU : p.act_kind);
 #if GN_SPLIT_NOSTORE
                     if (v.x == 123456.f) st4(p.C + off, v);
 #else
@@ -546,16 +546,19 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
   }
 }
 
-template <int TM, int TN, int WM, int WN, bool PRO, int PF>
+// ASILU: every problem of the launch uses SiLU (the reference's default): the activation is a compile-time constant.
+// With the kind as a run-time switch the eleven other activations' code cost the 128x128 split kernel a 36-byte spill
+// and the 64x64 fp32 kernel a wave of occupancy; models with another activation take the !ASILU instantiations.
+template <int TM, int TN, int WM, int WN, bool PRO, int PF, bool ASILU>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
-    gemm_body<TM, TN, WM, WN, PRO, PF, false>(ga);
+    gemm_body<TM, TN, WM, WN, PRO, PF, false, ASILU>(ga);
 }
 
 // 3 x bf16-split instantiation: two workgroups per CU (one wave of each per SIMD: while one is in its epilogue or at a
 // barrier the other feeds the matrix pipe), so the register budget is capped at 256 per lane.
-template <int TM, int TN, int WM, int WN, bool PRO>
+template <int TM, int TN, int WM, int WN, bool PRO, bool ASILU>
 __global__ __launch_bounds__(256, GN_SPLIT_MINW) void gemm_bf16x3_mfma(const GroupArgs ga) {
-    gemm_body<TM, TN, WM, WN, PRO, 1, true>(ga);
+    gemm_body<TM, TN, WM, WN, PRO, 1, true, ASILU>(ga);
 }
 
 }  // namespace gn
@@ -675,10 +678,18 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     long grid = 8L * ((end + 7) / 8);
     const long cap = use_big ? cap_big : 1024;
     if (grid > cap) grid = cap;
-#define GN_GEMM_GO_S(TM_, TN_, WM_, WN_, PRO_) \
-    hipLaunchKernelGGL((gn::gemm_bf16x3_mfma<TM_, TN_, WM_, WN_, PRO_>), dim3((unsigned)grid), dim3(256), 0, st, ga)
-#define GN_GEMM_GO_F(TM_, TN_, WM_, WN_, PRO_) \
-    hipLaunchKernelGGL((gn::gemm_f32_mfma<TM_, TN_, WM_, WN_, PRO_, 1>), dim3((unsigned)grid), dim3(256), 0, st, ga)
+    bool silu = true;
+    for (int i = 0; i < n; ++i) silu = silu && g[i].act_kind == GN_ACT_SILU;
+#define GN_GEMM_GO_S(TM_, TN_, WM_, WN_, PRO_)                                                                        \
+    do {                                                                                                              \
+        if (silu) hipLaunchKernelGGL((gn::gemm_bf16x3_mfma<TM_, TN_, WM_, WN_, PRO_, true>), dim3((unsigned)grid), dim3(256), 0, st, ga); \
+        else hipLaunchKernelGGL((gn::gemm_bf16x3_mfma<TM_, TN_, WM_, WN_, PRO_, false>), dim3((unsigned)grid), dim3(256), 0, st, ga);     \
+    } while (0)
+#define GN_GEMM_GO_F(TM_, TN_, WM_, WN_, PRO_)                                                                        \
+    do {                                                                                                              \
+        if (silu) hipLaunchKernelGGL((gn::gemm_f32_mfma<TM_, TN_, WM_, WN_, PRO_, 1, true>), dim3((unsigned)grid), dim3(256), 0, st, ga); \
+        else hipLaunchKernelGGL((gn::gemm_f32_mfma<TM_, TN_, WM_, WN_, PRO_, 1, false>), dim3((unsigned)grid), dim3(256), 0, st, ga);     \
+    } while (0)
 #if GN_SPLIT_GRID == 14
 #define GN_SPLIT_BIG(PRO_) GN_GEMM_GO_S(4, 1, 1, 4, PRO_)
 #elif GN_SPLIT_GRID == 12
