@@ -1001,11 +1001,13 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
         return gn_htr_backward_general(g_t_out, pre_t, w, w_raw, EQ, EK, rl, rowptr, src, dst, colptr, perm, N, F, lmax,
                                        mode, gEQ, gEK, g_rl, g_pre_t, act, st);
     const dim3 grid(gn::xcd_grid(N)), block(256);
-#define GN_HTRB(L, LLO, LHI, FIRST)                                                                              \
+#define GN_HTRB_T(L, LLO, LHI, FIRST)                                                                            \
     hipLaunchKernelGGL((gn::htr_bwd_target_group_kernel<L, LLO, LHI, FIRST>), grid, block, 0, st, g_t_out, pre_t, w, \
-                       EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl, g_pre_t, act);                                   \
+                       EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl, g_pre_t, act)
+#define GN_HTRB_S(L, LLO, LHI)                                                                                   \
     hipLaunchKernelGGL((gn::htr_bwd_source_group_kernel<L, LLO, LHI>), grid, block, 0, st, g_t_out, pre_t, EQ, EK, \
                        rl, colptr, perm, dst, N, F, gEK, act)
+#define GN_HTRB(L, LLO, LHI, FIRST) GN_HTRB_T(L, LLO, LHI, FIRST); GN_HTRB_S(L, LLO, LHI)
     if (lmax <= 2) {
         GN_SWITCH_LMAX(htr_bwd_target_kernel, grid, block, st, g_t_out, pre_t, w, EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl, g_pre_t, act);
         GN_LAUNCH_CHECK();
@@ -1013,7 +1015,9 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
     } else if (lmax == 3) {
         GN_HTRB(3, 1, 2, true); GN_HTRB(3, 3, 3, false);
     } else {
-        GN_HTRB(4, 1, 2, true); GN_HTRB(4, 3, 3, false); GN_HTRB(4, 4, 4, false);
+        GN_HTRB(4, 1, 2, true);
+        if (GN_HTRB_MERGE34_T) { GN_HTRB_T(4, 3, 4, false); } else { GN_HTRB_T(4, 3, 3, false); GN_HTRB_T(4, 4, 4, false); }
+        if (GN_HTRB_MERGE34_S) { GN_HTRB_S(4, 3, 4); } else { GN_HTRB_S(4, 3, 3); GN_HTRB_S(4, 4, 4); }
     }
     GN_LAUNCH_CHECK();
     return GN_OK;
@@ -1027,6 +1031,7 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
 
 extern "C" int gn_message_backward_groups(int lmax, int sep_dir, int sep_tensor, int act) {
     if (gn_use_highl(lmax) || act != GN_ACT_SILU) return 1;      // degree-sliced kernels (gn_highl.hip): one slice
+    if (lmax == 4 && sep_dir && sep_tensor && GN_MSGB_MERGE34_T) return 2;       // {scalar,1,2}, {3,4}
     return (lmax >= 3 && sep_dir && sep_tensor) ? lmax - 1 : 1;
 }
 
@@ -1062,9 +1067,11 @@ extern "C" int gn_message_backward(
             hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, 2, gs);
             GN_MSGB_S(3, 1, 2, true); GN_MSGB_S(3, 3, 3, false);
         } else {
-            GN_MSGB_T(4, 1, 2, true, 0); GN_MSGB_T(4, 3, 3, false, 1); GN_MSGB_T(4, 4, 4, false, 2);
-            hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, 3, gs);
-            GN_MSGB_S(4, 1, 2, true); GN_MSGB_S(4, 3, 3, false); GN_MSGB_S(4, 4, 4, false);
+            GN_MSGB_T(4, 1, 2, true, 0);
+            if (GN_MSGB_MERGE34_T) { GN_MSGB_T(4, 3, 4, false, 1); } else { GN_MSGB_T(4, 3, 3, false, 1); GN_MSGB_T(4, 4, 4, false, 2); }
+            hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, GN_MSGB_MERGE34_T ? 2 : 3, gs);
+            GN_MSGB_S(4, 1, 2, true);
+            if (GN_MSGB_MERGE34_S) { GN_MSGB_S(4, 3, 4, false); } else { GN_MSGB_S(4, 3, 3, false); GN_MSGB_S(4, 4, 4, false); }
         }
         GN_LAUNCH_CHECK();
         return GN_OK;
