@@ -113,13 +113,13 @@ def test_forces_match_oracle_wide(F, L, lmax):
     assert float(f.cpu().reshape(3, 14, 3).sum(1).abs().max()) < 1e-3 * float(f.abs().max())
 
 
-def _random_flag_cases(n=16):
+def _random_flag_cases(n=16, lmaxes=(1, 2, 2, 3, 4), rng_seed=1234, first_seed=100):
     """Seeded random flag combinations across every constructor switch the HIP path implements."""
     import random
-    rng = random.Random(1234)
+    rng = random.Random(rng_seed)
     cases = []
     for i in range(n):
-        lmax = rng.choice([1, 2, 2, 3, 4])
+        lmax = rng.choice(list(lmaxes))
         parts = []
         if rng.random() < 0.4:
             parts.append(rng.choice(["gated", "gatedt", "act"]))
@@ -140,12 +140,14 @@ def _random_flag_cases(n=16):
             radial_basis=rng.choice(["expnorm", "expnorm", "BesselBasis", "GaussianRBF"]), edge_updates=eu,
             layernorm=rng.choice(["", "", "layer"]), steerable_norm=rng.choice(["", "", "tensor"]),
             edge_ln=rng.choice(["", "layer"]), evec_dim=(16 if lin and rng.random() < 0.4 else None),
-            emlp_dim=rng.choice([None, 48]), seed=100 + i,
+            emlp_dim=rng.choice([None, 48]), seed=first_seed + i,
             activation=rng.choice(["silu", "silu", "softplus", "tanh", "elu", "selu", "mish", "gelu", "sigmoid"])))
     return cases
 
 
-@pytest.mark.parametrize("hp", _random_flag_cases(), ids=lambda hp: f"s{hp['seed']}")
+# the second set crosses the same switches at degrees 5..8 (the degree-sliced kernels of gn_highl.hip)
+@pytest.mark.parametrize("hp", _random_flag_cases() + _random_flag_cases(10, (5, 6, 7, 8), 4321, 300),
+                         ids=lambda hp: f"s{hp['seed']}_l{hp['lmax']}")
 def test_random_flag_combinations_match_oracle(hp):
     """Forward (h, X) and energy/forces against the oracle for random combinations of the constructor flags (the
     golden fixtures pin each flag against the reference; this crosses them)."""
