@@ -73,6 +73,10 @@ SIGNATURES = {
     "gn_pos_scatter": [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P],
     "gn_head_energy": [_P, _P, _F, _F, _F, _P, _P, _P, _I, _I, _P, _P, _I, _P, _I, _P],
     "gn_head_grad": [_P, _P, _F, _P, _I, _I, _P, _I, _P],
+    "gn_geb_context": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P],
+    "gn_geb_gate": [_P, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
+    "gn_dipole_reduce": [_P, _I, _P, _I, _P, _P, _I, _F, _F, _I, _I, _P, _P, _P],
+    "gn_ese_reduce": [_P, _P, _P, _P, _I, _P, _I, _P, _P],
     "gn_radius_count": [_P, _P, _I, _F, _I, _P, _P],
     "gn_radius_fill": [_P, _P, _I, _F, _I, _P, C.c_int64, _P, _P, _P, _P],
 }

@@ -1,4 +1,4 @@
-"""Energy / force read-out on the MI355X path.
+"""Read-out heads on the MI355X path: Atomwise (energy / forces), Dipole, ElectronicSpatialExtentV2.
 
 ``Atomwise`` mirrors the reference head (gotennet/models/components/outputs.py:
 323-376, with SchnetMLP layers.py:225-273) for its default shape on this path:
@@ -124,9 +124,10 @@ class Atomwise(nn.Module):
         _, c = self._packed()
         return c["scale"], c["shift"]
 
-    def energy_raw(self, h: torch.Tensor, z32: torch.Tensor, mol_ptr: torch.Tensor, n_mol: int):
+    def energy_raw(self, h: torch.Tensor, z32: torch.Tensor, mol_ptr: torch.Tensor, n_mol: int, raw: bool = False):
         """-> (energy [n_mol,1] (sum or mean over the molecule's atoms), y [N] per-atom contributions, tape).
-        ``tape`` (pre-activations of the hidden layers + the aggregation's per-atom weights) goes to ``grad_h_raw``."""
+        ``tape`` (pre-activations of the hidden layers + the aggregation's per-atom weights) goes to ``grad_h_raw``.
+        ``raw``: y = the MLP output itself (no standardisation, no atomref) -- what ElectronicSpatialExtentV2 reads."""
         layers, c = self._packed()
         N = h.shape[0]
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=h.device)
@@ -148,8 +149,8 @@ class Atomwise(nn.Module):
         y, e = new(N), new(n_mol, 1)
         mean = self.aggregation_mode == "mean"
         atom_scale = new(N) if mean else None
-        call("gn_head_energy", ptr(last_in), ptr(c["w"][-1]), c["b2"], c["scale"], c["shift"],
-             ptr(self.atomref.weight.detach()) if self.atomref is not None else None, ptr(z32), ptr(mol_ptr),
+        call("gn_head_energy", ptr(last_in), ptr(c["w"][-1]), c["b2"], 1.0 if raw else c["scale"], 0.0 if raw else c["shift"],
+             ptr(self.atomref.weight.detach()) if (self.atomref is not None and not raw) else None, ptr(z32), ptr(mol_ptr),
              n_mol, last_in.shape[1], ptr(y), ptr(e), int(mean), ptr(atom_scale), act, engine._stream())
         return e, y, (pres, last_in, atom_scale)
 
@@ -210,3 +211,172 @@ class _AtomwiseFn(torch.autograd.Function):
         mp = ctx.mol_ptr.long()
         per_atom = torch.repeat_interleave(ge.reshape(-1), mp[1:] - mp[:-1])
         return gh * per_atom.unsqueeze(1), None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# vector-representation read-outs of the QM9 task (reference models/tasks/QM9Task.py:168-187)
+def _pad4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class GatedEquivariantBlock(nn.Module):
+    """Reference outputs.py:24-93 (state_dict keys ``mix_vectors.weight``, ``scalar_net.{0,1}.{weight,bias}``).
+    ``forward(scalars [N, n_sin], vectors [N, 3, n_vin]) -> (s_out [N, n_sout], v_out [N, 3, n_vout])``; ``vectors`` may be
+    the ``X[:, :3, :]`` view of the [N, D, F] vector representation.  Inference only."""
+
+    def __init__(self, n_sin: int, n_vin: int, n_sout: int, n_vout: int, n_hidden: int, activation=F.silu,
+                 sactivation=None):
+        super().__init__()
+        if n_vin % 4 or n_hidden % 4:
+            raise NotImplementedError("GatedEquivariantBlock: n_vin and n_hidden must be multiples of 4 on the HIP path")
+        self.n_sin, self.n_vin, self.n_sout, self.n_vout, self.n_hidden = n_sin, n_vin, n_sout, n_vout, n_hidden
+        self.act_kind = activation_kind(activation)
+        self.sact_kind = activation_kind(sactivation) if sactivation is not None else -1
+        self.mix_vectors = Dense(n_vin, 2 * n_vout, activation=None, bias=False)
+        self.scalar_net = nn.Sequential(Dense(n_sin + n_vout, n_hidden, activation=resolve_activation(activation)),
+                                        Dense(n_hidden, n_sout + n_vout, activation=None))
+        self.sactivation = resolve_activation(sactivation) if sactivation is not None else None
+
+    def invalidate_packed(self):
+        self._cache = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._cache = None
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._cache = None
+        return out
+
+    def _packed(self):
+        """Weights padded to the GEMM's multiples of four (zero rows / columns): V block at column 0 and W block at column
+        pad4(n_vout) of the mixing product; ctx columns and output rows padded likewise."""
+        ts = [self.mix_vectors.weight, self.scalar_net[0].weight, self.scalar_net[0].bias,
+              self.scalar_net[1].weight, self.scalar_net[1].bias]
+        key = tuple((t._version, t.data_ptr()) for t in ts)
+        c = getattr(self, "_cache", None)
+        if c is None or c["key"] != key:
+            nv, ns, no, nh = self.n_vout, self.n_sin, self.n_sout, self.n_hidden
+            pv, kc, po = _pad4(nv), _pad4(ns + nv), _pad4(no + nv)
+            dev = ts[0].device
+            z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+            wmix = z(2 * pv, self.n_vin)
+            wmix[:nv], wmix[pv:pv + nv] = ts[0].detach()[:nv], ts[0].detach()[nv:]
+            w0 = z(nh, kc)
+            w0[:, :ns + nv] = ts[1].detach()
+            w1, b1 = z(po, nh), z(po)
+            w1[:no + nv], b1[:no + nv] = ts[3].detach(), ts[4].detach()
+            c = dict(key=key, wmix=wmix, w0=w0, b0=ts[2].detach().contiguous(), w1=w1, b1=b1, pv=pv, kc=kc, po=po)
+            self._cache = c
+        return c
+
+    def forward(self, scalars: torch.Tensor, vectors: torch.Tensor):
+        if not scalars.is_cuda:
+            raise GotenNetHipError("gotennet_amd.outputs.GatedEquivariantBlock runs on a ROCm device only")
+        c = self._packed()
+        N = scalars.shape[0]
+        if vectors.shape[1] != 3 or vectors.shape[2] != self.n_vin:
+            raise ValueError(f"vectors must be [N, 3, {self.n_vin}]")
+        # the X[:, :3, :] view of [N, D, F] is gathered into [N, 3, F] by a device copy (index plumbing: the GEMM's row map
+        # addresses input AND output rows, and the mixing product's output is dense)
+        vectors = vectors.detach().to(torch.float32).contiguous()
+        scalars = scalars.detach().to(torch.float32)
+        if scalars.stride(-1) != 1:
+            scalars = scalars.contiguous()
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=scalars.device)
+        pv, kc, po, nh = c["pv"], c["kc"], c["po"], self.n_hidden
+        vmix, ctx, hid, x = new(N * 3, 2 * pv), new(N, kc), new(N, nh), new(N, po)
+        engine.gemm(vectors, self.n_vin, c["wmix"], None, vmix, 2 * pv, N * 3, 2 * pv, self.n_vin, kind=self.act_kind)
+        call("gn_geb_context", ptr(scalars), scalars.stride(0), self.n_sin, ptr(vmix), 2 * pv, self.n_vout, N, ptr(ctx), kc,
+             engine._stream())
+        engine.gemm(ctx, kc, c["w0"], c["b0"], hid, nh, N, nh, kc, act=(0, nh), kind=self.act_kind)
+        engine.gemm(hid, nh, c["w1"], c["b1"], x, po, N, po, nh, kind=self.act_kind)
+        s_out, v_out = new(N, self.n_sout), new(N, 3, self.n_vout)
+        call("gn_geb_gate", ptr(x), po, self.n_sout, self.n_vout, ptr(vmix), 2 * pv, pv, N, self.sact_kind,
+             ptr(s_out), self.n_sout, ptr(v_out), self.n_vout, engine._stream())
+        return s_out, v_out
+
+
+def _field(inputs, name):
+    return inputs[name] if isinstance(inputs, dict) else getattr(inputs, name)
+
+
+class Dipole(nn.Module):
+    """Reference outputs.py:379-468: two GatedEquivariantBlocks on (h, X[:, :3]) -> atomic dipoles + charges,
+    ``y = sum_atoms (mu_n + pos_n q_n)`` per molecule (its norm with ``predict_magnitude``).  ``mean`` / ``stddev`` are
+    plain attributes like in the reference (not in the state_dict).  Inference only (the QM9 task takes no derivative)."""
+
+    def __init__(self, n_in: int, n_hidden: Optional[int] = None, activation=F.silu, property: str = "dipole",
+                 predict_magnitude: bool = False, output_v: bool = True, mean=None, stddev=None):
+        super().__init__()
+        self.stddev, self.mean, self.output_v = stddev, mean, output_v
+        n_hidden = n_in if n_hidden is None else n_hidden
+        self.property, self.derivative, self.predict_magnitude = property, None, predict_magnitude
+        self.equivariant_layers = nn.ModuleList([
+            GatedEquivariantBlock(n_sin=n_in, n_vin=n_in, n_sout=n_hidden, n_vout=n_hidden, n_hidden=n_hidden,
+                                  activation=activation, sactivation=activation),
+            GatedEquivariantBlock(n_sin=n_hidden, n_vin=n_hidden, n_sout=1, n_vout=1, n_hidden=n_hidden,
+                                  activation=activation)])
+        self.requires_dr = self.requires_stress = False
+        self.aggregation_mode = "sum"
+
+    def forward(self, inputs):
+        pos, batch = _field(inputs, "pos"), _field(inputs, "batch")
+        l0 = _field(inputs, "representation")
+        l1 = _field(inputs, "vector_representation")[:, :3, :]
+        for layer in self.equivariant_layers:
+            l0, l1 = layer(l0, l1)
+        n_mol = int(batch[-1].item()) + 1 if batch.numel() else 0
+        mp = molecule_ptr(batch, n_mol)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=l0.device)
+        y = new(n_mol, 1) if self.predict_magnitude else new(n_mol, 3)
+        y_vec = new(n_mol, 3, 1) if self.output_v else None
+        std = self.stddev is not None
+        call("gn_dipole_reduce", ptr(l1), 1, ptr(l0), 1, ptr(pos.detach().to(torch.float32).contiguous()), ptr(mp), n_mol,
+             float(self.stddev) if std else 1.0, float(self.mean) if std else 0.0, int(std), int(self.predict_magnitude),
+             ptr(y), ptr(y_vec), engine._stream())
+        result = {self.property: y}
+        if self.output_v:
+            result[self.property + "_vector"] = y_vec
+        return result
+
+
+#: standard atomic weights by atomic number (index 0: the dummy element, weight 1, as in ase.data.atomic_masses, which
+#: the reference reads at outputs.py:513).  Elements up to Kr are built in; heavier ones come from the ``atomic_mass``
+#: argument or from a reference checkpoint (the buffer is part of the state_dict).
+_ATOMIC_MASS = [1.0, 1.008, 4.002602, 6.94, 9.0121831, 10.81, 12.011, 14.007, 15.999, 18.998403163, 20.1797,
+                22.98976928, 24.305, 26.9815385, 28.085, 30.973761998, 32.06, 35.45, 39.948, 39.0983, 40.078,
+                44.955908, 47.867, 50.9415, 51.9961, 54.938044, 55.845, 58.933194, 58.6934, 63.546, 65.38, 69.723,
+                72.630, 74.921595, 78.971, 79.904, 83.798]
+
+
+class ElectronicSpatialExtentV2(Atomwise):
+    """Reference outputs.py:471-545: ``y = sum_atoms |pos_n - c|^2 x_n`` with ``x = out_net(h)`` (the raw MLP output:
+    the reference does not standardise here) and ``c`` the mass-weighted centroid of the molecule."""
+
+    def __init__(self, n_in: int, n_layers: int = 2, n_hidden: Optional[int] = None, activation=shifted_softplus,
+                 property: str = "y", contributions: Optional[str] = None, mean=None, stddev=None, outnet=None,
+                 atomic_mass: Optional[torch.Tensor] = None):
+        super().__init__(n_in, 1, "sum", n_layers, n_hidden, activation=activation, mean=mean, stddev=stddev,
+                         outnet=outnet, property=property, contributions=contributions)
+        if atomic_mass is None:
+            atomic_mass = torch.zeros(119)
+            atomic_mass[:len(_ATOMIC_MASS)] = torch.tensor(_ATOMIC_MASS)
+        self.register_buffer("atomic_mass", torch.as_tensor(atomic_mass, dtype=torch.float32))
+
+    def forward(self, inputs):
+        h, z, batch, pos = (_field(inputs, k) for k in ("representation", "z", "batch", "pos"))
+        if not h.is_cuda:
+            raise GotenNetHipError("gotennet_amd.outputs.ElectronicSpatialExtentV2 runs on a ROCm device only")
+        n_mol = int(batch[-1].item()) + 1 if batch.numel() else 0
+        mp, z32 = molecule_ptr(batch, n_mol), z.to(torch.int32)
+        _, x, _ = self.energy_raw(h.detach().contiguous(), z32, mp, n_mol, raw=True)
+        y = torch.empty((n_mol, 1), dtype=torch.float32, device=h.device)
+        call("gn_ese_reduce", ptr(x), ptr(pos.detach().to(torch.float32).contiguous()), ptr(z32), ptr(self.atomic_mass),
+             self.atomic_mass.numel(), ptr(mp), n_mol, ptr(y), engine._stream())
+        result = {self.property: y}
+        if self.contributions:
+            result[self.contributions] = x.reshape(-1, 1)
+        return result

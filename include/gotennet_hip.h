@@ -326,6 +326,26 @@ int gn_head_energy(const float* pre1, const float* W2, float b2, float scale, fl
 int gn_head_grad(const float* pre1, const float* W2, float scale, const float* atom_scale /* [N] or NULL */, int N, int Hd,
                  float* g_pre1, int act, void* stream);
 
+/* ---- vector-representation read-outs of the QM9 task (QM9Task.py:168-187) ---------------------------------------
+ * GatedEquivariantBlock (outputs.py:24-93) around two gn_gemm products:
+ *   vmix [N*3, ldv] = mix_vectors(vectors): V at column 0, W at column w_off, each n_vout wide;
+ *   gn_geb_context:  ctx [N, ldc] = [scalars (n_sin) | ||V||_2 over the 3 components (n_vout) | zeros];
+ *   x [N, ldx] = scalar_net(ctx) = [s (n_sout) | gate (n_vout) | padding]            (gn_gemm, twice);
+ *   gn_geb_gate:     s_out = sactivation(s) (sact = GN_ACT_* or -1 for none), v_out [N*3, ldo] = gate * W. */
+int gn_geb_context(const float* s, int lds, int n_sin, const float* vmix, int ldv, int n_vout, int N,
+                   float* ctx, int ldc, void* stream);
+int gn_geb_gate(const float* x, int ldx, int n_sout, int n_vout, const float* vmix, int ldv, int w_off, int N,
+                int sact, float* s_out, int lds, float* v_out, int ldo, void* stream);
+/* Dipole (outputs.py:430-468): y_b = sum_{n in molecule b} (mu_n + pos_n q_n), q_n = scale q_n + shift when
+ * standardise; y [n_mol,3], or [n_mol] = |y_b| when magnitude; y_vec [n_mol,3] = sum mu_n (or NULL). */
+int gn_dipole_reduce(const float* mu, int ldm, const float* q, int ldq, const float* pos, const int* mol_ptr,
+                     int n_mol, float scale, float shift, int standardise, int magnitude, float* y, float* y_vec,
+                     void* stream);
+/* ElectronicSpatialExtentV2 (outputs.py:516-545): c_b = mass-weighted centroid, y_b = sum_n |pos_n - c_b|^2 x_n;
+ * mass [n_mass] indexed by atomic number. */
+int gn_ese_reduce(const float* x, const float* pos, const int* z, const float* mass, int n_mass, const int* mol_ptr,
+                  int n_mol, float* y, void* stream);
+
 /* ---- adjacent: radius graph (Distance.forward, layers.py:1588-1604) ----------------------- */
 /* torch_cluster.radius_graph(pos, r, batch, loop=True, max_num_neighbors) semantics: edges j->i with
  * ||pos_j - pos_i||^2 < cutoff^2 (fp32) inside one molecule (batch sorted, int64), target-major,

@@ -582,3 +582,52 @@ def energy_and_forces(sd, cfg, head, z, pos, batch, n_mol, max_num_neighbors: in
     e = atomwise_energy(head, h, batch, n_mol, activation, z=z, aggregation=aggregation)
     (g,) = torch.autograd.grad(e.sum(), pos)
     return e.detach(), -g, (h.detach(), X.detach(), ei)
+
+
+# --------------------------------------------------------------------------- vector read-outs of the QM9 task
+def gated_equivariant_block(sd: Dict[str, Tensor], prefix: str, scalars: Tensor, vectors: Tensor,
+                            activation: str = "silu", sactivation: Optional[str] = None) -> Tuple[Tensor, Tensor]:
+    """outputs.py:67-93: vmix = mix_vectors(vectors) -> (V, W); ctx = [scalars | ||V|| over the 3 components];
+    x = scalar_net(ctx) -> (s, gate); v_out = gate * W; s_out = sactivation(s)."""
+    act = activation_of(activation)
+    vmix = F.linear(vectors, sd[prefix + "mix_vectors.weight"])
+    n_vout = vmix.shape[-1] // 2
+    V, W = vmix[..., :n_vout], vmix[..., n_vout:]
+    ctx = torch.cat([scalars, torch.norm(V, dim=-2)], dim=-1)
+    x = act(F.linear(ctx, sd[prefix + "scalar_net.0.weight"], sd[prefix + "scalar_net.0.bias"]))
+    x = F.linear(x, sd[prefix + "scalar_net.1.weight"], sd[prefix + "scalar_net.1.bias"])
+    n_sout = x.shape[-1] - n_vout
+    s_out, gate = x[..., :n_sout], x[..., n_sout:]
+    v_out = gate.unsqueeze(-2) * W
+    if sactivation is not None:
+        s_out = activation_of(sactivation)(s_out)
+    return s_out, v_out
+
+
+def dipole(sd: Dict[str, Tensor], h: Tensor, X: Tensor, pos: Tensor, batch: Tensor, n_mol: int,
+           activation: str = "silu", mean=None, stddev=None, predict_magnitude: bool = False):
+    """outputs.py:430-468 -> (y [n_mol, 3] or its norm [n_mol, 1], y_vector [n_mol, 3, 1])."""
+    l0, l1 = h, X[:, :3, :]
+    l0, l1 = gated_equivariant_block(sd, "equivariant_layers.0.", l0, l1, activation, activation)
+    l0, l1 = gated_equivariant_block(sd, "equivariant_layers.1.", l0, l1, activation, None)
+    if stddev is not None:
+        l0 = stddev * l0 + mean
+    y_atom = l1.squeeze(-1) + pos * l0
+    y = torch.zeros((n_mol, 3), dtype=y_atom.dtype).index_add_(0, batch, y_atom)
+    y_vec = torch.zeros((n_mol, 3, 1), dtype=l1.dtype).index_add_(0, batch, l1)
+    if predict_magnitude:
+        y = torch.norm(y, dim=1, keepdim=True)
+    return y, y_vec
+
+
+def electronic_spatial_extent(head: Dict[str, Tensor], h: Tensor, pos: Tensor, z: Tensor, batch: Tensor, n_mol: int,
+                              activation: str = "softplus"):
+    """outputs.py:516-545: x = out_net(h) (NOT standardised); c = mass-weighted centroid;
+    y = sum_atoms |pos - c|^2 x.  -> (y [n_mol, 1], x [N, 1])."""
+    raw = {k: v for k, v in head.items() if k.startswith("out_net.")}
+    x = atomwise_contributions(raw, h, None, activation)
+    mass = head["atomic_mass"].to(pos.dtype)[z].view(-1, 1)
+    seg = lambda v: torch.zeros((n_mol, v.shape[1]), dtype=v.dtype).index_add_(0, batch, v)
+    c = seg(mass * pos) / seg(mass)
+    yi = torch.norm(pos - c[batch], dim=1, keepdim=True) ** 2 * x
+    return seg(yi), x

@@ -303,3 +303,106 @@ def test_head_shapes_energy_and_forces_match_oracle(n_layers, n_hidden, agg, act
     else:
         assert rel_err(out["y"].detach().cpu(), e_ref) < TOL
     assert rel_err(out["forces"].detach().cpu(), f_ref) < TOL
+
+
+# ---------------------------------------------------------------- vector read-outs of the QM9 task (Dipole, ESE)
+def _qm9_kat(dtype=torch.float32):
+    k = np.load(os.path.join(GOLDEN_DIR, "kat_qm9_heads.npz"))
+    t = {n: torch.from_numpy(k[n]) for n in k.files if "/" not in n}
+    sd = {tag: {n[len(tag) + 1:]: torch.from_numpy(k[n]) for n in k.files if n.startswith(tag + "/")}
+          for tag in ("dip_task", "dip_vec", "ese")}
+    return t, sd
+
+
+def test_oracle_qm9_heads_match_reference_kat():
+    """Dipole as QM9Task builds it (magnitude, standardised charges), Dipole in vector form with n_hidden != n_in, and
+    ElectronicSpatialExtentV2, against the reference's own outputs (tools/make_golden.py qm9_heads_kat)."""
+    from oracle import gotennet_oracle as orc
+    t, sd = _qm9_kat()
+    h, X, pos, z, batch, n_mol = t["h"], t["X"], t["pos"], t["z"], t["batch"], int(t["n_mol"])
+    y, yv = orc.dipole(sd["dip_task"], h, X, pos, batch, n_mol, "silu", mean=torch.tensor(0.3), stddev=torch.tensor(1.7),
+                       predict_magnitude=True)
+    assert y.shape == t["dip_task_y"].shape == (n_mol, 1) and yv.shape == t["dip_task_yvec"].shape == (n_mol, 3, 1)
+    assert rel_err(y, t["dip_task_y"]) < 2e-6 and rel_err(yv, t["dip_task_yvec"]) < 2e-6
+    y, yv = orc.dipole(sd["dip_vec"], h, X, pos, batch, n_mol, "silu")
+    assert y.shape == (n_mol, 3)
+    assert rel_err(y, t["dip_vec_y"]) < 2e-6 and rel_err(yv, t["dip_vec_yvec"]) < 2e-6
+    y, x = orc.electronic_spatial_extent(sd["ese"], h, pos, z, batch, n_mol, "softplus")
+    assert rel_err(y, t["ese_y"]) < 2e-6 and rel_err(x, t["ese_contrib"]) < 2e-6
+    assert torch.equal(sd["ese"]["atomic_mass"], t["masses"])
+
+
+def test_qm9_head_state_dict_layout():
+    import gotennet_amd.outputs as out
+    _, sd = _qm9_kat()
+    dt = out.Dipole(n_in=64, predict_magnitude=True, property="property", mean=torch.tensor(0.3), stddev=torch.tensor(1.7))
+    dv = out.Dipole(n_in=64, n_hidden=32, property="dipole")
+    es = out.ElectronicSpatialExtentV2(n_in=64, property="property", contributions="contrib")
+    for mod, tag in ((dt, "dip_task"), (dv, "dip_vec"), (es, "ese")):
+        assert sorted(mod.state_dict().keys()) == sorted(sd[tag].keys()), tag
+        mod.load_state_dict(sd[tag], strict=True)
+    assert float(es.atomic_mass[6]) == pytest.approx(12.011) and float(es.atomic_mass[0]) == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.usefixtures("gemm_mode")
+def test_qm9_heads_against_reference():
+    """The HIP Dipole / ElectronicSpatialExtentV2 modules on the reference's KAT: inputs as the QM9 task hands them over
+    (duck-typed batch with .representation / .vector_representation [N, D, F], the block takes the X[:, :3] view)."""
+    import types
+    import gotennet_amd.outputs as out
+    t, sd = _qm9_kat()
+    n_mol = int(t["n_mol"])
+    inp = types.SimpleNamespace(z=t["z"].cuda(), batch=t["batch"].cuda(), pos=t["pos"].cuda(),
+                                representation=t["h"].cuda(), vector_representation=t["X"].cuda())
+    dt = out.Dipole(n_in=64, predict_magnitude=True, property="property", mean=torch.tensor(0.3), stddev=torch.tensor(1.7))
+    dt.load_state_dict(sd["dip_task"], strict=True)
+    r = dt.cuda().eval()(inp)
+    assert r["property"].shape == (n_mol, 1) and r["property_vector"].shape == (n_mol, 3, 1)
+    assert rel_err(r["property"].cpu(), t["dip_task_y"]) < 1e-4
+    assert rel_err(r["property_vector"].cpu(), t["dip_task_yvec"]) < 1e-4
+    dv = out.Dipole(n_in=64, n_hidden=32, property="dipole")
+    dv.load_state_dict(sd["dip_vec"], strict=True)
+    r = dv.cuda().eval()(inp)
+    assert r["dipole"].shape == (n_mol, 3)
+    assert rel_err(r["dipole"].cpu(), t["dip_vec_y"]) < 1e-4 and rel_err(r["dipole_vector"].cpu(), t["dip_vec_yvec"]) < 1e-4
+    es = out.ElectronicSpatialExtentV2(n_in=64, property="property", contributions="contrib")
+    es.load_state_dict(sd["ese"], strict=True)
+    r = es.cuda().eval()(inp)
+    assert rel_err(r["property"].cpu(), t["ese_y"]) < 1e-4 and rel_err(r["contrib"].cpu(), t["ese_contrib"]) < 1e-4
+    # a standalone block on a contiguous [N, 3, F] input gives the same as on the X[:, :3] view
+    blk = dv.equivariant_layers[0]
+    s1, v1 = blk(inp.representation, inp.vector_representation[:, :3, :])
+    s2, v2 = blk(inp.representation, inp.vector_representation[:, :3, :].contiguous())
+    assert torch.equal(s1, s2) and torch.equal(v1, v2)
+
+
+@pytest.mark.gpu
+def test_qm9_heads_on_the_representation_match_oracle():
+    """End to end: GotenNetWrapper -> Dipole / ESE on a 2-molecule batch against the oracle (F = 32, lmax = 2)."""
+    import types
+    import gotennet_amd
+    import gotennet_amd.outputs as out
+    from oracle import gotennet_oracle as orc
+    from tests.test_hip_parity import _synthetic
+    torch.manual_seed(7)
+    kw = dict(n_atom_basis=32, n_interactions=2, n_rbf=8, num_heads=8, scale_edge=False, lmax=2, sep_dir=True, sep_tensor=True)
+    net = gotennet_amd.GotenNetWrapper(cutoff_fn=gotennet_amd.CosineCutoff(5.0), **kw)
+    dip = out.Dipole(n_in=32, predict_magnitude=True, property="mu")
+    ese = out.ElectronicSpatialExtentV2(n_in=32, property="r2")
+    sd = {k: v.clone().double() for k, v in net.state_dict().items()}
+    dsd = {k: v.clone().double() for k, v in dip.state_dict().items()}
+    esd = {k: v.clone().double() for k, v in ese.state_dict().items()}
+    pos, batch, z = _synthetic(2, 9, 3.0, seed=3)
+    z = z.clamp(max=9)
+    cfg = orc.default_config(**kw)
+    ei, w, vec = orc.distance(pos.double(), batch, 5.0)
+    h, X = orc.gotennet_forward(sd, cfg, z, ei, w, vec)
+    y_mu, _ = orc.dipole(dsd, h, X, pos.double(), batch, 2, "silu", predict_magnitude=True)
+    y_r2, _ = orc.electronic_spatial_extent(esd, h, pos.double(), z, batch, 2, "softplus")
+    net, dip, ese = net.cuda().eval(), dip.cuda().eval(), ese.cuda().eval()
+    inp = types.SimpleNamespace(z=z.cuda(), pos=pos.cuda(), batch=batch.cuda())
+    with torch.no_grad():
+        inp.representation, inp.vector_representation = net(inp)
+        assert rel_err(dip(inp)["mu"].cpu(), y_mu) < 1e-4
+        assert rel_err(ese(inp)["r2"].cpu(), y_r2) < 1e-4

@@ -540,6 +540,59 @@ def head_kat():
     print("kat_head_l3_mean_ssp written:", [tuple(v.shape) for k, v in head3.state_dict().items() if k.endswith("weight")])
 
 
+def qm9_heads_kat():
+    """Known-answer tests for the two vector read-outs of the reference's QM9 task (QM9Task.py:168-187): Dipole
+    (outputs.py:379-468) as the task builds it (magnitude, standardised charges) and in its vector form with a narrower
+    hidden width, and ElectronicSpatialExtentV2 (471-545).  `ase` is not installed here: its mass table is replaced by
+    the product's built-in table (gotennet_amd.outputs._ATOMIC_MASS), so the masses themselves are NOT pinned by this
+    fixture -- everything downstream of them is."""
+    sys.path.insert(0, ROOT)
+    from gotennet_amd.outputs import _ATOMIC_MASS
+    masses = np.zeros(119)
+    masses[:len(_ATOMIC_MASS)] = _ATOMIC_MASS
+    sys.modules.setdefault("torch_scatter", types.ModuleType("torch_scatter"))
+    sys.modules["torch_scatter"].scatter = ref_shims._scatter
+    sys.modules.setdefault("ase", types.ModuleType("ase"))
+    sys.modules.setdefault("ase.data", types.ModuleType("ase.data"))
+    sys.modules["ase"].data = sys.modules["ase.data"]
+    sys.modules["ase.data"].atomic_masses = masses
+    from gotennet.models.components import outputs as ref_out
+    g = torch.Generator().manual_seed(51)
+    F_, D, n_mol = 64, 8, 3
+    sizes = [9, 1, 14]
+    N = sum(sizes)
+    z = torch.randint(1, 10, (N,), generator=g)
+    batch = torch.repeat_interleave(torch.arange(n_mol), torch.tensor(sizes))
+    h = torch.randn((N, F_), generator=g)
+    X = torch.randn((N, D, F_), generator=g) * 0.3
+    pos = torch.rand((N, 3), generator=g) * 4.0
+
+    class _D(dict):
+        __getattr__ = dict.__getitem__
+    inp = _D(z=z, batch=batch, pos=pos, representation=h, vector_representation=X)
+    out = dict(h=h.numpy(), X=X.numpy(), z=z.numpy(), batch=batch.numpy(), pos=pos.numpy(), n_mol=np.array(n_mol),
+               masses=masses.astype(np.float32))
+    dip_task = ref_out.Dipole(n_in=F_, predict_magnitude=True, property="property", mean=torch.tensor(0.3),
+                              stddev=torch.tensor(1.7))
+    dip_vec = ref_out.Dipole(n_in=F_, n_hidden=32, activation=torch.nn.functional.silu, property="dipole")
+    ese = ref_out.ElectronicSpatialExtentV2(n_in=F_, property="property", contributions="contrib")
+    sys.modules["ase.data"].atomic_masses = np.ones(120)      # what head_kat() expects
+    randomise(dip_task, 5100)
+    randomise(dip_vec, 5200)
+    randomise(ese, 5300)
+    ese.atomic_mass.copy_(torch.from_numpy(masses).float())    # randomise() must not touch the mass table
+    with torch.no_grad():
+        r1, r2, r3 = dip_task(inp), dip_vec(inp), ese(inp)
+    out.update(dip_task_y=r1["property"].numpy(), dip_task_yvec=r1["property_vector"].numpy(),
+               dip_vec_y=r2["dipole"].numpy(), dip_vec_yvec=r2["dipole_vector"].numpy(),
+               ese_y=r3["property"].numpy(), ese_contrib=r3["contrib"].numpy())
+    for tag, m in (("dip_task", dip_task), ("dip_vec", dip_vec), ("ese", ese)):
+        for k, v in m.state_dict().items():
+            out[f"{tag}/{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "kat_qm9_heads.npz"), **out)
+    print("kat_qm9_heads written:", sorted(k for k in out if "/" in k)[:6], "...", float(r1["property"][0]), float(r3["property"][0]))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)  # deterministic reduction order for the goldens
     only = sys.argv[1:]                    # optional: names of the fixtures to (re)generate
@@ -558,5 +611,7 @@ if __name__ == "__main__":
         sh_kat()
     if not only or "kat_sh_l8" in only:
         sh_kat_high()
+    if not only or "kat_qm9_heads" in only:
+        qm9_heads_kat()
     if not only or "kat_head" in only:
         head_kat()
