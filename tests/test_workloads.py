@@ -138,3 +138,32 @@ def test_full_size_workload_properties(name, n_mol):
         e5, f5 = run(z, ei, ed, ev @ Q.T, batch, n_mol)
         assert rel_err(e5.cpu(), e0.cpu()) < 1e-5
         assert rel_err(f5.cpu(), (f0 @ Q.T).cpu()) < TOL
+
+
+@pytest.mark.gpu
+def test_large_batch_is_batch_independent():
+    """C4's GLOBAL batch (1024 molecules, E = 433 684) on ONE GPU: the first 128 molecules give the 128-molecule batch's
+    energies and forces bit for bit (no index arithmetic depends on the batch size; tools/big_batch_check.py takes the
+    same check to 4096 molecules, where E (1+M) F exceeds 2^31 elements, 143 GiB of the 288)."""
+    import gotennet_amd
+    from gotennet_amd import synthetic
+    from gotennet_amd.graph import distance
+    from gotennet_amd.outputs import Atomwise
+    from gotennet_amd.pipeline import EnergyForces
+    torch.manual_seed(0)
+    net = gotennet_amd.GotenNet(n_atom_basis=256, n_interactions=6, n_rbf=32, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
+                                num_heads=8, scale_edge=False, lmax=2, sep_dir=True, sep_tensor=True).cuda().eval()
+    head = Atomwise(n_in=256, n_hidden=256, derivative="forces", activation="silu").cuda().eval()
+    ef = EnergyForces(net, head)
+    out = {}
+    for B in (128, 1024):
+        pos, batch, z = synthetic.make_batch("rmd17_aspirin", B, seed=0)
+        ei, w, vec = distance(pos.cuda(), batch.cuda(), 5.0, 32)
+        out[B] = ef(z.cuda(), ei, w, vec, batch.cuda(), B)
+        torch.cuda.synchronize()
+    e, f = out[1024]
+    assert torch.equal(e[:128], out[128][0]) and torch.equal(f[:128 * 21], out[128][1])
+    assert bool(torch.isfinite(e).all()) and bool(torch.isfinite(f).all())
+    assert float(f.reshape(1024, 21, 3).sum(1).abs().max()) < 1e-3 * float(f.abs().max())
+    del out, e, f
+    torch.cuda.empty_cache()
