@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC passes over one GEMM shape (GM/GN/GK env, default the 54368x1536x256 edge projection): issue/stall breakdown.
+# PMC passes over one GEMM shape (GM/GN/GK env, default the 54368x1536x256 edge projection; GN_GEMM_MODE picks the
+# arithmetic, default 3xbf16-split): issue/stall breakdown.  One counter set per pass (--kernel-trace + --pmc only).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 i=0
 for SET in "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" \
@@ -9,6 +10,6 @@ for SET in "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_IN
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_VALU"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $SET -d gpurun_out/pmc_gemm_$i -o r -- python tools/gemm_one.py > /dev/null 2>&1
-  python tools/rocprof_summary.py gpurun_out/pmc_gemm_$i/r_results.db 2>/dev/null | grep -E "^# PMC|gemm_f32|^kernel|counter" | head -12
+  python tools/rocprof_summary.py gpurun_out/pmc_gemm_$i/r_results.db 2>/dev/null | grep -E "^# PMC|gn::gemm_|^kernel" | grep -v "counters_collection" | head -12
   rm -rf gpurun_out/pmc_gemm_$i
 done
