@@ -36,7 +36,7 @@
 #define GN_SPLIT_NOSTORE 0     // probe only: skip the global stores of the epilogue
 #endif
 #ifndef GN_SPLIT_ABL
-#define GN_SPLIT_ABL 0         // probe builds only (wrong results): 1 no weight loads, 2 one A fragment address, 4 no split/stash,
+#define GN_SPLIT_ABL 0         // probe builds only (wrong results): 1 no weight loads, 2 one A fragment address, 4 no split/stash, 32 three of six MFMA terms,
 #endif                         // 8 no A fetch, 16 no barrier in the K loop -- what each part of the split main loop costs
 #ifndef GN_SPLIT_MINW
 #define GN_SPLIT_MINW 2        // minimum waves per SIMD of the split kernel (register cap 512 / n)
@@ -348,7 +348,7 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
             constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
             constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = (GN_SPLIT_ABL & 32) ? 3 : 0; t < 6; ++t)       // ablation 32: three of the six terms (timing probe)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
