@@ -45,9 +45,9 @@ class KernelTimer:
 
     @staticmethod
     def tag_of(name, args):
-        if name in ("gn_gemm_ex", "gn_gemm_split"):
+        if name in ("gn_gemm_ex", "gn_gemm_split", "gn_gemm_f16x2"):
             return f"gn_gemm[{args[6]}x{args[7]}x{args[8]}]"
-        if name in ("gn_gemm_group", "gn_gemm_group_split"):   # several independent problems in one launch
+        if name in ("gn_gemm_group", "gn_gemm_group_split", "gn_gemm_group_f16x2"):   # several independent problems in one launch
             return "gn_gemm[" + "+".join(f"{args[0][i].M}x{args[0][i].N}x{args[0][i].K}" for i in range(args[1])) + "]"
         return name
 
@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table (stderr)")
     ap.add_argument("--no-lmax4", action="store_true", help="skip the short lmax=4 side measurement")
-    ap.add_argument("--no-split", action="store_true", help="skip the short 3xbf16-split side measurement")
+    ap.add_argument("--no-split", action="store_true", help="skip the short side measurements in the other projection arithmetics")
     ap.add_argument("--no-graph", action="store_true", help="skip the single-molecule hipGraph-replay side measurement")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (path check)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the short C3 / C5 side measurements")
@@ -185,19 +185,23 @@ def worker(a):
     from gotennet_amd import engine
     res = measure(a, a.workload, a.batch, a.lmax, a.steps, a.warmup, rank, world, dev, dist)
     sides = world == 1                              # side measurements only on the single-GPU line
-    side = other = lat = None
+    side = lat = None
     wl = {}
     if sides and a.lmax != 4 and not a.no_lmax4 and a.workload == "rmd17_aspirin":
         # the north-star's "L=4" target shape (lmax = 4): the gather/scatter target is quoted on it
         side = measure(a, a.workload, a.batch, 4, max(20, a.steps), 3, rank, world, dev, dist)
+    others = {}
     if sides and not a.no_split:
-        # the other projection arithmetic (exact fp32 MFMA <-> 3 x bf16-split MFMA), reported alongside
+        # the other projection arithmetics (exact fp32 MFMA, 3 x bf16-split, 2 x fp16-split), reported alongside
         default_mode = engine.GEMM_MODE
-        engine.GEMM_MODE = "split" if default_mode == "f32" else "f32"
-        try:
-            other = measure(a, a.workload, a.batch, a.lmax, max(5, a.steps // 2), 2, rank, world, dev, dist)
-        finally:
-            engine.GEMM_MODE = default_mode
+        for mode in ("f32", "split", "f16x2"):
+            if mode == default_mode:
+                continue
+            engine.GEMM_MODE = mode
+            try:
+                others[mode] = measure(a, a.workload, a.batch, a.lmax, max(5, a.steps // 2), 2, rank, world, dev, dist)
+            finally:
+                engine.GEMM_MODE = default_mode
     if sides and not a.no_workloads and a.workload == "rmd17_aspirin":
         # BASELINE configs[2] and configs[4] on the same model family (single GPU)
         wl["md22_ac_ala3_b64"] = measure(a, "md22_ac_ala3", 64, 2, 10, 2, rank, world, dev, dist)
@@ -212,9 +216,9 @@ def worker(a):
                           "config": so["config"]["workload"]}
         if lat is not None:
             also["single_molecule_latency"] = lat
-        if other is not None:
+        for mode, other in others.items():
             so = other["out"]
-            also["other_projection_mode"] = {
+            also.setdefault("other_projection_modes", {})[mode] = {
                 "dtype": so["dtype"], "value": so["value"], "unit": so["unit"], "ms_per_step": so["ms_per_step"],
                 "steps": so["steps"], "roofline": so["roofline"]}
         if side is not None:
@@ -384,16 +388,22 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
                         **common,
                         largest_launch=dict(shape_MxNxK=big[0][8:-1], us=round(big[2], 2), tflops=round(big[3], 2),
                                             frac=round(big[3] / MFMA_F32_PEAK_TF, 4)))
-        # 3 x bf16-split: the kernel EXECUTES six bf16 MFMA flops per algorithmic fp32 flop, so it is priced against
-        # the dense bf16 matrix peak: achieved = 6 x algorithmic flops / time
-        return dict(kernel="gn::gemm_bf16x3_mfma (all projection launches; every fp32 product as 6 bf16 MFMAs, fp32 accumulate)",
-                    bound="mfma", achieved=round(6 * ach, 1), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
-                    frac=round(6 * ach / MFMA_BF16_PEAK_TF, 4),
-                    note="achieved = EXECUTED bf16 MFMA flops (6 x algorithmic) / summed launch time; peak = dense bf16 MFMA",
+        # split modes: the kernel EXECUTES several 16-bit MFMA flops per algorithmic fp32 flop (six bf16 terms, or three
+        # fp16 terms with block exponents), so it is priced against the dense 16-bit matrix peak:
+        # achieved = terms x algorithmic flops / time
+        terms, kname, what = ((3, "gn::gemm_f16x2_mfma", "3 fp16 MFMAs on 2 scaled fp16 planes") if _engine_mode() == "f16x2"
+                              else (6, "gn::gemm_bf16x3_mfma", "6 bf16 MFMAs on 3 bf16 planes"))
+        return dict(kernel=f"{kname} (all projection launches; every fp32 product as {what}, fp32 accumulate)",
+                    bound="mfma", achieved=round(terms * ach, 1), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
+                    frac=round(terms * ach / MFMA_BF16_PEAK_TF, 4),
+                    note=f"achieved = EXECUTED 16-bit MFMA flops ({terms} x algorithmic) / summed launch time; peak = dense bf16 / "
+                         "fp16 MFMA (2.5 PF).  The fp16 mode executes half the flops of the bf16 mode for the same product: "
+                         "compare algorithmic_tflops across modes, not frac",
+                    executed_terms_per_product=terms,
                     algorithmic_tflops=round(ach, 2), algorithmic_vs_fp32_mfma_peak=round(ach / MFMA_F32_PEAK_TF, 4),
                     **common,
-                    largest_launch=dict(shape_MxNxK=big[0][8:-1], us=round(big[2], 2), executed_tflops=round(6 * big[3], 1),
-                                        frac=round(6 * big[3] / MFMA_BF16_PEAK_TF, 4), algorithmic_tflops=round(big[3], 2)))
+                    largest_launch=dict(shape_MxNxK=big[0][8:-1], us=round(big[2], 2), executed_tflops=round(terms * big[3], 1),
+                                        frac=round(terms * big[3] / MFMA_BF16_PEAK_TF, 4), algorithmic_tflops=round(big[3], 2)))
 
     def roof_message():
         """GATA message STAGE: SURVEY 8d B_msg over the summed duration of the stage's launches (one fused launch,
@@ -434,7 +444,8 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
             "value": round(B * world * steps / dt, 1), "unit": "molecules/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if _engine_mode() == "f32" else "f32 (3xbf16-split MFMA, fp32 accumulate)", "data": "synthetic",
+            "dtype": {"f32": "f32", "split": "f32 (3xbf16-split MFMA, fp32 accumulate)",
+                      "f16x2": "f32 (2xfp16-split MFMA with block exponents, fp32 accumulate)"}[_engine_mode()], "data": "synthetic",
             "config": {"workload": f"{workload} batch={B}/GPU (N={N} atoms, E={E} edges incl. self-loops), "
                                    f"n_atom_basis={F}, n_interactions={L}, lmax={lmax}, n_rbf={R}, heads={H}, "
                                    "sep_dir/sep_tensor, energy+forces",

@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GN_LIB_PATH") or os.path.join(_PKG, "libgotennet_hip.so")
 
 GN_ERR_BAD_ARG = 10001
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 
@@ -55,6 +55,10 @@ SIGNATURES = {
     "gn_split_bf16x3": [_P, _I, _I, _P, _P],
     "gn_split_bf16x3_size": [_I, _I],
     "gn_gemm_group_split": [_P, _I, _P],
+    "gn_gemm_f16x2": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _I, _P],
+    "gn_split_f16x2": [_P, _I, _I, _P, _P],
+    "gn_split_f16x2_size": [_I, _I],
+    "gn_gemm_group_f16x2": [_P, _I, _P],
     "gn_htr_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "gn_message_backward": [_P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                             _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.c_long, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -101,7 +105,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes
-        fn.restype = C.c_long if name == "gn_split_bf16x3_size" else C.c_int
+        fn.restype = C.c_long if name in ("gn_split_bf16x3_size", "gn_split_f16x2_size") else C.c_int
     if lib.gn_abi_version(None) != ABI_VERSION:
         raise GotenNetHipError("libgotennet_hip.so ABI version mismatch; rebuild")
     _lib = lib

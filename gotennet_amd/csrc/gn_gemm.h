@@ -61,6 +61,34 @@ __device__ __forceinline__ void split4_trunc(float4 v, bf16x4& hi, bf16x4& mid, 
     lo = __builtin_bit_cast(bf16x4, l);
 }
 
+// ---- 2 x fp16 split with block exponents (MODE 2) --------------------------------------------------------------
+// x' = x * 2^-e with |x'| < 2^15 (e: a per-block power of two, see gemm_body), x' = hi + lo with hi = fp16(x') and
+// lo = fp16(x' - hi): 22 significand bits in two planes, so an fp32 product needs THREE fp16 MFMAs (hi*hi, hi*lo, lo*hi;
+// lo*lo is below 2^-22 of the product) instead of the six of the bf16 split.  fp16 has five exponent bits: elements more
+// than 2^17 below their block's maximum keep fewer bits (absolute error <= 2^-39 of the block maximum) -- harmless in a
+// dot product, which is dominated by the block's large elements.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4_f16(float4 v, int neg_e, f16x4& hi, f16x4& lo) {
+    const float a0 = ldexpf(v.x, neg_e), a1 = ldexpf(v.y, neg_e), a2 = ldexpf(v.z, neg_e), a3 = ldexpf(v.w, neg_e);
+    const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1, h2 = (_Float16)a2, h3 = (_Float16)a3;
+    hi = f16x4{h0, h1, h2, h3};
+    lo = f16x4{(_Float16)(a0 - (float)h0), (_Float16)(a1 - (float)h1), (_Float16)(a2 - (float)h2), (_Float16)(a3 - (float)h3)};
+}
+
+// wave-wide maximum of an unsigned value without touching LDS: row_shr 1/2/4/8 (zero-filled), then row_bcast 15 and 31;
+// the result is read from lane 63 and is wave-uniform (an SGPR)
+__device__ __forceinline__ unsigned wave_umax_sgpr(unsigned v) {
+    auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ int phys_row(const GemmArgs& p, int r) {
     // identity row map (row_cnt = 1: every product except the per-degree W_vk ones): no integer division -- the
     // epilogue calls this once per stored row, and a runtime division is ~40 VALU instructions
@@ -73,7 +101,8 @@ __device__ __forceinline__ int phys_row(const GemmArgs& p, int r) {
 }  // namespace gn
 
 // launcher for a group of n <= GN_MAX_GROUP problems (gn_gemm.hip).  split = 0: exact fp32 MFMA, W = fp32 [N][K];
-// split = 1: 3 x bf16-split MFMA, W = the fragment-major bf16 planes written by gn_split_bf16x3
+// split = 1: 3 x bf16-split MFMA, W = the fragment-major bf16 planes written by gn_split_bf16x3;
+// split = 2: 2 x fp16-split MFMA with block exponents, W = the planes (+ header) written by gn_split_f16x2
 int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split);
 
 // wave-specialised split kernel (gn_gemm_ws.hip): eligibility of a group and its launch (ga as built by gn_gemm_launch)

@@ -75,18 +75,29 @@ namespace gn {
 // tile is (32 TM WM) x (32 TN WN).  Exact fp32: 2 x 2 waves.  SPLIT, 128 x 128 tile: 1 x 4 waves of 4 x 1 tiles -- every
 // wave then needs ONE 32-column block of the weight per k-step (3 KiB from L2 through the 64 B/clk L1 path instead of
 // 6 KiB with 2 x 2 tiles per wave) and re-reads the whole A slab from LDS, which has the bandwidth to spare.
-template <int TM, int TN, int WM, int WN, bool PRO, int PF, bool SPLIT, bool ASILU>
+// MODE: 0 exact fp32 MFMA, 1 three bf16 planes (six MFMA terms), 2 two scaled fp16 planes (three MFMA terms, gn_gemm.h)
+template <int TM, int TN, int WM, int WN, bool PRO, int PF, int MODE, bool ASILU>
 __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
     static_assert(WM * WN == 4, "four waves per workgroup");
+    constexpr bool SPLIT = MODE != 0;
+    constexpr bool F16 = MODE == 2;
+    constexpr int NP = F16 ? 2 : 3;                 // operand planes
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int RA = BM / 32, RB = BN / 32;       // staged float4 rows per thread
     constexpr int STAGE = (BM + BN) * PITCH;        // floats per K-slab buffer (A rows then W rows)
     constexpr int CP = BN + 4;                      // epilogue tile pitch
     constexpr int APL = BM * SPLIT_PB;              // SPLIT: bf16 elements per A plane of a slab
-    constexpr int STAGE_S = 3 * APL;                // SPLIT: bf16 elements per slab buffer
+    constexpr int STAGE_S = NP * APL;               // SPLIT: 16-bit elements per slab buffer
     constexpr int MAIN_FLOATS = SPLIT ? (2 * STAGE_S) / 2 : 2 * STAGE;
     constexpr int LDS_FLOATS = (MAIN_FLOATS > BM * CP) ? MAIN_FLOATS : BM * CP;
-    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+    // F16: + the block exponents of the two slab buffers, [2][4] signed bytes: wave q stages rows 8q..8q+7 of every
+    // 32-row M-tile, and those rows -- accumulator registers 4q..4q+3 of every MFMA tile -- share ONE exponent per slab.
+    // One dword per slab buffer, so "did anything change" is a single scalar compare per slab.
+    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS + (F16 ? 2 : 0)];
+    signed char* const exps = reinterpret_cast<signed char*>(smem + LDS_FLOATS);
+    int e_run = -120;                               // F16, staging side: running exponent of this wave's rows
+    unsigned e_acc = 0x88888888u;                   // F16, MFMA side: the four block exponents (bytes) the accumulators are held in
+    int ewt = 0;                                    // F16: the weight tensor's exponent (header of the packed planes)
 
     // One launch walks the tiles of up to GN_MAX_GROUP independent problems (a "group": the atom-sized products of
     // a layer are too small to fill 256 CUs one at a time).  Inside a problem tiles are row-tile major, so consecutive
@@ -201,7 +212,38 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
         for (int i = 0; i < RA; ++i) qa[i] = ld4(Ab + (size_t)prow[i] * p.lda + ka);   // prow of a row past M is row 0: valid memory
         kflag = kok;
     };
+    // F16: scale this wave's 8-row block of every M-tile by 2^-e (e = running maximum of the block's binary exponent
+    // over the slabs staged so far, so that |x'| < 2^15), split x' = hi + lo into two fp16 planes, publish e
+    auto stash_f16 = [&](int sb, const float4 (&v)[RA]) {
+        _Float16* d0 = reinterpret_cast<_Float16*>(smem) + sb * STAGE_S + sr * SPLIT_PB + 4 * c4;
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+        int need = (int)((wave_umax_sgpr(__float_as_uint(m)) >> 23) & 0xffu) - 126 - 15;          // |x| < 2^(need + 15)
+        need = need < -120 ? -120 : need;            // (a signed byte; blocks below 2^-105 keep fewer bits)
+        e_run = need > e_run ? need : e_run;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            f16x4 h, l;
+            split4_f16(v[i], -e_run, h, l);
+            _Float16* d = d0 + 32 * i * SPLIT_PB;
+            *reinterpret_cast<f16x4*>(d) = h;
+            *reinterpret_cast<f16x4*>(d + APL) = l;
+        }
+        if (lane == 0) exps[sb * 4 + wave] = (signed char)e_run;
+    };
     auto stashA = [&](int sb, const float4 (&qa)[RA], bool kflag) {
+        if constexpr (F16) {
+            float4 v[RA];
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const bool ok = aok[i] && kflag;
+                v[i] = make_float4(ok ? qa[i].x : 0.f, ok ? qa[i].y : 0.f, ok ? qa[i].z : 0.f, ok ? qa[i].w : 0.f);
+            }
+            stash_f16(sb, v);
+            return;
+        }
         __bf16* d0 = reinterpret_cast<__bf16*>(smem) + sb * STAGE_S + sr * SPLIT_PB + 4 * c4;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
@@ -251,6 +293,8 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
     auto stash = [&](int sb, const float4 (&qa)[RA], const float4 (&qb)[RB]) {
         if constexpr (L2) {
             stashA(sb, qa2[0], kok2[0]);
+        } else if constexpr (F16) {
+            stash_f16(sb, qa);
         } else if constexpr (SPLIT) {
             __bf16* d0 = reinterpret_cast<__bf16*>(smem) + sb * STAGE_S + sr * SPLIT_PB + 4 * c4;
 #pragma unroll
@@ -270,26 +314,48 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
             for (int i = 0; i < RB; ++i) st4(&buf[(BM + sr + 32 * i) * PITCH + 4 * c4], qb[i]);
         }
     };
-    // SPLIT: B operands of k-step g (16 deep) for this wave's TN column blocks, three planes each, L2 -> registers
+    // SPLIT: B operands of k-step g (16 deep) for this wave's TN column blocks, NP planes each, L2 -> registers
+    // (F16: the packed planes start with a 256-byte header whose first int is the weight tensor's exponent)
     const uint4* wfrag = reinterpret_cast<const uint4*>(p.W);
     int ks2 = 0;                                    // k-steps per column block in the fragment-major weight (even)
     size_t nt_off[TN];
     auto set_btile = [&](int n0b) {
-        wfrag = reinterpret_cast<const uint4*>(p.W);
+        wfrag = reinterpret_cast<const uint4*>(p.W) + (F16 ? 16 : 0);
+        if constexpr (F16) ewt = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(p.W));
         ks2 = 2 * ((p.K + BK - 1) / BK);
         const int nt_last = (p.N + 31) / 32 - 1;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             int nt = n0b / 32 + wn * TN + j;
             nt = nt < nt_last ? nt : nt_last;        // column blocks past N: any valid block (results are never stored)
-            nt_off[j] = (size_t)nt * ks2 * 192 + lane;
+            nt_off[j] = (size_t)nt * ks2 * (NP * 64) + lane;
         }
     };
-    auto load_b = [&](int g, uint4 (&q)[TN][3]) {
+    auto load_b = [&](int g, uint4 (&q)[TN][NP]) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int s_ = 0; s_ < 3; ++s_) q[j][s_] = wfrag[nt_off[j] + (size_t)(g * 3 + s_) * 64];
+            for (int s_ = 0; s_ < NP; ++s_) q[j][s_] = wfrag[nt_off[j] + (size_t)(g * NP + s_) * 64];
+    };
+    // F16: bring the accumulator rows of every 8-row block to the exponent slab buffer `sb` was staged with.  The
+    // exponents only grow and settle after the first slabs: the common case is TM scalar compares that all fall through.
+    auto rescale = [&](int sb) {
+        const unsigned en = (unsigned)__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(exps + sb * 4));
+        if (__builtin_expect(en != e_acc, 0)) {
+            asm volatile("" ::: "memory");              // a real branch: never if-convert the multiplies
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int eo = (int)(signed char)(e_acc >> (8 * q)), e1 = (int)(signed char)(en >> (8 * q));
+                const float f = ldexpf(1.0f, eo - e1);                  // exponents only grow: f <= 1, exact
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][4 * q + r] *= f;
+            }
+            e_acc = en;
+        }
     };
 
     // double-buffered LDS K loop, one barrier per slab; register set s holds slab kt+1 when slab kt is
@@ -319,8 +385,12 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if constexpr (F16) {
+        e_run = -120;
+        e_acc = 0x88888888u;                         // -120 in every byte (the accumulators are zero)
+    }
     stash(0, pa[0], pb[0]);
-    uint4 bq[2][TN][3];
+    uint4 bq[2][TN][NP];
     if constexpr (SPLIT) {
         set_btile(n0);
         load_b(0, bq[0]);
@@ -336,7 +406,27 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
         // the barrier slab kt + 2 goes in flight from HBM.  The last slab is peeled so that the steady-state body has
         // no conditional code: it is ONE scheduling region and the split arithmetic can sit in the MFMAs' shadow.
         if (!L2 && nk > 1) fetch(BK, pa[0], pb[0]);
-        auto kstep = [&](const __bf16* Ap, int ks, const uint4 (&bw)[TN][3]) {
+        auto kstep = [&](const __bf16* Ap, int ks, const uint4 (&bw)[TN][NP]) {
+            if constexpr (F16) {
+                // x = hi + lo per operand: lo*hi, hi*lo, hi*hi (lo*lo is below 2^-22 of the product)
+                f16x8 a[TM][2];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int s_ = 0; s_ < 2; ++s_)
+                        a[i][s_] = *reinterpret_cast<const f16x8*>(Ap + s_ * APL + i * 32 * SPLIT_PB + ks * 16);
+                constexpr int TA[3] = {1, 0, 0};
+                constexpr int TB[3] = {0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                a[i][TA[t]], __builtin_bit_cast(f16x8, bw[j][TB[t]]), acc[i][j], 0, 0, 0);
+                return;
+            } else {
             bf16x8 a[TM][3];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -355,6 +445,7 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                             a[i][TA[t]], __builtin_bit_cast(bf16x8, bw[j][TB[t]]), acc[i][j], 0, 0, 0);
+            }
         };
         const __bf16* Abase = reinterpret_cast<const __bf16*>(smem) + (wm * 32 * TM + frow) * SPLIT_PB + (lane >> 5) * 8;
         if constexpr (L2) {
@@ -369,6 +460,7 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
                 if (!(GN_SPLIT_ABL & 1)) load_b(2 * kt + 1, bq[1]);
                 if constexpr (!last) { if (!(GN_SPLIT_ABL & 8)) fetchA((kt + 2) * BK, qa2[set], kok2[set]); }   // slab kt + 2 -> the set slab kt came from
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (F16) rescale(set);
                 kstep(Ap, 0, bq[0]);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!last) { if (!(GN_SPLIT_ABL & 1)) load_b(2 * kt + 2, bq[0]); }
@@ -398,6 +490,7 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
         for (int kt = 0; kt < nk; ++kt) {
             const __bf16* Ap = Abase + (kt & 1) * STAGE_S;
             load_b(2 * kt + 1, bq[1]);
+            if constexpr (F16) rescale(kt & 1);
             kstep(Ap, 0, bq[0]);
             if (kt + 1 < nk) load_b(2 * kt + 2, bq[0]);
             kstep(Ap, 1, bq[1]);
@@ -474,7 +567,9 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                smem[row * CP + wn * 32 * TN + j * 32 + (lane & 31)] = acc[i][j][r];
+                float v = acc[i][j][r];
+                if constexpr (F16) v *= ldexpf(1.0f, (int)(signed char)(e_acc >> (8 * (r >> 2))) + ewt);   // back from the block / weight exponents
+                smem[row * CP + wn * 32 * TN + j * 32 + (lane & 31)] = v;
             }
     __syncthreads();
     GN_TR(3);
@@ -551,14 +646,20 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
 // and the 64x64 fp32 kernel a wave of occupancy; models with another activation take the !ASILU instantiations.
 template <int TM, int TN, int WM, int WN, bool PRO, int PF, bool ASILU>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(const GroupArgs ga) {
-    gemm_body<TM, TN, WM, WN, PRO, PF, false, ASILU>(ga);
+    gemm_body<TM, TN, WM, WN, PRO, PF, 0, ASILU>(ga);
 }
 
 // 3 x bf16-split instantiation: two workgroups per CU (one wave of each per SIMD: while one is in its epilogue or at a
 // barrier the other feeds the matrix pipe), so the register budget is capped at 256 per lane.
 template <int TM, int TN, int WM, int WN, bool PRO, bool ASILU>
 __global__ __launch_bounds__(256, GN_SPLIT_MINW) void gemm_bf16x3_mfma(const GroupArgs ga) {
-    gemm_body<TM, TN, WM, WN, PRO, 1, true, ASILU>(ga);
+    gemm_body<TM, TN, WM, WN, PRO, 1, 1, ASILU>(ga);
+}
+
+// 2 x fp16-split instantiation (three MFMA terms per product, block exponents): same grid and tile shapes
+template <int TM, int TN, int WM, int WN, bool PRO, bool ASILU>
+__global__ __launch_bounds__(256, GN_SPLIT_MINW) void gemm_f16x2_mfma(const GroupArgs ga) {
+    gemm_body<TM, TN, WM, WN, PRO, 1, 2, ASILU>(ga);
 }
 
 }  // namespace gn
@@ -623,6 +724,8 @@ static int gemm_group_impl(const gn_gemm_desc* d, int n, void* stream, int split
 extern "C" int gn_gemm_group(const gn_gemm_desc* d, int n, void* stream) { return gemm_group_impl(d, n, stream, 0); }
 // the same group on the 3 x bf16-split path: every desc.W points to the planes written by gn_split_bf16x3
 extern "C" int gn_gemm_group_split(const gn_gemm_desc* d, int n, void* stream) { return gemm_group_impl(d, n, stream, 1); }
+// ... and on the 2 x fp16-split path: every desc.W points to the buffer written by gn_split_f16x2
+extern "C" int gn_gemm_group_f16x2(const gn_gemm_desc* d, int n, void* stream) { return gemm_group_impl(d, n, stream, 2); }
 
 // one launch for n <= GN_MAX_GROUP problems (validated by the callers)
 int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
@@ -673,7 +776,7 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     // results; measured on MI355X it ties this kernel -- 262 / 244 us vs 245 / 250 us on the two edge-sized products
     // of the C2 step -- so the simpler 4-wave kernel stays the default)
     static const bool ws_on = getenv("GN_GEMM_WS") && atoi(getenv("GN_GEMM_WS")) == 1;
-    if (split && use_big && BMB == 128 && ws_on && gn_gemm_ws_eligible(g, n)) return gn_gemm_ws_launch(ga, end, st);
+    if (split == 1 && use_big && BMB == 128 && ws_on && gn_gemm_ws_eligible(g, n)) return gn_gemm_ws_launch(ga, end, st);
     // persistent launch: at most 2 (big tiles) / 4 (small tiles) workgroups per CU walk the tile list (+2 %)
     long grid = 8L * ((end + 7) / 8);
     const long cap = use_big ? cap_big : 1024;
@@ -684,6 +787,11 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     do {                                                                                                              \
         if (silu) hipLaunchKernelGGL((gn::gemm_bf16x3_mfma<TM_, TN_, WM_, WN_, PRO_, true>), dim3((unsigned)grid), dim3(256), 0, st, ga); \
         else hipLaunchKernelGGL((gn::gemm_bf16x3_mfma<TM_, TN_, WM_, WN_, PRO_, false>), dim3((unsigned)grid), dim3(256), 0, st, ga);     \
+    } while (0)
+#define GN_GEMM_GO_H(TM_, TN_, WM_, WN_, PRO_)                                                                        \
+    do {                                                                                                              \
+        if (silu) hipLaunchKernelGGL((gn::gemm_f16x2_mfma<TM_, TN_, WM_, WN_, PRO_, true>), dim3((unsigned)grid), dim3(256), 0, st, ga); \
+        else hipLaunchKernelGGL((gn::gemm_f16x2_mfma<TM_, TN_, WM_, WN_, PRO_, false>), dim3((unsigned)grid), dim3(256), 0, st, ga);     \
     } while (0)
 #define GN_GEMM_GO_F(TM_, TN_, WM_, WN_, PRO_)                                                                        \
     do {                                                                                                              \
@@ -697,7 +805,10 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
 #else
 #define GN_SPLIT_BIG(PRO_) GN_GEMM_GO_S(2, 2, 2, 2, PRO_)
 #endif
-    if (split) {
+    if (split == 2) {
+        if (use_big) { if (pro) GN_GEMM_GO_H(4, 1, 1, 4, true); else GN_GEMM_GO_H(4, 1, 1, 4, false); }
+        else { if (pro) GN_GEMM_GO_H(1, 1, 2, 2, true); else GN_GEMM_GO_H(1, 1, 2, 2, false); }
+    } else if (split) {
         if (use_big) { if (pro) GN_SPLIT_BIG(true); else GN_SPLIT_BIG(false); }
         else { if (pro) GN_GEMM_GO_S(1, 1, 2, 2, true); else GN_GEMM_GO_S(1, 1, 2, 2, false); }
     } else {
@@ -706,9 +817,26 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     }
 #undef GN_SPLIT_BIG
 #undef GN_GEMM_GO_S
+#undef GN_GEMM_GO_H
 #undef GN_GEMM_GO_F
     GN_LAUNCH_CHECK();
     return GN_OK;
+}
+
+static int gemm_planes_single(const float* A, int lda, const unsigned short* W3, const float* bias, float* C, int ldc,
+                              int Mrows, int Nout, int K, int act_lo, int act_hi,
+                              int row_cnt, int row_gstride, int row_goff,
+                              const float* res, const float* gate, int gate_mode, float* pre_out,
+                              int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
+                              const float* a_gate, int ldg, int act_kind, void* stream, int mode) {
+    if (!gemm_args_ok(Mrows, Nout, K, lda, ldc, act_lo, act_hi, row_cnt, res, gate, gate_mode, pro_mode, pro_lo, pro_hi,
+                      a_pre, ldp, a_gate, ldg) || !W3 || act_kind < 0 || act_kind >= GN_ACT_COUNT)
+        return GN_ERR_BAD_ARG;
+    if (Mrows == 0) return GN_OK;
+    gn::GemmArgs p{A, reinterpret_cast<const float*>(W3), bias, C, res, gate, pre_out, a_pre, a_gate, lda, ldc, ldp, ldg,
+                   Mrows, Nout, K, act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, gate_mode,
+                   nullptr, nullptr, 0, 0, act_kind};
+    return gn_gemm_launch(&p, 1, (hipStream_t)stream, mode);
 }
 
 extern "C" int gn_gemm_split(const float* A, int lda, const unsigned short* W3, const float* bias, float* C, int ldc,
@@ -717,14 +845,18 @@ extern "C" int gn_gemm_split(const float* A, int lda, const unsigned short* W3, 
                              const float* res, const float* gate, int gate_mode, float* pre_out,
                              int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
                              const float* a_gate, int ldg, int act_kind, void* stream) {
-    if (!gemm_args_ok(Mrows, Nout, K, lda, ldc, act_lo, act_hi, row_cnt, res, gate, gate_mode, pro_mode, pro_lo, pro_hi,
-                      a_pre, ldp, a_gate, ldg) || !W3 || act_kind < 0 || act_kind >= GN_ACT_COUNT)
-        return GN_ERR_BAD_ARG;
-    if (Mrows == 0) return GN_OK;
-    gn::GemmArgs p{A, reinterpret_cast<const float*>(W3), bias, C, res, gate, pre_out, a_pre, a_gate, lda, ldc, ldp, ldg,
-                   Mrows, Nout, K, act_lo, act_hi, pro_mode, pro_lo, pro_hi, row_cnt, row_gstride, row_goff, gate_mode,
-                   nullptr, nullptr, 0, 0, act_kind};
-    return gn_gemm_launch(&p, 1, (hipStream_t)stream, 1);
+    return gemm_planes_single(A, lda, W3, bias, C, ldc, Mrows, Nout, K, act_lo, act_hi, row_cnt, row_gstride, row_goff, res,
+                              gate, gate_mode, pre_out, pro_mode, pro_lo, pro_hi, a_pre, ldp, a_gate, ldg, act_kind, stream, 1);
+}
+
+extern "C" int gn_gemm_f16x2(const float* A, int lda, const unsigned short* W2, const float* bias, float* C, int ldc,
+                             int Mrows, int Nout, int K, int act_lo, int act_hi,
+                             int row_cnt, int row_gstride, int row_goff,
+                             const float* res, const float* gate, int gate_mode, float* pre_out,
+                             int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
+                             const float* a_gate, int ldg, int act_kind, void* stream) {
+    return gemm_planes_single(A, lda, W2, bias, C, ldc, Mrows, Nout, K, act_lo, act_hi, row_cnt, row_gstride, row_goff, res,
+                              gate, gate_mode, pre_out, pro_mode, pro_lo, pro_hi, a_pre, ldp, a_gate, ldg, act_kind, stream, 2);
 }
 
 extern "C" int gn_gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc,

@@ -45,7 +45,55 @@ __global__ void split_bf16x3_frag_kernel(const float* __restrict__ w, int N, int
     o[1024] = (unsigned short)(__float_as_uint(lo) >> 16);
 }
 
+// ---- 2 x fp16 planes with a tensor exponent (MODE 2 of gemm_body) ---------------------------------------------------
+// out = [256-byte header: int exponent ewt, uint amax bits][nt][g][plane 0..1][lane][8 fp16]; planes hold
+// w' = w * 2^-ewt (|w'| < 2^15) as hi = fp16(w'), lo = fp16(w' - hi).  Two launches, no host read-back.
+__global__ void weight_amax_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ hdr) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float m = idx < n ? fabsf(w[idx]) : 0.f;
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(hdr + 1, __float_as_uint(m));      // |x| as uint: order-preserving, exact
+}
+__global__ void split_f16x2_frag_kernel(const float* __restrict__ w, int N, int K, int ks2, long total,
+                                        unsigned* __restrict__ hdr) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ewt = (int)((hdr[1] >> 23) & 0xffu) - 126 - 15;                  // |w| < 2^(ewt + 15)
+    if (idx == 0) reinterpret_cast<int*>(hdr)[0] = ewt;
+    if (idx >= total) return;
+    const int e = (int)(idx & 7);
+    const int lane = (int)((idx >> 3) & 63);
+    const long rest = idx >> 9;
+    const int g = (int)(rest % ks2);
+    const long nt = rest / ks2;
+    const long n = nt * 32 + (lane & 31);
+    const int k = 16 * g + 8 * (lane >> 5) + e;
+    const float x = ldexpf((n < N && k < K) ? w[n * K + k] : 0.f, -ewt);
+    const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
+    _Float16* o = reinterpret_cast<_Float16*>(hdr) + 128 + ((nt * ks2 + g) * 2) * 512 + lane * 8 + e;
+    o[0] = hi;
+    o[512] = lo;
+}
+
 }  // namespace gn
+
+extern "C" long gn_split_f16x2_size(int N, int K) {            // in 16-bit elements, header included
+    if (N <= 0 || K <= 0) return 0;
+    return 128 + (long)((N + 31) / 32) * (2L * ((K + gn::BK - 1) / gn::BK)) * 2 * 512;
+}
+
+extern "C" int gn_split_f16x2(const float* w, int N, int K, unsigned short* out, void* stream) {
+    if (N <= 0 || K <= 0 || !w || !out) return GN_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int ks2 = 2 * ((K + gn::BK - 1) / gn::BK);
+    const long total = (long)((N + 31) / 32) * ks2 * 512, n = (long)N * K;
+    if (hipMemsetAsync(out, 0, 256, st) != hipSuccess) return GN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gn::weight_amax_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, n,
+                       reinterpret_cast<unsigned*>(out));
+    hipLaunchKernelGGL(gn::split_f16x2_frag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, N, K, ks2,
+                       total, reinterpret_cast<unsigned*>(out));
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
 
 extern "C" long gn_split_bf16x3_size(int N, int K) {
     if (N <= 0 || K <= 0) return 0;

@@ -102,24 +102,37 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-#: projection arithmetic: "split" (default) = every fp32 operand as three bf16 planes, six bf16 MFMAs per product,
-#: fp32 accumulate: fp32-class error (<= 1e-6 vs an fp64 product, the same as the exact kernel; every GPU parity test
-#: runs in both modes) at 2.67x the fp32 MFMA rate; "f32" = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf
-#: chain).  Env GN_GEMM_MODE overrides.
-GEMM_MODE = os.environ.get("GN_GEMM_MODE", "split")
+#: projection arithmetic (env GN_GEMM_MODE overrides; every GPU parity test runs in all three):
+#:   "f16x2" (default) -- every fp32 operand as two fp16 planes scaled by block exponents (A: per 8 rows x 32 columns,
+#:       running maximum, accumulators rescaled when it grows; W: per tensor), THREE fp16 MFMAs per product, fp32
+#:       accumulate: <= 3e-7 of the output's max-norm vs an fp64 product.  Results depend on how rows fall into 8-row
+#:       blocks at the 1e-7 level (a molecule's energy moves by ~1e-6 relative when its position in the batch changes);
+#:       identical inputs give identical bits.
+#:   "split" -- three bf16 planes, six bf16 MFMAs per product: same error class, row-wise arithmetic independent of the
+#:       batch layout (bit-exact batch independence), 14 % slower on the C2 step.
+#:   "f32"   -- exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain), 40 % slower.
+GEMM_MODE = os.environ.get("GN_GEMM_MODE", "f16x2")
+
+
+#: projection arithmetic -> (single-product entry point, grouped entry point, weight packer, its size query, dtype)
+_PLANE_MODES = {"split": ("gn_gemm_split", "gn_gemm_group_split", "gn_split_bf16x3", "gn_split_bf16x3_size", torch.bfloat16),
+                "f16x2": ("gn_gemm_f16x2", "gn_gemm_group_f16x2", "gn_split_f16x2", "gn_split_f16x2_size", torch.float16)}
 
 
 def split_weight(W: torch.Tensor) -> torch.Tensor:
-    """bf16 hi/mid/lo planes of a weight [N, K] in the MFMA-fragment-major order of gn_split_bf16x3, cached ON the
-    tensor object (the packed weights are long-lived; GotenNet.invalidate_packed() drops them with the pack)."""
-    cached = getattr(W, "_gn_split", None)
+    """Operand planes of a weight [N, K] for the current GEMM_MODE in MFMA-fragment-major order (gn_split_bf16x3: bf16
+    hi/mid/lo; gn_split_f16x2: header + fp16 hi/lo), cached ON the tensor object per mode (the packed weights are
+    long-lived; GotenNet.invalidate_packed() drops them with the pack)."""
+    key = "_gn_split_" + GEMM_MODE
+    cached = getattr(W, key, None)
     if cached is not None and cached[0] == W._version and cached[1] == W.data_ptr():
         return cached[2]
+    _, _, packer, sizer, dt = _PLANE_MODES[GEMM_MODE]
     N, K = W.shape
-    w3 = torch.empty(_lib.load().gn_split_bf16x3_size(N, K), dtype=torch.bfloat16, device=W.device)
-    call("gn_split_bf16x3", ptr(W.contiguous()), N, K, ptr(w3), _stream())
-    W._gn_split = (W._version, W.data_ptr(), w3)
-    return w3
+    planes = torch.empty(getattr(_lib.load(), sizer)(N, K), dtype=dt, device=W.device)
+    call(packer, ptr(W.contiguous()), N, K, ptr(planes), _stream())
+    setattr(W, key, (W._version, W.data_ptr(), planes))
+    return planes
 
 
 def gemm(A, lda, W, bias, C, ldc, rows, nout, K, act=(0, 0), rowmap=(1, 1, 0), res=None, gate=None,
@@ -128,8 +141,8 @@ def gemm(A, lda, W, bias, C, ldc, rows, nout, K, act=(0, 0), rowmap=(1, 1, 0), r
     """C = epi(pro(A) W^T + bias); ``kind``: GN_ACT_* of the activated columns / SiLU' gates / prologues.  ``a_off`` / ``c_off`` / ``p_off`` / ``g_off``: float offsets of the first
     column.  ``dgate``: multiply the output by SiLU'(dgate) (same addressing as C)."""
     name = "gn_gemm_ex"
-    if GEMM_MODE == "split":
-        name, W = "gn_gemm_split", split_weight(W)
+    if GEMM_MODE in _PLANE_MODES:
+        name, W = _PLANE_MODES[GEMM_MODE][0], split_weight(W)
     call(name, A.data_ptr() + 4 * a_off, lda, ptr(W), ptr(bias), C.data_ptr() + 4 * c_off, ldc,
          rows, nout, K, act[0], act[1], rowmap[0], rowmap[1], rowmap[2], ptr(res),
          (dgate.data_ptr() + 4 * g_off) if dgate is not None else ptr(gate), 1 if dgate is not None else 0, ptr(pre_out),
@@ -141,7 +154,7 @@ def gemm_group(problems):
     """Several INDEPENDENT ``gemm(...)`` calls (a list of argument dicts) as ONE launch (gn_gemm_group, or
     gn_gemm_group_split with the weights replaced by their cached bf16 planes)."""
     problems = [q for q in problems if q is not None]
-    split = GEMM_MODE == "split"
+    split = GEMM_MODE in _PLANE_MODES
     for i0 in range(0, len(problems), 4):
         chunk = problems[i0:i0 + 4]
         arr = (_lib.GemmDesc * len(chunk))()
@@ -166,7 +179,7 @@ def gemm_group(problems):
             d.a_gate = ptr(g("a_gate")); d.ldg = g("ldg", 0)
             d.A2, d.A3, d.a_seg = ptr(g("A2")), ptr(g("A3")), g("a_seg", 0)
             d.act_kind = g("kind", ACT)
-        call("gn_gemm_group_split" if split else "gn_gemm_group", arr, len(chunk), _stream())
+        call(_PLANE_MODES[GEMM_MODE][1] if split else "gn_gemm_group", arr, len(chunk), _stream())
 
 
 #: GN_ACT_* kind the grouped GEMM descriptors default to: set by ``forward`` / ``backward`` / ``gata_layer`` / ``eqff_layer``

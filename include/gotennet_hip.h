@@ -37,7 +37,7 @@ extern "C" {
 
 #define GN_OK 0
 #define GN_ERR_BAD_ARG 10001     /* shape/flag combination the kernels do not implement */
-#define GN_ABI_VERSION 4
+#define GN_ABI_VERSION 5
 
 /* `act`: the element-wise activation of the reference's `activation` constructor argument (str2act, layers.py:596-700;
  * shifted_softplus layers.py:40-50).  Wherever an entry point below says SiLU, it means this kind. */
@@ -177,6 +177,23 @@ int gn_gemm_split(const float* A, int lda, const unsigned short* W3, const float
                   const float* a_gate, int ldg, int act_kind, void* stream);
 /* gn_gemm_group on the split path: every problems[i].W points to gn_split_bf16x3 planes (cast to const float*). */
 int gn_gemm_group_split(const gn_gemm_desc* problems, int n, void* stream);
+
+/* 2 x fp16 split variant with block exponents: the same contract again, every weight passed as the buffer written
+ * ONCE per weight by gn_split_f16x2 (a 256-byte header holding the tensor's binary exponent, then two fp16 planes
+ * hi + lo of w * 2^-exponent in the same fragment-major order; gn_split_f16x2_size(N, K) 16-bit elements; the amax is
+ * found on the device, no host read-back).  A is scaled per 8-row x 32-column block by the running maximum of the
+ * block's binary exponent (exact powers of two, accumulators rescaled when it grows), split into two fp16 planes, and
+ * the product accumulated in fp32 from THREE plane pairs on v_mfma_f32_32x32x16_f16 -- half the matrix work of the
+ * bf16 split; 22 significand bits per operand: <= 2e-7 of the output's max-norm against an fp64 product. */
+long gn_split_f16x2_size(int N, int K);
+int gn_split_f16x2(const float* w /* [N][K] fp32 */, int N, int K, unsigned short* out, void* stream);
+int gn_gemm_f16x2(const float* A, int lda, const unsigned short* W2, const float* bias, float* C, int ldc,
+                  int Mrows, int Nout, int K, int act_lo, int act_hi,
+                  int row_cnt, int row_gstride, int row_goff,
+                  const float* res, const float* gate, int gate_mode, float* pre_out,
+                  int pro_mode, int pro_lo, int pro_hi, const float* a_pre, int ldp,
+                  const float* a_gate, int ldg, int act_kind, void* stream);
+int gn_gemm_group_f16x2(const gn_gemm_desc* problems, int n, void* stream);
 
 /* ---- K6 GATA message / softmax / aggregate -------------------------------------------- */
 /* Attention weights (gotennet.py:497-511): s[e,h] = sum_{c in head h} q[i,c] k[j,c] t_attn[e,c];

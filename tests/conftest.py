@@ -17,9 +17,10 @@ def repo_root():
     return ROOT
 
 
-@pytest.fixture(params=["f32", "split"])
+@pytest.fixture(params=["f32", "split", "f16x2"])
 def gemm_mode(request):
-    """Run a GPU parity test in both projection arithmetics: exact fp32 MFMA and the 3 x bf16-split MFMA."""
+    """Run a GPU parity test in every projection arithmetic: exact fp32 MFMA, the 3 x bf16-split MFMA and the
+    2 x fp16-split MFMA with block exponents."""
     from gotennet_amd import engine
     old = engine.GEMM_MODE
     engine.GEMM_MODE = request.param

@@ -3,7 +3,8 @@ must give the energies and forces of the 128-molecule batch, bit for bit.   pyth
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 import gotennet_amd
-from gotennet_amd import synthetic
+from gotennet_amd import engine, synthetic
+engine.GEMM_MODE = os.environ.get("GN_GEMM_MODE", "split")      # bit-exact batch independence holds for the row-wise arithmetics
 from gotennet_amd.graph import distance
 from gotennet_amd.outputs import Atomwise
 from gotennet_amd.pipeline import EnergyForces
