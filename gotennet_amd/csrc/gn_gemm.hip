@@ -221,6 +221,17 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
         for (int i = 0; i < RA; ++i)
             m = fmaxf(m, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
         int need = (int)((wave_umax_sgpr(__float_as_uint(m)) >> 23) & 0xffu) - 126 - 15;          // |x| < 2^(need + 15)
+        if (__builtin_expect(need > 112, 0)) {       // an Inf (a NaN never wins v_max) in the block: scale by its FINITE
+            asm volatile("" ::: "memory");           // values, so that only the rows that hold the Inf turn non-finite
+            float mf = 0.f;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const float c[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) mf = fmaxf(mf, fabsf(c[t]) <= 3.0e38f ? fabsf(c[t]) : 0.f);
+            }
+            need = (int)((wave_umax_sgpr(__float_as_uint(mf)) >> 23) & 0xffu) - 126 - 15;
+        }
         need = need < -120 ? -120 : need;            // (a signed byte; blocks below 2^-105 keep fewer bits)
         e_run = need > e_run ? need : e_run;
 #pragma unroll

@@ -367,3 +367,61 @@ torch.save([v.cpu() for v in (ep, na, pre, t2, gout, gnp)], sys.argv[1])
             outs[ws] = torch.load(path)
     for a, b in zip(outs["0"], outs["1"]):
         assert torch.equal(a, b)
+
+
+def test_fp16_block_exponent_products_on_hostile_operands():
+    """The default projection arithmetic (two fp16 planes, running block exponents) against an fp64 product on operands
+    chosen to stress the scaling: magnitudes from 1e-20 to 1e+20, rows eight decades apart inside one 8-row block, a K
+    range whose leading slabs are 1e-9 of the trailing ones (the accumulators must be rescaled mid-tile) and the reverse,
+    all-zero blocks, a K-segmented A operand whose three segments differ by 1e6, and non-finite inputs (must propagate,
+    not turn finite).  Tolerance: 5e-7 of the output's max-norm (an fp32 matmul is at 5e-7 on the same operands)."""
+    from gotennet_amd import engine
+    old, engine.GEMM_MODE = engine.GEMM_MODE, "f16x2"
+    try:
+        g = torch.Generator(device="cuda").manual_seed(3)
+        rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+
+        def run(A, W, **kw):
+            M, K = A.shape[0], W.shape[1]
+            C = torch.empty(M, W.shape[0], device="cuda")
+            engine.gemm_group([dict(A=A, lda=A.shape[1], W=W, C=C, ldc=W.shape[0], rows=M, nout=W.shape[0], K=K, **kw)])
+            torch.cuda.synchronize()
+            return C
+
+        def check(A, W, tol=5e-7):
+            C, ref = run(A, W), A.double() @ W.double().t()
+            assert rel_err(C.double().cpu(), ref.cpu()) < tol, rel_err(C.double().cpu(), ref.cpu())
+
+        W = rn(192, 256) * 0.1
+        for scale in (1e-20, 1e-6, 1.0, 1e6, 1e20):
+            check(rn(700, 256) * scale, W)
+            check(rn(700, 256), W * scale)
+        rows = rn(700, 256) * (10.0 ** torch.randint(-8, 1, (700, 1), device="cuda", generator=g).float())
+        check(rows, W)
+        grow = rn(700, 256)
+        grow[:, :96] *= 1e-9                                      # small slabs first: exponents grow, accumulators rescale
+        check(grow, W)
+        shrink = rn(700, 256)
+        shrink[:, 160:] *= 1e-9
+        check(shrink, W)
+        holes = rn(700, 256)
+        holes[64:200] = 0.0
+        holes[:, 32:64] = 0.0
+        check(holes, W)
+        check(torch.zeros(130, 256, device="cuda"), W, tol=1.0)   # 0 / 0: just must not produce NaN
+        assert float(run(torch.zeros(130, 256, device="cuda"), W).abs().max()) == 0.0
+        # K-segmented A (three tensors along K, gX = gXp W_vu + gEQ W_vq + gEK W_vk): segments 1e6 apart
+        A1, A2, A3 = rn(500, 64) * 1e-3, rn(500, 64) * 1e3, rn(500, 64)
+        Wc = rn(64, 192) * 0.1
+        C = run(A1, Wc, A2=A2, A3=A3, a_seg=64)
+        ref = torch.cat([A1, A2, A3], 1).double() @ Wc.double().t()
+        assert rel_err(C.double().cpu(), ref.cpu()) < 5e-7
+        # non-finite inputs propagate
+        bad = rn(300, 256)
+        bad[7, 5], bad[200, 100] = float("inf"), float("nan")
+        out = run(bad, W)
+        assert not torch.isfinite(out[7]).any() or torch.isnan(out[7]).any()
+        assert torch.isnan(out[200]).all()
+        assert torch.isfinite(out[100]).all()                     # other 8-row blocks are untouched
+    finally:
+        engine.GEMM_MODE = old

@@ -35,7 +35,7 @@ for L in (2, 4):
     msg = [k for k, _ in pick(f, "message_aggregate")]                     # 1 kernel at lmax 2, the degree groups above
     soft = pick(f, "attn_softmax_kernel")[0][0]
     htr = pick(f, "htr_edge_kernel")[0][0]
-    gem = [k for k, _ in pick(f, "gemm_bf16x3_mfma")]
+    gem = [k for k, _ in pick(f, "gn::gemm_") if "split" not in k]           # the projection kernels of the default mode
     n = sum(f[k][1] for k in gem)
     entry = {
         "gn_message_aggregate": sum(byt(k) for k in msg),

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile on the GPU box: rocprofv3 kernel stats + PMC passes (FETCH_SIZE / WRITE_SIZE, separate passes) for
-# lmax 2 and 4 in the default projection mode, kernel stats of the exact-fp32 mode; summaries under gpurun_out/profiles/.
+# lmax 2 and 4 in the default projection mode, kernel stats of the exact-fp32 and bf16x3 modes; summaries under gpurun_out/profiles/.
 #   bash tools/profile_round.sh r02
 R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -11,6 +11,7 @@ for L in 2 4; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/prof_write_l$L -o r -- $B --lmax $L --steps 2 --warmup 1 > /dev/null 2>&1
 done
 GN_GEMM_MODE=f32 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats_f32 -o r -- $B --lmax 2 --steps 5 --warmup 2 > /dev/null 2>&1
+GN_GEMM_MODE=split rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats_bf16x3 -o r -- $B --lmax 2 --steps 5 --warmup 2 > /dev/null 2>&1
 
 # summarise on the box (the rocpd databases are too large to ship back) and drop the databases
 mkdir -p gpurun_out/profiles
@@ -20,5 +21,6 @@ for L in 2 4; do
   python tools/rocprof_summary.py gpurun_out/prof_write_l$L/r_results.db 2>/dev/null | grep -E "^# source|^# PMC|gn::" > gpurun_out/profiles/${R}_pmc_write_size_lmax$L.txt
 done
 python tools/rocprof_summary.py gpurun_out/prof_stats_f32/r_results.db 2>/dev/null > gpurun_out/profiles/${R}_kernel_stats_lmax2_exact_f32.txt
-rm -rf gpurun_out/prof_stats_l* gpurun_out/prof_fetch_l* gpurun_out/prof_write_l* gpurun_out/prof_stats_f32
+python tools/rocprof_summary.py gpurun_out/prof_stats_bf16x3/r_results.db 2>/dev/null > gpurun_out/profiles/${R}_kernel_stats_lmax2_bf16x3.txt
+rm -rf gpurun_out/prof_stats_l* gpurun_out/prof_fetch_l* gpurun_out/prof_write_l* gpurun_out/prof_stats_f32 gpurun_out/prof_stats_bf16x3
 ls -la gpurun_out/profiles
