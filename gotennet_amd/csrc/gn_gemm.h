@@ -69,11 +69,17 @@ __device__ __forceinline__ void split4_trunc(float4 v, bf16x4& hi, bf16x4& mid, 
 // dot product, which is dominated by the block's large elements.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split4_f16(float4 v, int neg_e, f16x4& hi, f16x4& lo) {
-    const float a0 = ldexpf(v.x, neg_e), a1 = ldexpf(v.y, neg_e), a2 = ldexpf(v.z, neg_e), a3 = ldexpf(v.w, neg_e);
-    const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1, h2 = (_Float16)a2, h3 = (_Float16)a3;
-    hi = f16x4{h0, h1, h2, h3};
-    lo = f16x4{(_Float16)(a0 - (float)h0), (_Float16)(a1 - (float)h1), (_Float16)(a2 - (float)h2), (_Float16)(a3 - (float)h3)};
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// vector forms so that the compiler picks the packed instructions of gfx950: v_pk_mul_f32, v_cvt_pk_f16_f32 (round to
+// nearest even), v_pk_add_f32 -- 3 VALU per element instead of 6 with scalar ldexp / convert / subtract
+__device__ __forceinline__ void split4_f16(float4 v, float scale /* 2^-e */, f16x4& hi, f16x4& lo) {
+    const f32x2 a0 = f32x2{v.x, v.y} * scale, a1 = f32x2{v.z, v.w} * scale;
+    const f16x2 h0 = __builtin_convertvector(a0, f16x2), h1 = __builtin_convertvector(a1, f16x2);
+    const f16x2 l0 = __builtin_convertvector(a0 - __builtin_convertvector(h0, f32x2), f16x2);
+    const f16x2 l1 = __builtin_convertvector(a1 - __builtin_convertvector(h1, f32x2), f16x2);
+    hi = f16x4{h0.x, h0.y, h1.x, h1.y};
+    lo = f16x4{l0.x, l0.y, l1.x, l1.y};
 }
 
 // wave-wide maximum of an unsigned value without touching LDS: row_shr 1/2/4/8 (zero-filled), then row_bcast 15 and 31;

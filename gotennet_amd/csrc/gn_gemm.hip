@@ -234,10 +234,11 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
         }
         need = need < -120 ? -120 : need;            // (a signed byte; blocks below 2^-105 keep fewer bits)
         e_run = need > e_run ? need : e_run;
+        const float scale = __uint_as_float((unsigned)(127 - e_run) << 23);        // 2^-e_run (e_run in [-120, 113])
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             f16x4 h, l;
-            split4_f16(v[i], -e_run, h, l);
+            split4_f16(v[i], scale, h, l);
             _Float16* d = d0 + 32 * i * SPLIT_PB;
             *reinterpret_cast<f16x4*>(d) = h;
             *reinterpret_cast<f16x4*>(d + APL) = l;
