@@ -167,8 +167,10 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
     int prow[RA];
     const float* brow[RB];
     bool aok[RA], bok[RB];
+    bool a_full = false;                            // every row of the tile is inside M and K is a multiple of the slab depth: no masks
     auto set_tile = [&](int t_idx) {
         const int m0f = ((t_idx - g_begin) / tiles_n) * BM, n0f = ((t_idx - g_begin) % tiles_n) * BN;
+        a_full = m0f + BM <= p.M && (p.K % BK) == 0;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int gm = m0f + sr + 32 * i;
@@ -247,6 +249,10 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
     };
     auto stashA = [&](int sb, const float4 (&qa)[RA], bool kflag) {
         if constexpr (F16) {
+            if (a_full) {                            // interior tile (wave-uniform): 16 selects and their compares less per slab
+                stash_f16(sb, qa);
+                return;
+            }
             float4 v[RA];
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
