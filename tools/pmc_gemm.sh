@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes over one GEMM shape (GM/GN/GK env, default the 54368x1536x256 edge projection; GN_GEMM_MODE picks the
-# arithmetic, default 3xbf16-split): issue/stall breakdown.  One counter set per pass (--kernel-trace + --pmc only).
+# arithmetic, default 2xfp16-split): issue/stall breakdown.  One counter set per pass (--kernel-trace + --pmc only).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 i=0
 for SET in "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" \
