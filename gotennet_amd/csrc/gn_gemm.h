@@ -113,4 +113,4 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split);
 
 // wave-specialised split kernel (gn_gemm_ws.hip): eligibility of a group and its launch (ga as built by gn_gemm_launch)
 bool gn_gemm_ws_eligible(const gn::GemmArgs* g, int n);
-int gn_gemm_ws_launch(const gn::GroupArgs& ga, long tiles, hipStream_t st);
+int gn_gemm_ws_launch(const gn::GroupArgs& ga, long tiles, hipStream_t st, int mode /* 1 bf16x3, 2 fp16x2 */);

@@ -794,7 +794,7 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     // results; measured on MI355X it ties this kernel -- 262 / 244 us vs 245 / 250 us on the two edge-sized products
     // of the C2 step -- so the simpler 4-wave kernel stays the default)
     static const bool ws_on = getenv("GN_GEMM_WS") && atoi(getenv("GN_GEMM_WS")) == 1;
-    if (split == 1 && use_big && BMB == 128 && ws_on && gn_gemm_ws_eligible(g, n)) return gn_gemm_ws_launch(ga, end, st);
+    if (split && use_big && BMB == 128 && ws_on && gn_gemm_ws_eligible(g, n)) return gn_gemm_ws_launch(ga, end, st, split);
     // persistent launch: at most 2 (big tiles) / 4 (small tiles) workgroups per CU walk the tile list (+2 %)
     long grid = 8L * ((end + 7) / 8);
     const long cap = use_big ? cap_big : 1024;

@@ -47,15 +47,22 @@ extern "C" int gn_debug_trace_ws(long long* host_out) {
 namespace gn {
 
 constexpr int WS_BM = 128, WS_BN = 128, WS_CP = WS_BN + 4;
-constexpr int WS_APL = WS_BM * SPLIT_PB;            // bf16 elements per A plane of a slab
-constexpr int WS_STAGE = 3 * WS_APL;                // bf16 elements per slab buffer
+constexpr int WS_APL = WS_BM * SPLIT_PB;            // 16-bit elements per A plane of a slab
 constexpr int WS_NBUF = 3;                          // A slab buffers in LDS (the producers run two slabs ahead)
-constexpr int WS_LDS_BYTES = WS_NBUF * WS_STAGE * 2 + WS_BM * WS_CP * 4;
 
+// F16 = false: three bf16 planes, six MFMA terms.  F16 = true: two fp16 planes scaled by running block exponents, three
+// terms (MODE 2 of gn_gemm.hip): producer wave q owns rows 8q..8q+7 of every 32-row MFMA tile and publishes their
+// exponent per slab buffer as one byte; the consumers rescale accumulator registers 4q..4q+3 when it grows.  Same block
+// structure, same term order as the 4-wave kernels: bit-identical results in both arithmetics.
+template <bool F16>
 __device__ __forceinline__ void gemm_ws_body(const GroupArgs ga) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[WS_LDS_BYTES];
+    constexpr int NP = F16 ? 2 : 3;
+    constexpr int WS_STAGE = NP * WS_APL;           // 16-bit elements per slab buffer
+    constexpr int WS_LDS_BYTES = WS_NBUF * WS_STAGE * 2 + WS_BM * WS_CP * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[WS_LDS_BYTES + 16];
     __bf16* Abuf = reinterpret_cast<__bf16*>(smem_raw);
     float* Cst = reinterpret_cast<float*>(smem_raw + WS_NBUF * WS_STAGE * 2);
+    signed char* exps = reinterpret_cast<signed char*>(smem_raw + WS_LDS_BYTES);       // F16: [WS_NBUF][4] block exponents
 
     // the XCD-aware tile walk of gn_gemm.hip (same order: an A row tile is pulled through one L2); scalars, no arrays
     // indexed at run time (those would live in scratch memory)
@@ -127,16 +134,43 @@ __device__ __forceinline__ void gemm_ws_body(const GroupArgs ga) {
         const int frow = lane & 31;
         const __bf16* Abase = Abuf + frow * SPLIT_PB + (lane >> 5) * 8;
         f32x16 acc[4];
-        uint4 bw[2][2][3];                                         // [slab parity][k-step][plane]
-        bf16x8 fa[2][3], fb[2][3];                                 // two fragment groups in flight
-        auto load_g = [&](const __bf16* Ap, int ks, int pair, bf16x8 (&f)[2][3]) {
+        uint4 bw[2][2][NP];                                        // [slab parity][k-step][plane]
+        bf16x8 fa[2][NP], fb[2][NP];                               // two fragment groups in flight (16-bit x 8: bf16 or fp16 bits)
+        unsigned e_acc = 0x88888888u;                              // F16: the four block exponents (bytes) the accumulators are held in
+        int ewt = 0;                                               // F16: exponent of the weight tensor
+        auto load_g = [&](const __bf16* Ap, int ks, int pair, bf16x8 (&f)[2][NP]) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int s_ = 0; s_ < 3; ++s_)
+                for (int s_ = 0; s_ < NP; ++s_)
                     f[i][s_] = *reinterpret_cast<const bf16x8*>(Ap + s_ * WS_APL + (2 * pair + i) * 32 * SPLIT_PB + ks * 16);
         };
-        auto mfma12 = [&](const bf16x8 (&f)[2][3], const uint4 (&w3)[3], f32x16& c0, f32x16& c1) {
+        auto rescale = [&](int buf) {                              // F16: accumulators to the exponents slab buffer `buf` was staged with
+            const unsigned en = (unsigned)__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(exps + buf * 4));
+            if (__builtin_expect(en != e_acc, 0)) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float f = ldexpf(1.0f, (int)(signed char)(e_acc >> (8 * q)) - (int)(signed char)(en >> (8 * q)));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][4 * q + r] *= f;
+                }
+                e_acc = en;
+            }
+        };
+        auto mfma12 = [&](const bf16x8 (&f)[2][NP], const uint4 (&w3)[NP], f32x16& c0, f32x16& c1) {
+            if constexpr (F16) {
+                constexpr int TA[3] = {1, 0, 0};                   // lo*hi, hi*lo, hi*hi
+                constexpr int TB[3] = {0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[0][TA[t]]), __builtin_bit_cast(f16x8, w3[TB[t]]), c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[1][TA[t]]), __builtin_bit_cast(f16x8, w3[TB[t]]), c1, 0, 0, 0);
+                }
+                return;
+            } else {
             // smallest terms first (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi): the same order per accumulator as
             // the 4-wave kernel, so the results are bit-identical to it
             constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
@@ -147,6 +181,7 @@ __device__ __forceinline__ void gemm_ws_body(const GroupArgs ga) {
                     c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0][TA[t]], __builtin_bit_cast(bf16x8, w3[TB[t]]), c0, 0, 0, 0);
                     c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1][TA[t]], __builtin_bit_cast(bf16x8, w3[TB[t]]), c1, 0, 0, 0);
                 }
+            }
             }
         };
         int rb = 0;                                                // LDS buffer of the current slab (global slab count mod 3)
@@ -166,9 +201,13 @@ __device__ __forceinline__ void gemm_ws_body(const GroupArgs ga) {
                 const int nt_last = (q.N + 31) / 32 - 1;
                 int nt = n0 / 32 + wave;
                 nt = nt < nt_last ? nt : nt_last;                  // column block past N: any valid block (never stored)
-                return reinterpret_cast<const uint4*>(q.W) + (size_t)nt * (2 * (q.K / BK)) * 192 + lane;
+                return reinterpret_cast<const uint4*>(q.W) + (F16 ? 16 : 0) + (size_t)nt * (2 * (q.K / BK)) * (NP * 64) + lane;
             };
             const uint4* wf = weights_of(p, local);
+            if constexpr (F16) {
+                ewt = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(p.W));
+                e_acc = 0x88888888u;
+            }
             const int next = idx + stride;
             const bool has_next = next < w.stop;
             const uint4* wf_n = wf;                                // weights of the next tile's first slab (prefetched in the last slab)
@@ -179,9 +218,9 @@ __device__ __forceinline__ void gemm_ws_body(const GroupArgs ga) {
                 GN_WS_PROBLEM(pn, gn_);
                 wf_n = weights_of(pn, ln_);
             }
-            auto load_b = [&](const uint4* wq, int g, uint4 (&q)[3]) {
+            auto load_b = [&](const uint4* wq, int g, uint4 (&q)[NP]) {
 #pragma unroll
-                for (int s_ = 0; s_ < 3; ++s_) q[s_] = wq[(size_t)(g * 3 + s_) * 64];
+                for (int s_ = 0; s_ < NP; ++s_) q[s_] = wq[(size_t)(g * NP + s_) * 64];
             };
             if (first) {
                 load_b(wf, 0, bw[0][0]);
@@ -204,6 +243,7 @@ __device__ __forceinline__ void gemm_ws_body(const GroupArgs ga) {
                 load_b(wq, g0 + 1, bw[par ^ 1][1]);
                 load_g(Ap, 0, 1, fb);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (F16) rescale(rb);
                 mfma12(fa, bw[par][0], acc[0], acc[1]);
                 load_g(Ap, 1, 0, fa);
                 __builtin_amdgcn_sched_barrier(0);
@@ -230,7 +270,9 @@ __device__ __forceinline__ void gemm_ws_body(const GroupArgs ga) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    Cst[row * WS_CP + wave * 32 + (lane & 31)] = acc[i][r];
+                    float v = acc[i][r];
+                    if constexpr (F16) v *= ldexpf(1.0f, (int)(signed char)(e_acc >> (8 * (r >> 2))) + ewt);
+                    Cst[row * WS_CP + wave * 32 + (lane & 31)] = v;
                 }
             __syncthreads();                                       // E: the tile is staged
             GN_WTR(2);
@@ -281,7 +323,39 @@ __device__ __forceinline__ void gemm_ws_body(const GroupArgs ga) {
         for (int i = 0; i < 4; ++i) q[i] = ld4(Ab + f_off[i]);
     };
     int pb = 2;                                                    // LDS buffer the next staged slab goes to (global slab count mod 3)
+    int e_run = -120;                                              // F16: running exponent of this wave's rows in the tile being staged
     auto stashA = [&](int buf, const float4 (&q)[4]) {
+        if constexpr (F16) {
+            _Float16* d0 = reinterpret_cast<_Float16*>(Abuf) + buf * WS_STAGE + sr * SPLIT_PB + 4 * c4;
+            float m = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(q[i].x), fabsf(q[i].y)), fmaxf(fabsf(q[i].z), fabsf(q[i].w))));
+            int need = (int)((wave_umax_sgpr(__float_as_uint(m)) >> 23) & 0xffu) - 126 - 15;
+            if (__builtin_expect(need > 112, 0)) {                 // an Inf in the block: scale by its finite values
+                asm volatile("" ::: "memory");
+                float mf = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float c[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) mf = fmaxf(mf, fabsf(c[t]) <= 3.0e38f ? fabsf(c[t]) : 0.f);
+                }
+                need = (int)((wave_umax_sgpr(__float_as_uint(mf)) >> 23) & 0xffu) - 126 - 15;
+            }
+            need = need < -120 ? -120 : need;
+            e_run = need > e_run ? need : e_run;
+            const float scale = __uint_as_float((unsigned)(127 - e_run) << 23);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f16x4 h, l;
+                split4_f16(q[i], scale, h, l);
+                _Float16* d = d0 + 32 * i * SPLIT_PB;
+                *reinterpret_cast<f16x4*>(d) = h;
+                *reinterpret_cast<f16x4*>(d + WS_APL) = l;
+            }
+            if ((ptid & 63) == 0) exps[buf * 4 + (ptid >> 6)] = (signed char)e_run;
+        } else {
         __bf16* d0 = Abuf + buf * WS_STAGE + sr * SPLIT_PB + 4 * c4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -291,6 +365,7 @@ __device__ __forceinline__ void gemm_ws_body(const GroupArgs ga) {
             *reinterpret_cast<bf16x4*>(d) = h;
             *reinterpret_cast<bf16x4*>(d + WS_APL) = m;
             *reinterpret_cast<bf16x4*>(d + 2 * WS_APL) = l;
+        }
         }
     };
 
@@ -358,6 +433,7 @@ __device__ __forceinline__ void gemm_ws_body(const GroupArgs ga) {
         constexpr int set = decltype(SET)::value, dk = decltype(DK)::value;
         float4 nr[4], ng[4];
         if constexpr (dk == 2) drain_load(kt + 1 < 4 ? kt + 1 : 3, nr, ng);
+        if constexpr (F16) { if (kt + 2 == nk) e_run = -120; }     // the slab staged now is slab 0 of the NEXT tile
         if (!(GN_WS_ABL & 1)) stashA(pb, qa[set]);                 // slab kt + 2 (of this tile, or slab 0 / 1 of the next)
         pb = pb == WS_NBUF - 1 ? 0 : pb + 1;
         const int v = kt + 4;                                      // ... and its register set takes slab kt + 4
@@ -428,7 +504,8 @@ __device__ __forceinline__ void gemm_ws_body(const GroupArgs ga) {
     }
 }
 
-__global__ __launch_bounds__(512) void gemm_bf16x3_ws(const GroupArgs ga) { gemm_ws_body(ga); }
+__global__ __launch_bounds__(512) void gemm_bf16x3_ws(const GroupArgs ga) { gemm_ws_body<false>(ga); }
+__global__ __launch_bounds__(512) void gemm_f16x2_ws(const GroupArgs ga) { gemm_ws_body<true>(ga); }
 
 }  // namespace gn
 
@@ -440,10 +517,11 @@ bool gn_gemm_ws_eligible(const gn::GemmArgs* g, int n) {
     return n > 0;
 }
 
-int gn_gemm_ws_launch(const gn::GroupArgs& ga, long tiles, hipStream_t st) {
+int gn_gemm_ws_launch(const gn::GroupArgs& ga, long tiles, hipStream_t st, int mode) {
     long grid = 8L * ((tiles + 7) / 8);
     if (grid > 256) grid = 256;                                    // one 512-thread workgroup per CU
-    hipLaunchKernelGGL(gn::gemm_bf16x3_ws, dim3((unsigned)grid), dim3(512), 0, st, ga);
+    if (mode == 2) hipLaunchKernelGGL(gn::gemm_f16x2_ws, dim3((unsigned)grid), dim3(512), 0, st, ga);
+    else hipLaunchKernelGGL(gn::gemm_bf16x3_ws, dim3((unsigned)grid), dim3(512), 0, st, ga);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }

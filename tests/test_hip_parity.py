@@ -331,13 +331,14 @@ def test_wave_specialised_gemm_opt_in():
     import subprocess
     import sys
     from gotennet_amd import engine
-    if engine.GEMM_MODE != "split":
-        pytest.skip("the wave-specialised kernel exists for the split arithmetic only")
+    if engine.GEMM_MODE == "f32":
+        pytest.skip("the wave-specialised kernel exists for the two split arithmetics only")
+    mode = engine.GEMM_MODE
     code = r"""
 import sys, torch
 sys.path.insert(0, %r)
 from gotennet_amd import engine
-engine.GEMM_MODE = "split"
+engine.GEMM_MODE = %r
 torch.manual_seed(0)
 dev = "cuda"
 r = lambda *s: torch.randn(*s, device=dev)
@@ -355,7 +356,7 @@ engine.gemm_group([dict(A=g, lda=6 * F, W=WeT, C=gout, ldc=F, rows=E, nout=F, K=
                    dict(A=gx, lda=5 * F, W=WsT, C=gnp, ldc=4 * F, rows=N, nout=F, K=5 * F, c_off=2 * F, dgate=pre, g_off=2 * F)])
 torch.cuda.synchronize()
 torch.save([v.cpu() for v in (ep, na, pre, t2, gout, gnp)], sys.argv[1])
-""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), mode)
     import tempfile
     outs = {}
     with tempfile.TemporaryDirectory() as td:
