@@ -267,7 +267,7 @@ def graph_latency(a, rep, head, dev, n_mol=1, iters=200):
 
 #: launches of the GATA message stage (gotennet.py:452-559, 613-640): scores + segment softmax + message + aggregate.
 #: B_msg is the stage's algorithmic traffic, so the stage's launches are timed TOGETHER.
-MSG_STAGE = ("gn_attn_softmax", "gn_message_aggregate", "gn_message_fused")
+MSG_STAGE = ("gn_attn_softmax", "gn_message_aggregate")
 HTR_TAG = "gn_htr_edge"
 
 

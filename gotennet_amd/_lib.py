@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GN_LIB_PATH") or os.path.join(_PKG, "libgotennet_hip.so")
 
 GN_ERR_BAD_ARG = 10001
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 
@@ -44,7 +44,6 @@ SIGNATURES = {
     "gn_gemm": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "gn_attn_softmax": [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P],
     "gn_message_aggregate": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "gn_message_fused": [_P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gn_htr_edge": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "gn_eqff_context": [_P, _P, _F, _I, _I, _I, _P, _P],
     "gn_eqff_update": [_P, _P, _I, _I, _I, _P, _P, _P],

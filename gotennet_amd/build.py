@@ -46,11 +46,11 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
         # one translation unit per worker: the files are independent and the largest takes about a minute
         with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as pool:
             list(pool.map(one, zip(srcs, objs)))
-        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+        link = [hipcc] + [f for f in FLAGS if f.startswith("--offload-arch")] + ["-shared", "-fPIC"] + objs + ["-o", out]
         if verbose:
             print(" ".join(link), flush=True)
         subprocess.run(link, check=True)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

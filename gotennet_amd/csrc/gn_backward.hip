@@ -162,13 +162,15 @@ struct MsgShape {
 // by-target pass: g_tf, g_cut, g_rl, attention backward (g_a -> g_s), g_ta, g_q
 // (body in a forceinline function with __restrict__ parameters: with the pointers read from the argument struct the
 //  compiler had to assume that the g_eproj stores alias every later load and issued the row loads one at a time)
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
-__device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, const float* __restrict__ x_, const float* __restrict__ v_, const float* __restrict__ eproj_, const float* __restrict__ a_, const float* __restrict__ qk_, const float* __restrict__ X_in_, const float* __restrict__ rl_, const float* __restrict__ cut_, const int* __restrict__ outdeg_, const float* __restrict__ g_h1_, const float* __restrict__ g_X1_, const int* __restrict__ rowptr_, const int* __restrict__ src_, float* __restrict__ g_eproj_, float* __restrict__ g_s_, float* __restrict__ g_nproj_, float* __restrict__ g_rl_, float* __restrict__ g_cut_) {
+// GS_LDS: the head gradients g_a -> g_s of this target stay in LDS between the three phases (deg * H <= GS_CAP floats)
+// and reach the global g_s rows (read by the by-source pass) in ONE coalesced copy; otherwise they go through those rows
+// like in round 2 (three dependent global round trips per workgroup).  Same arithmetic, same order in both forms.
+constexpr int GS_CAP = 2048;
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, bool GS_LDS>
+__device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, float* gsl, float* red, float* hsum, const float* __restrict__ x_, const float* __restrict__ v_, const float* __restrict__ eproj_, const float* __restrict__ a_, const float* __restrict__ qk_, const float* __restrict__ X_in_, const float* __restrict__ rl_, const float* __restrict__ cut_, const int* __restrict__ outdeg_, const float* __restrict__ g_h1_, const float* __restrict__ g_X1_, const int* __restrict__ rowptr_, const int* __restrict__ src_, float* __restrict__ g_eproj_, float* __restrict__ g_s_, float* __restrict__ g_nproj_, float* __restrict__ g_rl_, float* __restrict__ g_cut_) {
     using S = MsgShape<LMAX, SEP_DIR, SEP_TENSOR>;
     constexpr int D = S::D, M = S::M;
     constexpr int KP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));      // D rl sums, padded to a power of two
-    __shared__ __attribute__((aligned(16))) float red[1024];
-    __shared__ float hsum[256 * M];
     const int N = p.N, F = p.F, H = p.H;
     const int i = xcd_item(blockIdx.x, N);
     if (i < 0) return;
@@ -179,6 +181,10 @@ __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, const f
     int hb[M];
 #pragma unroll
     for (int b = 0; b < M; ++b) hb[b] = (b * F + c0) / per_head;
+    auto GS = [&](int e, int h) -> float& {
+        if constexpr (GS_LDS) return gsl[(e - e0) * H + h];
+        else return g_s_[(size_t)e * H + h];
+    };
 
     const float4 gdh = ld4(g_h1_ + (size_t)i * F + c0);
     float4 gdX[D];
@@ -240,7 +246,7 @@ __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, const f
 #pragma unroll
             for (int k = 1; k < M; ++k) hv += hp[k];
             hv = group_sum(hv, rpl);
-            if (part == 0) g_s_[(size_t)e * H + hh] = hv;
+            if (part == 0) GS(e, hh) = hv;
         }
         if (lps >= KP) {                             // D rl sums in one butterfly
             float vals[KP];
@@ -263,12 +269,12 @@ __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, const f
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         for (int h = wave; h < H; h += 4) {
             float dot = 0.f;
-            for (int e = e0 + lane; e < e1; e += 64) dot += a_[(size_t)e * H + h] * g_s_[(size_t)e * H + h];
+            for (int e = e0 + lane; e < e1; e += 64) dot += a_[(size_t)e * H + h] * GS(e, h);
             dot = wave_sum(dot);
             for (int e = e0 + lane; e < e1; e += 64) {
                 const float nrm = outdeg_ ? sqrtf((float)outdeg_[src_[e]]) * p.inv_sqrt_f : p.inv_sqrt_f;
                 const float av = a_[(size_t)e * H + h];
-                g_s_[(size_t)e * H + h] = av * g_s_[(size_t)e * H + h] - (av / nrm) * dot;
+                GS(e, h) = av * GS(e, h) - (av / nrm) * dot;
             }
         }
     }
@@ -277,8 +283,12 @@ __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, const f
     const int hq = c0 / (F / H);
     const float4 qi = ld4(qk_ + (size_t)i * p.ldqk + c0);
     float4 gq = zero4();
+    if constexpr (GS_LDS) {
+        const int n = (e1 - e0) * H;
+        for (int idx = threadIdx.x; idx < n; idx += 256) g_s_[(size_t)e0 * H + idx] = gsl[idx];
+    }
     for (int e = e0 + slot; e < e1; e += ns) {
-        const float gs = g_s_[(size_t)e * H + hq];
+        const float gs = GS(e, hq);
         const float4 kj = ld4(qk_ + (size_t)src_[e] * p.ldqk + F + c0);
         const float4 pta = ld4_nt(eproj_ + (size_t)e * p.lde + c0);
         gq = fma4(gs, kj * act4(pta, GN_ACT_SILU), gq);
@@ -291,7 +301,15 @@ __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, const f
 
 template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_TGT) void msg_bwd_target_kernel(const MsgBwdArgs p) {
-    msg_bwd_target_body<LMAX, SEP_DIR, SEP_TENSOR>(p, p.x, p.v, p.eproj, p.a, p.qk, p.X_in, p.rl, p.cut, p.outdeg, p.g_h1, p.g_X1, p.rowptr, p.src, p.g_eproj, p.g_s, p.g_nproj, p.g_rl, p.g_cut);
+    __shared__ __attribute__((aligned(16))) float red[1024];
+    __shared__ float hsum[256 * MsgShape<LMAX, SEP_DIR, SEP_TENSOR>::M];
+    __shared__ float gsl[GS_CAP];
+    const int i = xcd_item(blockIdx.x, p.N);
+    if (i < 0) return;
+    if ((p.rowptr[i + 1] - p.rowptr[i]) * p.H <= GS_CAP)      // workgroup-uniform, decided once
+        msg_bwd_target_body<LMAX, SEP_DIR, SEP_TENSOR, true>(p, gsl, red, hsum, p.x, p.v, p.eproj, p.a, p.qk, p.X_in, p.rl, p.cut, p.outdeg, p.g_h1, p.g_X1, p.rowptr, p.src, p.g_eproj, p.g_s, p.g_nproj, p.g_rl, p.g_cut);
+    else
+        msg_bwd_target_body<LMAX, SEP_DIR, SEP_TENSOR, false>(p, gsl, red, hsum, p.x, p.v, p.eproj, p.a, p.qk, p.X_in, p.rl, p.cut, p.outdeg, p.g_h1, p.g_X1, p.rowptr, p.src, p.g_eproj, p.g_s, p.g_nproj, p.g_rl, p.g_cut);
 }
 
 // by-source pass: g_x, g_v, g_k, and g_X (tensor-gate path) of the gathered source rows
@@ -465,14 +483,17 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_TGT_G) void msg_bwd_target_gro
 }
 
 // softmax backward over the summed head gradients of all groups, then scores backward (g_ta, g_q)
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const MsgBwdArgs p, const float* __restrict__ ga_parts, int G, size_t gstride) {
-    __shared__ __attribute__((aligned(16))) float red[1024];
-    const int N = p.N, F = p.F, H = p.H;
-    const int i = xcd_item(blockIdx.x, N);
-    if (i < 0) return;
+template <bool GS_LDS>
+__device__ __forceinline__ void attn_bwd_body(const MsgBwdArgs& p, const float* __restrict__ ga_parts, int G, size_t gstride,
+                                              float* red, float* gsl, int i) {
+    const int F = p.F, H = p.H;
     const int lps = F >> 2, ns = 256 / lps;
     const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
     const int e0 = p.rowptr[i], e1 = p.rowptr[i + 1];
+    auto GS = [&](int e, int h) -> float& {
+        if constexpr (GS_LDS) return gsl[(e - e0) * H + h];
+        else return p.g_s[(size_t)e * H + h];
+    };
     {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         for (int h = wave; h < H; h += 4) {
@@ -480,23 +501,27 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const MsgBwdArgs p, const
             for (int e = e0 + lane; e < e1; e += 64) {
                 float ga = 0.f;
                 for (int q = 0; q < G; ++q) ga += ga_parts[q * gstride + (size_t)e * H + h];
-                p.g_s[(size_t)e * H + h] = ga;
+                GS(e, h) = ga;
                 dot += p.a[(size_t)e * H + h] * ga;
             }
             dot = wave_sum(dot);
             for (int e = e0 + lane; e < e1; e += 64) {
                 const float nrm = p.outdeg ? sqrtf((float)p.outdeg[p.src[e]]) * p.inv_sqrt_f : p.inv_sqrt_f;
                 const float av = p.a[(size_t)e * H + h];
-                p.g_s[(size_t)e * H + h] = av * p.g_s[(size_t)e * H + h] - (av / nrm) * dot;
+                GS(e, h) = av * GS(e, h) - (av / nrm) * dot;
             }
         }
     }
     __syncthreads();
+    if constexpr (GS_LDS) {
+        const int n = (e1 - e0) * H;
+        for (int idx = threadIdx.x; idx < n; idx += 256) p.g_s[(size_t)e0 * H + idx] = gsl[idx];
+    }
     const int hq = c0 / (F / H);
     const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
     float4 gq = zero4();
     for (int e = e0 + slot; e < e1; e += ns) {
-        const float gs = p.g_s[(size_t)e * H + hq];
+        const float gs = GS(e, hq);
         const float4 kj = ld4(p.qk + (size_t)p.src[e] * p.ldqk + F + c0);
         const float4 pta = ld4_nt(p.eproj + (size_t)e * p.lde + c0);
         gq = fma4(gs, kj * act4(pta, GN_ACT_SILU), gq);
@@ -505,6 +530,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const MsgBwdArgs p, const
     st4(&red[slot * F + c0], gq);
     __syncthreads();
     if (slot == 0) st4(p.g_nproj + (size_t)i * p.ldn + c0, red4(red, c0, F, ns));
+}
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const MsgBwdArgs p, const float* __restrict__ ga_parts, int G, size_t gstride) {
+    __shared__ __attribute__((aligned(16))) float red[1024];
+    __shared__ float gsl[GS_CAP];
+    const int i = xcd_item(blockIdx.x, p.N);
+    if (i < 0) return;
+    if ((p.rowptr[i + 1] - p.rowptr[i]) * p.H <= GS_CAP) attn_bwd_body<true>(p, ga_parts, G, gstride, red, gsl, i);
+    else attn_bwd_body<false>(p, ga_parts, G, gstride, red, gsl, i);
 }
 
 template <int LMAX, int LLO, int LHI, bool SCALAR>

@@ -14,117 +14,99 @@
 namespace gn {
 
 // ------------------------------------------------------------------ attention weights
-// The two attention phases for ONE target (also used inside the message kernel, gn_message_fused): scores and the
-// normalised weights stay in LDS (`sc`, deg * H floats; the reduction buffer of the message kernel, idle until its epilogue) when the
-// target's degree fits (`in_lds`), else they go through the global a[] rows of this target like the stand-alone
-// kernel.  The normalised weights are ALSO written to a[] (the force backward and the other degree-group launches read
-// them).  All 256 threads of the workgroup must call it.
-__device__ __forceinline__ void attn_phases(const float* __restrict__ q, const float* __restrict__ k, int ldqk,
-                                            const float* __restrict__ ta, int ldt, const int* __restrict__ src,
-                                            const int* __restrict__ outdeg, int i, int e0, int e1, int F, int H,
-                                            float inv_sqrt_f, float* __restrict__ a, float* sc, bool in_lds, int act) {
+// reference gotennet.py:497-511 + PyG softmax.  One workgroup per target.  The raw scores, their exponentials and the
+// normalised weights of a target live in LDS (deg * H floats) and a[] is written ONCE, coalesced, at the end: the
+// round-2 form kept them in the target's global a[] rows, i.e. four dependent global round trips (store scores ->
+// barrier -> load / store exp -> load / store weights) per workgroup of a kernel that moves 55 MB -- 29 us at C2, 1.9 TB/s.
+// Targets whose scores do not fit (deg * H > ATTN_CAP: a 256-neighbour atom at 8 heads still fits) take the global
+// form; the choice is workgroup-uniform and made ONCE (a per-access select cost 31 -> 38 us in round 2), the
+// arithmetic and its order are the same in both, so the two forms agree bit for bit.
+// ASILU: activation fixed to SiLU at compile time (the run-time switch over twelve kinds costs registers and branches).
+constexpr int ATTN_CAP = 2048;
+template <bool IN_LDS, bool ASILU>
+__device__ __forceinline__ void attn_softmax_body(
+    const float* __restrict__ q, const float* __restrict__ k, int ldqk, const float* __restrict__ ta, int ldt,
+    const int* __restrict__ src, const int* __restrict__ outdeg, int i, int e0, int e1, int F, int H, float inv_sqrt_f,
+    float* __restrict__ a, float* sc, int act) {
     const int lps = F >> 2, ns = 256 / lps;
     const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
-    const int lph = lps / H;
+    const int lph = lps / H;                       // lanes per head (power of two, >= 1)
+    auto S = [&](int e, int h) -> float& {          // this target's score of edge e, head h
+        if constexpr (IN_LDS) return sc[(e - e0) * H + h];
+        else return a[(size_t)e * H + h];
+    };
     const float4 qi = ld4(q + (size_t)i * ldqk + c0);
-    for (int e = e0 + slot; e < e1; e += ns) {
-        const float4 kj = ld4(k + (size_t)src[e] * ldqk + c0);
-        float4 te = ld4(ta + (size_t)e * ldt + c0);
-        te = act4(te, act);
-        float p = qi.x * kj.x * te.x;
-        p += qi.y * kj.y * te.y;
-        p += qi.z * kj.z * te.z;
-        p += qi.w * kj.w * te.w;
-        p = group_sum(p, lph);
+    // two edges per trip: both index -> row load chains in flight together (a slot sees ~5 edges of a 20-neighbour atom)
+    for (int e = e0 + slot; e < e1; e += 2 * ns) {
+        const int eb = e + ns < e1 ? e + ns : e;
+        const int ja = src[e], jb = src[eb];
+        const float4 ka = ld4(k + (size_t)ja * ldqk + c0), kb = ld4(k + (size_t)jb * ldqk + c0);
+        const float4 ta_ = act4(ld4_nt(ta + (size_t)e * ldt + c0), act);     // stored pre-activation: t_attn = act(.)
+        const float4 tb_ = act4(ld4_nt(ta + (size_t)eb * ldt + c0), act);
+        float pa = qi.x * ka.x * ta_.x;
+        pa += qi.y * ka.y * ta_.y;
+        pa += qi.z * ka.z * ta_.z;
+        pa += qi.w * ka.w * ta_.w;
+        float pb = qi.x * kb.x * tb_.x;
+        pb += qi.y * kb.y * tb_.y;
+        pb += qi.z * kb.z * tb_.z;
+        pb += qi.w * kb.w * tb_.w;
+        pa = group_sum(pa, lph);
+        pb = group_sum(pb, lph);
         if ((lp & (lph - 1)) == 0) {
-            if (in_lds) sc[(e - e0) * H + lp / lph] = p; else a[(size_t)e * H + lp / lph] = p;
+            S(e, lp / lph) = pa;
+            if (eb != e) S(eb, lp / lph) = pb;
         }
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int h = wave; h < H; h += 4) {
         float mx = -INFINITY;
-        for (int e = e0 + lane; e < e1; e += 64) mx = fmaxf(mx, in_lds ? sc[(e - e0) * H + h] : a[(size_t)e * H + h]);
+        for (int e = e0 + lane; e < e1; e += 64) mx = fmaxf(mx, S(e, h));
         mx = wave_max(mx);
         float sm = 0.f;
         for (int e = e0 + lane; e < e1; e += 64) {
-            const float ex = expf((in_lds ? sc[(e - e0) * H + h] : a[(size_t)e * H + h]) - mx);
-            if (in_lds) sc[(e - e0) * H + h] = ex; else a[(size_t)e * H + h] = ex;
+            const float ex = expf(S(e, h) - mx);
+            S(e, h) = ex;
             sm += ex;
         }
         sm = wave_sum(sm) + 1e-16f;
         for (int e = e0 + lane; e < e1; e += 64) {
             const float nrm = outdeg ? sqrtf((float)outdeg[src[e]]) * inv_sqrt_f : inv_sqrt_f;
-            const float w = (in_lds ? sc[(e - e0) * H + h] : a[(size_t)e * H + h]) / sm * nrm;
-            if (in_lds) sc[(e - e0) * H + h] = w;
-            a[(size_t)e * H + h] = w;
+            S(e, h) = S(e, h) / sm * nrm;
         }
     }
-    __syncthreads();
+    if constexpr (IN_LDS) {
+        __syncthreads();
+        const int n = (e1 - e0) * H;
+        for (int idx = threadIdx.x; idx < n; idx += 256) a[(size_t)e0 * H + idx] = sc[idx];
+    }
 }
 
-// reference gotennet.py:497-511 + PyG softmax, stand-alone launch: a[e,h] holds the raw scores between the two phases
-// (L2-resident: the target's rows were just written by this workgroup).  Keeping them in LDS like the fused form does
-// was measured SLOWER here (37-39 us vs 31 us at C2): the `in_lds` selects sit in every inner loop.
-// ASILU: activation fixed to SiLU at compile time (the run-time switch over twelve kinds costs registers and branches).
 template <bool ASILU>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_ATTN) void attn_softmax_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int ldqk,
     const float* __restrict__ ta, int ldt,
     const int* __restrict__ rowptr, const int* __restrict__ src, const int* __restrict__ outdeg,
     int N, int F, int H, float inv_sqrt_f, float* __restrict__ a, int act_rt) {
+    __shared__ float sc[ATTN_CAP];
     const int act = ASILU ? (int)GN_ACT_SILU : act_rt;
     const int i = xcd_item(blockIdx.x, N);
     if (i < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
-    const int lph = lps / H;                       // lanes per head (power of two, >= 1)
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
-    const float4 qi = ld4(q + (size_t)i * ldqk + c0);
-    for (int e = e0 + slot; e < e1; e += ns) {
-        const float4 kj = ld4(k + (size_t)src[e] * ldqk + c0);
-        const float4 te = act4(ld4(ta + (size_t)e * ldt + c0), act);      // stored pre-activation: t_attn = act(.)
-        float p = qi.x * kj.x * te.x;
-        p += qi.y * kj.y * te.y;
-        p += qi.z * kj.z * te.z;
-        p += qi.w * kj.w * te.w;
-        p = group_sum(p, lph);
-        if ((lp & (lph - 1)) == 0) a[(size_t)e * H + lp / lph] = p;
-    }
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int h = wave; h < H; h += 4) {
-        float mx = -INFINITY;
-        for (int e = e0 + lane; e < e1; e += 64) mx = fmaxf(mx, a[(size_t)e * H + h]);
-        mx = wave_max(mx);
-        float sm = 0.f;
-        for (int e = e0 + lane; e < e1; e += 64) {
-            const float ex = expf(a[(size_t)e * H + h] - mx);
-            a[(size_t)e * H + h] = ex;
-            sm += ex;
-        }
-        sm = wave_sum(sm) + 1e-16f;
-        for (int e = e0 + lane; e < e1; e += 64) {
-            const float nrm = outdeg ? sqrtf((float)outdeg[src[e]]) * inv_sqrt_f : inv_sqrt_f;
-            a[(size_t)e * H + h] = a[(size_t)e * H + h] / sm * nrm;
-        }
-    }
+    if ((e1 - e0) * H <= ATTN_CAP)
+        attn_softmax_body<true, ASILU>(q, k, ldqk, ta, ldt, src, outdeg, i, e0, e1, F, H, inv_sqrt_f, a, sc, act);
+    else
+        attn_softmax_body<false, ASILU>(q, k, ldqk, ta, ldt, src, outdeg, i, e0, e1, F, H, inv_sqrt_f, a, sc, act);
 }
-
-// q / k / t_attn / outdeg of the fused form (null q = the attention weights were computed by an earlier launch)
-struct AttnIn {
-    const float* q; const float* k; int ldqk;
-    const float* ta; const int* outdeg; float inv_sqrt_f;
-    int act;                                        // GN_ACT_*: t_attn = act(W_re t + b)
-};
 
 // ------------------------------------------------------------------ K6 message + aggregate (lmax <= 2: one launch)
 // M F-wide blocks of the value vector: 0 = scalar; direction gate of degree l: block
 // (SEP_DIR ? l : 1); tensor gate: block TB0 + (SEP_TENSOR ? l-1 : 0), TB0 = 1 + (SEP_DIR ? LMAX : 1).
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, bool FUSE>
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
     const float* __restrict__ x, const float* __restrict__ v, int ldxv,
-    const float* __restrict__ tf, int ldt, float* a, const AttnIn at,
+    const float* __restrict__ tf, int ldt, const float* __restrict__ a,
     const float* __restrict__ rl, const float* __restrict__ cut,
     const int* __restrict__ rowptr, const int* __restrict__ src,
     const float* __restrict__ h_in, const float* __restrict__ X_in,
@@ -143,9 +125,6 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
     const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
     const int per_head = (M * F) / H;
-    // FUSE: attention scores + segment softmax of this target first (gotennet.py:497-511); the weights then come from LDS
-    const bool a_lds = FUSE && (e1 - e0) * H <= CH * 1024;
-    if constexpr (FUSE) attn_phases(at.q, at.k, at.ldqk, at.ta, ldt, src, at.outdeg, i, e0, e1, F, H, at.inv_sqrt_f, a, red, a_lds, GN_ACT_SILU);
 
     int hb[M];
 #pragma unroll
@@ -162,7 +141,6 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
         const float* vr = v + (size_t)j * ldxv + c0;
         const float* tr = tf + (size_t)e * ldt + c0;
         const float* ar = a + (size_t)e * H;
-        const float* al = red + (e - e0) * H;      // FUSE: this edge's weights in LDS
         const float* Xj = X_in + (size_t)j * D * F + c0;
         const float* re = rl + (size_t)e * D;
         float4 o[M];
@@ -170,7 +148,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
         for (int b = 0; b < M; ++b) {
             // gotennet.py:516-529: (t_filter * x_j) * cutoff + attn * v_j
             const float4 sp = (ld4_nt(tr + b * F) * ld4(xr + b * F)) * ce;
-            const float ab = (FUSE && a_lds) ? al[hb[b]] : ar[hb[b]];
+            const float ab = ar[hb[b]];
             o[b] = fma4(ab, ld4(vr + b * F), sp);
         }
         acc[0] = acc[0] + o[0];
@@ -188,7 +166,6 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
     }
 
     // fixed-order reduction over slots, CH rows per pass; slot s finishes rows s, s+ns, ...
-    if constexpr (FUSE) __syncthreads();            // `red` held the attention weights until every slot left the edge loop
 #pragma unroll
     for (int base = 0; base < ROWS; base += CH) {
         if (base) __syncthreads();
@@ -217,10 +194,10 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
 // (1 + D) accumulator rows are cut into degree groups {scalar,1,2}, {3}, {4} so that every launch
 // keeps <= 9 float4 accumulators per lane (3+ waves/SIMD instead of 2 at 246 VGPRs).  Gates are
 // per degree, so the groups re-read nothing but the per-edge scalars.
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR, bool FUSE>
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR>
 __device__ __forceinline__ void message_aggregate_group_body(
     const float* __restrict__ x, const float* __restrict__ v, int ldxv,
-    const float* __restrict__ tf, int ldt, float* a, const AttnIn at,
+    const float* __restrict__ tf, int ldt, const float* __restrict__ a,
     const float* __restrict__ rl, const float* __restrict__ cut,
     const int* __restrict__ rowptr, const int* __restrict__ src,
     const float* __restrict__ h_in, const float* __restrict__ X_in,
@@ -241,9 +218,6 @@ __device__ __forceinline__ void message_aggregate_group_body(
     const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
     const int per_head = (M * F) / H;
-    // FUSE (the first degree group): attention weights of this target, kept in LDS and written to a[] for the other groups
-    const bool a_lds = FUSE && (e1 - e0) * H <= CH * 1024;
-    if constexpr (FUSE) attn_phases(at.q, at.k, at.ldqk, at.ta, ldt, src, at.outdeg, i, e0, e1, F, H, at.inv_sqrt_f, a, red, a_lds, GN_ACT_SILU);
 
     int hb[M];                                      // attention head of this lane's channels in block b
 #pragma unroll
@@ -260,13 +234,12 @@ __device__ __forceinline__ void message_aggregate_group_body(
         const float* vr = v + (size_t)j * ldxv + c0;
         const float* tr = tf + (size_t)e * ldt + c0;
         const float* ar = a + (size_t)e * H;
-        const float* al = red + (e - e0) * H;      // FUSE: this edge's weights in LDS
         const float* Xj = X_in + (size_t)j * D * F + c0;
         const float* re = rl + (size_t)e * D;
         // gotennet.py:516-529: (t_filter * x_j) * cutoff + attn * v_j, block b of the value vector
         auto gate = [&](int b) {
             const float4 sp = (ld4_nt(tr + b * F) * ld4(xr + b * F)) * ce;
-            const float ab = (FUSE && a_lds) ? al[hb[b]] : ar[hb[b]];
+            const float ab = ar[hb[b]];
             return fma4(ab, ld4(vr + b * F), sp);
         };
         // all gate loads first (independent, issued back to back), then the X_j rows
@@ -291,7 +264,6 @@ __device__ __forceinline__ void message_aggregate_group_body(
     }
 
     // fixed-order reduction over slots, CH rows per pass; slot s finishes rows s, s+ns, ...
-    if constexpr (FUSE) __syncthreads();            // `red` held the attention weights until every slot left the edge loop
 #pragma unroll
     for (int base = 0; base < ROWS; base += CH) {
         if (base) __syncthreads();
@@ -313,19 +285,19 @@ __device__ __forceinline__ void message_aggregate_group_body(
 }
 
 #define GN_MSG_GROUP_ARGS                                                                                   \
-    const float *__restrict__ x, const float *__restrict__ v, int ldxv, const float *__restrict__ tf, int ldt, float *a, \
-        const AttnIn at, const float *__restrict__ rl, const float *__restrict__ cut, const int *__restrict__ rowptr,    \
+    const float *__restrict__ x, const float *__restrict__ v, int ldxv, const float *__restrict__ tf, int ldt,            \
+        const float *__restrict__ a, const float *__restrict__ rl, const float *__restrict__ cut, const int *__restrict__ rowptr,    \
         const int *__restrict__ src, const float *__restrict__ h_in, const float *__restrict__ X_in,                     \
         float *__restrict__ h_out, float *__restrict__ X_out, int N, int F, int H
-#define GN_MSG_GROUP_PASS x, v, ldxv, tf, ldt, a, at, rl, cut, rowptr, src, h_in, X_in, h_out, X_out, N, F, H
+#define GN_MSG_GROUP_PASS x, v, ldxv, tf, ldt, a, rl, cut, rowptr, src, h_in, X_in, h_out, X_out, N, F, H
 // one degree group per launch; the two-degree group {3,4} (16 accumulator rows) gets its own occupancy target
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR, bool FUSE>
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G) void message_aggregate_group_kernel(GN_MSG_GROUP_ARGS) {
-    message_aggregate_group_body<LMAX, SEP_DIR, SEP_TENSOR, LLO, LHI, SCALAR, FUSE>(GN_MSG_GROUP_PASS);
+    message_aggregate_group_body<LMAX, SEP_DIR, SEP_TENSOR, LLO, LHI, SCALAR>(GN_MSG_GROUP_PASS);
 }
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR, bool FUSE>
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G34) void message_aggregate_group34_kernel(GN_MSG_GROUP_ARGS) {
-    message_aggregate_group_body<LMAX, SEP_DIR, SEP_TENSOR, LLO, LHI, SCALAR, FUSE>(GN_MSG_GROUP_PASS);
+    message_aggregate_group_body<LMAX, SEP_DIR, SEP_TENSOR, LLO, LHI, SCALAR>(GN_MSG_GROUP_PASS);
 }
 
 // ------------------------------------------------------------------ K7 HTR edge weights
@@ -396,53 +368,45 @@ extern "C" int gn_attn_softmax(const float* q, const float* k, int ldqk, const f
     return GN_OK;
 }
 
-#define GN_MSG_ONE(L, SD, ST, LLO, LHI, SC, FU)                                                                 \
-    hipLaunchKernelGGL((gn::message_aggregate_group_kernel<L, SD, ST, LLO, LHI, SC, FU>), dim3(gn::xcd_grid(N)), dim3(256), \
-                       0, (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, at, rl, cut, rowptr, src, h_in, X_in,  \
+#define GN_MSG_ONE(L, SD, ST, LLO, LHI, SC)                                                                     \
+    hipLaunchKernelGGL((gn::message_aggregate_group_kernel<L, SD, ST, LLO, LHI, SC>), dim3(gn::xcd_grid(N)), dim3(256), \
+                       0, (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in,      \
                        h_out, X_out, N, F, H)
-// degree groups per lmax: {scalar,1..min(lmax,2)}, {3}, {4}; the attention phases ride in the first launch
-#define GN_MSG_MONO(L, SD, ST, FU)                                                                          \
-    hipLaunchKernelGGL((gn::message_aggregate_kernel<L, SD, ST, FU>), dim3(gn::xcd_grid(N)), dim3(256), 0,     \
-                       (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, at, rl, cut, rowptr, src, h_in, X_in, \
+// degree groups per lmax: {scalar,1..min(lmax,2)}, {3}, {4} (lmax = 4: {3,4} in one launch, GN_K6_MERGE34)
+#define GN_MSG_MONO(L, SD, ST)                                                                              \
+    hipLaunchKernelGGL((gn::message_aggregate_kernel<L, SD, ST>), dim3(gn::xcd_grid(N)), dim3(256), 0,         \
+                       (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in,     \
                        h_out, X_out, N, F, H)
-#define GN_MSG_LAUNCH_F(L, SD, ST, FU)                                    \
+#define GN_MSG_LAUNCH(L, SD, ST)                                          \
     do {                                                                  \
-        if constexpr (L <= 2) { GN_MSG_MONO(L, SD, ST, FU); }             \
+        if constexpr (L <= 2) { GN_MSG_MONO(L, SD, ST); }                 \
         else {                                                            \
-            GN_MSG_ONE(L, SD, ST, 1, 2, true, FU);                        \
+            GN_MSG_ONE(L, SD, ST, 1, 2, true);                            \
             if constexpr (L >= 4 && GN_K6_MERGE34) {                      \
-                hipLaunchKernelGGL((gn::message_aggregate_group34_kernel<L, SD, ST, 3, 4, false, false>), dim3(gn::xcd_grid(N)), \
-                                   dim3(256), 0, (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, at, rl, cut, rowptr, src, \
+                hipLaunchKernelGGL((gn::message_aggregate_group34_kernel<L, SD, ST, 3, 4, false>), dim3(gn::xcd_grid(N)), \
+                                   dim3(256), 0, (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, \
                                    h_in, X_in, h_out, X_out, N, F, H);    \
             }                                                             \
             else {                                                        \
-                GN_MSG_ONE(L, SD, ST, 3, 3, false, false);                \
-                if constexpr (L >= 4) { GN_MSG_ONE(L, SD, ST, 4, 4, false, false); } \
+                GN_MSG_ONE(L, SD, ST, 3, 3, false);                       \
+                if constexpr (L >= 4) { GN_MSG_ONE(L, SD, ST, 4, 4, false); } \
             }                                                             \
         }                                                                 \
     } while (0)
-#define GN_MSG_LAUNCH(L, SD, ST) \
-    do { if (fuse) GN_MSG_LAUNCH_F(L, SD, ST, true); else GN_MSG_LAUNCH_F(L, SD, ST, false); } while (0)
 
-static int message_launch(const float* x, const float* v, int ldxv, const float* t_filter, int ldt, float* a,
-                          gn::AttnIn at, bool fuse, const float* rl, const float* cut, const int* rowptr, const int* src,
-                          const float* h_in, const float* X_in, float* h_out, float* X_out,
-                          int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream) {
+extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, const float* t_filter, int ldt,
+                                    const float* a, const float* rl, const float* cut,
+                                    const int* rowptr, const int* src,
+                                    const float* h_in, const float* X_in, float* h_out, float* X_out,
+                                    int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream) {
     if (!feature_dim_ok(F) || N < 0 || H <= 0 || lmax < 1 || lmax > 8 || (ldxv & 3) || (ldt & 3) || X_in == X_out)
         return GN_ERR_BAD_ARG;
     const int M = 1 + (sep_dir ? lmax : 1) + (sep_tensor ? lmax : 1);
     if ((M * F) % H || ((M * F) / H) % 4) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
-    const bool highl = gn_use_highl(lmax);
-    if (fuse && (highl || at.act != GN_ACT_SILU)) {    // attention weights first, as a launch of their own
-        const int rc = gn_attn_softmax(at.q, at.k, at.ldqk, at.ta, ldt, rowptr, src, at.outdeg, N, F, H, a, at.act, stream);
-        if (rc != GN_OK) return rc;
-        fuse = false;
-    }
-    if (highl) {                                       // degrees 5..8: one launch per degree (gn_highl.hip)
+    if (gn_use_highl(lmax))                            // degrees 5..8: one launch per degree (gn_highl.hip)
         return gn_highl_message(x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in, h_out, X_out, N, F, H,
                                 lmax, sep_dir, sep_tensor, (hipStream_t)stream);
-    }
     const int key = lmax * 4 + (sep_dir ? 2 : 0) + (sep_tensor ? 1 : 0);
     switch (key) {
         case 4: case 5: case 6: case 7: GN_MSG_LAUNCH(1, false, false); break;   // lmax = 1: flags are no-ops
@@ -461,28 +425,6 @@ static int message_launch(const float* x, const float* v, int ldxv, const float*
     }
     GN_LAUNCH_CHECK();
     return GN_OK;
-}
-
-extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, const float* t_filter, int ldt,
-                                    const float* a, const float* rl, const float* cut,
-                                    const int* rowptr, const int* src,
-                                    const float* h_in, const float* X_in, float* h_out, float* X_out,
-                                    int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream) {
-    return message_launch(x, v, ldxv, t_filter, ldt, const_cast<float*>(a), gn::AttnIn{}, false, rl, cut, rowptr, src,
-                          h_in, X_in, h_out, X_out, N, F, H, lmax, sep_dir, sep_tensor, stream);
-}
-
-extern "C" int gn_message_fused(const float* q, const float* k, int ldqk, const float* eproj, int ldt,
-                                const int* outdeg, const float* x, const float* v, int ldxv, float* a,
-                                const float* rl, const float* cut, const int* rowptr, const int* src,
-                                const float* h_in, const float* X_in, float* h_out, float* X_out,
-                                int N, int F, int H, int lmax, int sep_dir, int sep_tensor, int act, void* stream) {
-    if (!feature_dim_ok(F) || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || (F / 4) / H > 64 || (ldqk & 3) || !a ||
-        act < 0 || act >= GN_ACT_COUNT)
-        return GN_ERR_BAD_ARG;
-    const gn::AttnIn at{q, k, ldqk, eproj, outdeg, (float)(1.0 / sqrt((double)F)), act};
-    return message_launch(x, v, ldxv, eproj + F, ldt, a, at, true, rl, cut, rowptr, src, h_in, X_in, h_out, X_out,
-                          N, F, H, lmax, sep_dir, sep_tensor, stream);
 }
 
 extern "C" int gn_htr_edge(const float* EQ, const float* EK, const float* rl, const int* rowptr, const int* src,

@@ -111,6 +111,6 @@ __device__ __forceinline__ int phys_row(const GemmArgs& p, int r) {
 // split = 2: 2 x fp16-split MFMA with block exponents, W = the planes (+ header) written by gn_split_f16x2
 int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split);
 
-// wave-specialised split kernel (gn_gemm_ws.hip): eligibility of a group and its launch (ga as built by gn_gemm_launch)
-bool gn_gemm_ws_eligible(const gn::GemmArgs* g, int n);
-int gn_gemm_ws_launch(const gn::GroupArgs& ga, long tiles, hipStream_t st, int mode /* 1 bf16x3, 2 fp16x2 */);
+// row-stationary kernel for the K = 256 products in the 2 x fp16 arithmetic (gn_gemm_rs.hip)
+bool gn_gemm_rs_eligible(const gn::GemmArgs* g, int n);
+int gn_gemm_rs_launch(const gn::GemmArgs* g, int n, hipStream_t st, double nt_min_bytes);

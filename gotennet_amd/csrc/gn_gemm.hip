@@ -586,7 +586,7 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 float v = acc[i][j][r];
-                if constexpr (F16) v *= ldexpf(1.0f, (int)(signed char)(e_acc >> (8 * (r >> 2))) + ewt);   // back from the block / weight exponents
+                if constexpr (F16) v = ldexpf(v, (int)(signed char)(e_acc >> (8 * (r >> 2))) + ewt);   // back from the block / weight exponents (only the RESULT may under- / overflow)
                 smem[row * CP + wn * 32 * TN + j * 32 + (lane & 31)] = v;
             }
     __syncthreads();
@@ -774,6 +774,8 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     // outputs of 100 MB and more (the [E, (1+M)F] edge projection) are stored non-temporally: they are consumed by
     // later kernels from HBM anyway and would only evict the node tables (K6 +5 %); GN_GEMM_NT_MB overrides
     static const double nt_min = (getenv("GN_GEMM_NT_MB") ? atof(getenv("GN_GEMM_NT_MB")) : 100.0) * 1048576.0;
+    // K = F = 256 products in the default arithmetic: operand rows stationary in registers (gn_gemm_rs.hip)
+    if (split == 2 && gn_gemm_rs_eligible(g, n)) return gn_gemm_rs_launch(g, n, st, nt_min);
     for (int i = 0; i < gn::GN_MAX_GROUP; ++i) {
         ga.g[i] = g[i < n ? i : n - 1];
         ga.g[i].nt_store = (double)ga.g[i].M * ga.g[i].N * 4.0 >= nt_min;
@@ -790,11 +792,6 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
         ga.spread |= (g[i].K != g[0].K) || ti * 4 < t0 || t0 * 4 < ti;
     }
     if (end == 0) return GN_OK;
-    // GN_GEMM_WS=1 sends the large split-mode products to the wave-specialised kernel (gn_gemm_ws.hip: bit-identical
-    // results; measured on MI355X it ties this kernel -- 262 / 244 us vs 245 / 250 us on the two edge-sized products
-    // of the C2 step -- so the simpler 4-wave kernel stays the default)
-    static const bool ws_on = getenv("GN_GEMM_WS") && atoi(getenv("GN_GEMM_WS")) == 1;
-    if (split && use_big && BMB == 128 && ws_on && gn_gemm_ws_eligible(g, n)) return gn_gemm_ws_launch(ga, end, st, split);
     // persistent launch: at most 2 (big tiles) / 4 (small tiles) workgroups per CU walk the tile list (+2 %)
     long grid = 8L * ((end + 7) / 8);
     const long cap = use_big ? cap_big : 1024;

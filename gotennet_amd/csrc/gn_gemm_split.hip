@@ -48,9 +48,15 @@ __global__ void split_bf16x3_frag_kernel(const float* __restrict__ w, int N, int
 // ---- 2 x fp16 planes with a tensor exponent (MODE 2 of gemm_body) ---------------------------------------------------
 // out = [256-byte header: int exponent ewt, uint amax bits][nt][g][plane 0..1][lane][8 fp16]; planes hold
 // w' = w * 2^-ewt (|w'| < 2^15) as hi = fp16(w'), lo = fp16(w' - hi).  Two launches, no host read-back.
+// (one atomic per wave of 4096 elements, not per 64: a [1536 x 256] weight took 118 us with 6144 contended atomics)
 __global__ void weight_amax_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ hdr) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    float m = idx < n ? fabsf(w[idx]) : 0.f;
+    const long base = (long)blockIdx.x * (blockDim.x * 64) + threadIdx.x;
+    float m = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) {
+        const long idx = base + (long)k * blockDim.x;
+        m = fmaxf(m, idx < n ? fabsf(w[idx]) : 0.f);
+    }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) atomicMax(hdr + 1, __float_as_uint(m));      // |x| as uint: order-preserving, exact
 }
@@ -87,7 +93,7 @@ extern "C" int gn_split_f16x2(const float* w, int N, int K, unsigned short* out,
     const int ks2 = 2 * ((K + gn::BK - 1) / gn::BK);
     const long total = (long)((N + 31) / 32) * ks2 * 512, n = (long)N * K;
     if (hipMemsetAsync(out, 0, 256, st) != hipSuccess) return GN_ERR_BAD_ARG;
-    hipLaunchKernelGGL(gn::weight_amax_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, n,
+    hipLaunchKernelGGL(gn::weight_amax_kernel, dim3((unsigned)((n + 256 * 64 - 1) / (256 * 64))), dim3(256), 0, st, w, n,
                        reinterpret_cast<unsigned*>(out));
     hipLaunchKernelGGL(gn::split_f16x2_frag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, N, K, ks2,
                        total, reinterpret_cast<unsigned*>(out));

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64) void ese_reduce_kernel(
     ms = wave_sum(ms);
     float c[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) c[k] = wave_sum(mp[k]) / ms;
+    for (int k = 0; k < 3; ++k) c[k] = ms > 0.f ? wave_sum(mp[k]) / ms : 0.f;      // (massless molecule: rejected by the host; no 0 / 0 here)
     float s = 0.f;
     for (int n = n0 + lane; n < n1; n += 64) {
         const float dx = pos[(size_t)n * 3] - c[0], dy = pos[(size_t)n * 3 + 1] - c[1], dz = pos[(size_t)n * 3 + 2] - c[2];

@@ -200,13 +200,6 @@ class _act_scope:
         ACT = self.old
 
 
-#: GN_FUSE_ATTENTION=1: attention scores + segment softmax run inside the message kernel (gn_message_fused, one launch,
-#: weights in LDS; bit-identical).  Default off: measured SLOWER on MI355X (C2: 134.7 vs 118.7 us per stage at lmax 2,
-#: 260 vs 239 us at lmax 4, tools/k6_stage_probe.py) -- the message kernel runs at 2 waves/SIMD (184 VGPRs), so the two
-#: softmax phases and their barriers run at a quarter of the stand-alone kernel's occupancy.
-FUSE_ATTENTION = os.environ.get("GN_FUSE_ATTENTION", "0") == "1"
-
-
 def validate_edges(edge_index: torch.Tensor, n_atoms: int) -> int:
     """Bit 0: ``edge_index[1]`` is not non-decreasing (needs a stable sort by target); bit 1: an index is outside
     [0, n_atoms).  One tiny kernel + ONE host read of its flag (a stream synchronisation)."""
@@ -423,6 +416,20 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
     return h, X, tape
 
 
+def gata_input_norms(cfg: Config, lw: LayerWeights, h: torch.Tensor, X: torch.Tensor):
+    """The optional input norms of a GATA layer (gotennet.py:397-398) on their own: -> (h or LN(h), X or TLN(X))."""
+    N, F_ = h.shape[0], cfg.F
+    if cfg.layernorm and N:
+        hn = torch.empty_like(h)
+        call("gn_layernorm", ptr(h), ptr(lw.ln_w), ptr(lw.ln_b), 1e-5, N, F_, ptr(hn), _stream())
+        h = hn
+    if cfg.steerable_norm and N:
+        Xn = torch.empty_like(X)
+        call("gn_tensor_norm", ptr(X), ptr(lw.tln_w), 1e-12, N, F_, cfg.lmax, ptr(Xn), _stream())
+        X = Xn
+    return h, X
+
+
 def _gata_layer_impl(cfg: Config, lw: LayerWeights, g: "Graph", h: torch.Tensor, X: torch.Tensor, t: torch.Tensor):
     """ONE GATA layer (gotennet.py:366-450) on its own, inference only: what ``GATA.forward`` of the mirror module runs
     when a caller composes layers directly.  Same kernels as ``forward`` (which additionally fuses the neighbouring EQFF
@@ -495,11 +502,6 @@ def message_stage(cfg: Config, g: "Graph", nact, xs, vs, eproj, attn, h, X, h2, 
     rest."""
     F_, H, M = cfg.F, cfg.H, cfg.M
     lde = (1 + M) * F_
-    if FUSE_ATTENTION:
-        call("gn_message_fused", ptr(nact), nact.data_ptr() + 4 * F_, 4 * F_, ptr(eproj), lde, ptr(g.outdeg),
-             ptr(xs), ptr(vs), M * F_, ptr(attn), ptr(g.rl), ptr(g.cut), ptr(g.rowptr), ptr(g.src),
-             ptr(h), ptr(X), ptr(h2), ptr(X2), g.N, F_, H, cfg.lmax, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act, _stream())
-        return
     call("gn_attn_softmax", ptr(nact), nact.data_ptr() + 4 * F_, 4 * F_, ptr(eproj), lde,
          ptr(g.rowptr), ptr(g.src), ptr(g.outdeg), g.N, F_, H, ptr(attn), cfg.act, _stream())
     call("gn_message_aggregate", ptr(xs), ptr(vs), M * F_, eproj.data_ptr() + 4 * F_, lde,

@@ -251,8 +251,10 @@ class GATA(_LayerPackCache, nn.Module):
                 n_edges: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
         """Reference GATA.forward (gotennet.py:366-450): ``h`` [N,1,F] (or [N,F]), ``X`` [N,D,F], ``rl_ij`` [E,D],
         ``t_ij`` [E,F] (or [E,1,F]), ``r_ij`` [E] distances (the cosine cutoff is applied inside, as in ``message``).
-        ``n_edges`` is accepted for signature compatibility; with ``scale_edge`` the out-degree of every source is
-        recomputed from ``edge_index`` exactly as GotenNet.forward does (gotennet.py:986-989).  Any edge order."""
+        With ``scale_edge`` the kernels normalise by the out-degree of every edge's source, recomputed from
+        ``edge_index`` exactly as GotenNet.forward does (gotennet.py:986-989); a caller-supplied ``n_edges`` [E] / [E,1]
+        must BE that quantity (checked on the device, ``ValueError`` otherwise: another normalisation has no kernel).
+        Any edge order.  No edges: the (optionally normalised) inputs come back unchanged."""
         _require_cuda(h, "GATA")
         if self.training and self.dropout > 0:
             raise NotImplementedError("attention dropout (training mode) is not on the accelerated path; call .eval()")
@@ -263,6 +265,15 @@ class GATA(_LayerPackCache, nn.Module):
         h2, X2, t2 = f32c(h.reshape(N, -1)), f32c(X), f32c(t_ij.reshape(E, -1))
         rl, r = f32c(rl_ij.reshape(E, -1)), f32c(r_ij.reshape(-1))
         edge_index = edge_index.contiguous()
+        if E == 0:                                   # no messages, no edge update: only the input norms act (gotennet.py:397-398)
+            ho, Xo = engine.gata_input_norms(cfg, lw, h2, X2)
+            return ho.clone().reshape(hs) if ho is h2 else ho.reshape(hs), Xo.clone() if Xo is X2 else Xo, t_ij.clone()
+        if n_edges is not None and self.scale_edge:
+            deg = torch.zeros(N, dtype=torch.float32, device=h.device).index_add_(
+                0, edge_index[0], torch.ones(E, dtype=torch.float32, device=h.device))
+            if not bool(torch.equal(n_edges.reshape(-1).to(torch.float32), deg[edge_index[0]])):
+                raise ValueError("GATA.forward: n_edges differs from the out-degree of each edge's source "
+                                 "(gotennet.py:986-989); the accelerated path implements that normalisation only")
         order = None
         if E:
             bits = engine.validate_edges(edge_index, N)

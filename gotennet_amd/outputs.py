@@ -371,6 +371,13 @@ class ElectronicSpatialExtentV2(Atomwise):
         if not h.is_cuda:
             raise GotenNetHipError("gotennet_amd.outputs.ElectronicSpatialExtentV2 runs on a ROCm device only")
         n_mol = int(batch[-1].item()) + 1 if batch.numel() else 0
+        if z.numel():
+            # the built-in table stops at Kr (the reference reads ase's full table): an element without a mass would
+            # silently shift the mass-weighted centroid (and an all-massless molecule divides 0 by 0)
+            zc = z.long().clamp(0, self.atomic_mass.numel() - 1)
+            if bool(((self.atomic_mass[zc] <= 0) | (z.long() != zc)).any()):
+                raise ValueError("ElectronicSpatialExtentV2: an atomic number has no entry in `atomic_mass` (built-in "
+                                 "table: Z <= 36); pass atomic_mass= or load a reference checkpoint that carries it")
         mp, z32 = molecule_ptr(batch, n_mol), z.to(torch.int32)
         _, x, _ = self.energy_raw(h.detach().contiguous(), z32, mp, n_mol, raw=True)
         y = torch.empty((n_mol, 1), dtype=torch.float32, device=h.device)

@@ -20,8 +20,35 @@ class EnergyForces:
     so the order of the edge list never shows in the result.  Callers that pass radius-graph output
     (``gotennet_amd.graph.distance``: target-major by construction) switch it off and stay sync-free."""
 
-    def __init__(self, representation: GotenNet, head: Atomwise, check_edges: bool = True):
+    def __init__(self, representation: GotenNet, head: Atomwise, check_edges: bool = True, cache_topology: bool = True):
         self.rep, self.head, self.check_edges = representation, head, check_edges
+        #: ``cache_topology``: a repeated call with the SAME ``edge_index`` tensor (same storage, shape and PyTorch
+        #: version counter -- an MD loop or a benchmark on a fixed neighbour list) reuses the CSR / CSC index arrays,
+        #: the validation verdict and the stable-sort permutation of the previous call: no sort / scan / fill launch and
+        #: no host read on such a step, only the geometry kernel runs on the new ``edge_diff`` / ``edge_vec``.  The cache
+        #: holds a reference to the tensor (its memory cannot be recycled under the key); writes that bypass PyTorch's
+        #: version counter (raw pointers, ``.data``) are not seen: pass ``cache_topology=False`` for such callers.
+        self.cache_topology = cache_topology
+        self._topo = None
+
+    def _graph(self, cfg, pw, N, edge_index, edge_diff, edge_vec, need_csc):
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), tuple(edge_index.stride()), N,
+               id(pw), cfg.lmax, cfg.R, cfg.basis, bool(cfg.scale_edge), bool(self.check_edges))
+        hit = self.cache_topology and self._topo is not None and self._topo[0] == key and self._topo[1] is edge_index
+        if hit:
+            _, _, g, order = self._topo
+            if order is not None:
+                edge_diff, edge_vec = edge_diff[order], edge_vec[order]
+            g.set_geometry(edge_diff.contiguous(), edge_vec.contiguous())
+        else:
+            ei, order = edge_index.contiguous(), None
+            if self.check_edges:
+                ei, edge_diff, edge_vec, order = engine.sorted_edges(ei, edge_diff, edge_vec, N)
+            g = engine.Graph(cfg, pw, N, ei, edge_diff.contiguous(), edge_vec.contiguous())
+            self._topo = (key, edge_index, g, order) if self.cache_topology else None
+        if need_csc:
+            g.csc()
+        return g
 
     @torch.no_grad()
     def __call__(self, z: torch.Tensor, edge_index: torch.Tensor, edge_diff: torch.Tensor, edge_vec: torch.Tensor,
@@ -32,11 +59,7 @@ class EnergyForces:
         cfg, pw = rep.config(), rep.packed_weights()
         N = z.shape[0]
         z32 = z.to(torch.int32)
-        edge_index = edge_index.contiguous()
-        if self.check_edges:
-            edge_index, edge_diff, edge_vec, _ = engine.sorted_edges(edge_index, edge_diff, edge_vec, N)
-        edge_diff, edge_vec = edge_diff.contiguous(), edge_vec.contiguous()
-        g = engine.Graph(cfg, pw, N, edge_index, edge_diff, edge_vec)
+        g = self._graph(cfg, pw, N, edge_index, edge_diff, edge_vec, forces)
         h, X, tape = engine.forward(cfg, pw, z32, g, save=forces)
         if mol_ptr is None:
             mol_ptr = molecule_ptr(batch, n_mol)

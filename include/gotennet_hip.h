@@ -37,7 +37,7 @@ extern "C" {
 
 #define GN_OK 0
 #define GN_ERR_BAD_ARG 10001     /* shape/flag combination the kernels do not implement */
-#define GN_ABI_VERSION 5
+#define GN_ABI_VERSION 6
 
 /* `act`: the element-wise activation of the reference's `activation` constructor argument (str2act, layers.py:596-700;
  * shifted_softplus layers.py:40-50).  Wherever an entry point below says SiLU, it means this kind. */
@@ -216,17 +216,6 @@ int gn_message_aggregate(const float* x, const float* v, int ldxv, const float* 
                          const int* rowptr, const int* src,
                          const float* h_in, const float* X_in, float* h_out, float* X_out,
                          int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream);
-
-/* The whole GATA message stage of one layer as ONE launch (lmax <= 2; lmax >= 3: the first of the degree-group
- * launches): gn_attn_softmax's two phases run inside the message kernel's workgroup -- it already owns the target --
- * and the attention weights stay in LDS (gotennet.py:452-559, 497-511, 613-640, 426-427).  `eproj` rows hold
- * [pre-activation W_re t + b (F) | t_filter (M F)] with leading dimension ldt; a [E,H] is still written (the force
- * backward reads it). */
-int gn_message_fused(const float* q, const float* k, int ldqk, const float* eproj, int ldt,
-                     const int* outdeg, const float* x, const float* v, int ldxv, float* a,
-                     const float* rl, const float* cut, const int* rowptr, const int* src,
-                     const float* h_in, const float* X_in, float* h_out, float* X_out,
-                     int N, int F, int H, int lmax, int sep_dir, int sep_tensor, int act, void* stream);
 
 /* ---- K7 HTR edge weights -------------------------------------------------------------- */
 /* w[e,f] = sum_l sum_m P(EQ[i])_m * P(EK[j])_m with P(a) = a - (a . rl_l) rl_l per degree block

@@ -281,95 +281,6 @@ def test_softmax_high_degree():
     assert rel_err(X.cpu(), X_ref) < TOL
 
 
-@pytest.mark.parametrize("name", ["l2_sep_f32", "l3_sep_scale_f32", "l4_sep_f32", "l1_nosep_scale_f32"])
-def test_fused_attention_launch_is_bit_identical(name):
-    """gn_message_fused (opt-in: scores + segment softmax inside the message kernel, weights in LDS) against the
-    default two-launch form: same arithmetic in the same order -> bit-identical (h, X) and golden parity."""
-    from gotennet_amd import engine
-    cfg, sd, _, t = load_case(name)
-    net = _net_from_case(cfg, sd)
-    args = (t["z"].cuda(), t["edge_index"].cuda(), t["edge_diff"].cuda(), t["edge_vec"].cuda())
-    h0, X0 = net(*args)
-    engine.FUSE_ATTENTION = True
-    try:
-        h1, X1 = net(*args)
-    finally:
-        engine.FUSE_ATTENTION = False
-    assert torch.equal(h0, h1) and torch.equal(X0, X1)
-    assert rel_err(h1.cpu(), t["h"]) < TOL and rel_err(X1.cpu(), t["X"]) < TOL
-
-
-def test_fused_attention_high_degree_spills_to_global():
-    """A 600-edge target at lmax = 1: deg * H exceeds the LDS reduction buffer, the weights go through global memory."""
-    import gotennet_amd
-    from gotennet_amd import engine
-    torch.manual_seed(5)
-    net = gotennet_amd.GotenNet(n_atom_basis=64, n_interactions=2, n_rbf=16, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
-                                num_heads=8, scale_edge=True, lmax=1).cuda().eval()
-    n = 600
-    g = torch.Generator().manual_seed(2)
-    pos = torch.rand((n, 3), generator=g) * 2.5
-    z = torch.randint(1, 9, (n,), generator=g)
-    src = torch.cat([torch.arange(0, n), torch.arange(1, n)])
-    dst = torch.cat([torch.zeros(n, dtype=torch.long), torch.arange(1, n)])
-    vec = pos[src] - pos[dst]
-    w = torch.where(src != dst, vec.norm(dim=1), torch.zeros(src.numel()))
-    args = (z.cuda(), torch.stack([src, dst]).cuda(), w.cuda(), vec.cuda())
-    h0, X0 = net(*args)
-    engine.FUSE_ATTENTION = True
-    try:
-        h1, X1 = net(*args)
-    finally:
-        engine.FUSE_ATTENTION = False
-    assert torch.equal(h0, h1) and torch.equal(X0, X1)
-
-
-def test_wave_specialised_gemm_opt_in():
-    """GN_GEMM_WS=1 (read once per process by the launcher): the wave-specialised split kernel must reproduce the
-    default kernel bit for bit on the edge-sized products (same term order), with riders and every epilogue kind."""
-    import os
-    import subprocess
-    import sys
-    from gotennet_amd import engine
-    if engine.GEMM_MODE == "f32":
-        pytest.skip("the wave-specialised kernel exists for the two split arithmetics only")
-    mode = engine.GEMM_MODE
-    code = r"""
-import sys, torch
-sys.path.insert(0, %r)
-from gotennet_amd import engine
-engine.GEMM_MODE = %r
-torch.manual_seed(0)
-dev = "cuda"
-r = lambda *s: torch.randn(*s, device=dev)
-E, N, F = 5000, 300, 256
-t, h, w = r(E, F), r(N, F), r(E, F)
-We, be, Wn, bn, Wt, bt = r(6 * F, F) / 16, r(6 * F), r(4 * F, F) / 16, r(4 * F), r(F, F) / 16, r(F)
-ep, na, pre, t2 = (torch.empty(E, 6 * F, device=dev), torch.empty(N, 4 * F, device=dev), torch.empty(N, 4 * F, device=dev),
-                   torch.empty(E, F, device=dev))
-engine.gemm_group([dict(A=t, lda=F, W=We, bias=be, C=ep, ldc=6 * F, rows=E, nout=6 * F, K=F),
-                   dict(A=h, lda=F, W=Wn, bias=bn, C=na, ldc=4 * F, rows=N, nout=4 * F, K=F, act=(2 * F, 4 * F), pre_out=pre)])
-engine.gemm_group([dict(A=t, lda=F, W=Wt, bias=bt, C=t2, ldc=F, rows=E, nout=F, K=F, act=(0, F), res=t, gate=w)])
-g, WeT, gin, gout = r(E, 6 * F), r(F, 6 * F) / 40, r(E, F), torch.empty(E, F, device=dev)
-gx, WsT, gnp = r(N, 5 * F), r(F, 5 * F) / 36, torch.zeros(N, 4 * F, device=dev)
-engine.gemm_group([dict(A=g, lda=6 * F, W=WeT, C=gout, ldc=F, rows=E, nout=F, K=6 * F, res=gin),
-                   dict(A=gx, lda=5 * F, W=WsT, C=gnp, ldc=4 * F, rows=N, nout=F, K=5 * F, c_off=2 * F, dgate=pre, g_off=2 * F)])
-torch.cuda.synchronize()
-torch.save([v.cpu() for v in (ep, na, pre, t2, gout, gnp)], sys.argv[1])
-""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), mode)
-    import tempfile
-    outs = {}
-    with tempfile.TemporaryDirectory() as td:
-        for ws in ("0", "1"):
-            path = os.path.join(td, f"ws{ws}.pt")
-            env = dict(os.environ, GN_GEMM_WS=ws)
-            res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
-            assert res.returncode == 0, res.stderr[-2000:]
-            outs[ws] = torch.load(path)
-    for a, b in zip(outs["0"], outs["1"]):
-        assert torch.equal(a, b)
-
-
 def test_fp16_block_exponent_products_on_hostile_operands():
     """The default projection arithmetic (two fp16 planes, running block exponents) against an fp64 product on operands
     chosen to stress the scaling: magnitudes from 1e-20 to 1e+20, rows eight decades apart inside one 8-row block, a K
