@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--no-lmax4", action="store_true", help="skip the short lmax=4 side measurement")
     ap.add_argument("--no-split", action="store_true", help="skip the short side measurements in the other projection arithmetics")
     ap.add_argument("--no-graph", action="store_true", help="skip the single-molecule hipGraph-replay side measurement")
+    ap.add_argument("--no-forward-only", action="store_true", help="skip the energy-only (no force backward) side measurement")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (path check)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the short C3 / C5 side measurements")
     ap.add_argument("--selftest-dist", action="store_true",
@@ -206,16 +207,23 @@ def worker(a):
         # BASELINE configs[2] and configs[4] on the same model family (single GPU)
         wl["md22_ac_ala3_b64"] = measure(a, "md22_ac_ala3", 64, 2, 10, 2, rank, world, dev, dist)
         wl["md22_nanotube_b8_lmax3"] = measure(a, "md22_nanotube", 8, 3, 10, 2, rank, world, dev, dist)
+    fwd = None
+    if sides and not a.no_forward_only:
+        fwd = forward_only(a, res["rep"], res["head"], dev)
     if sides and not a.no_graph:
         lat = graph_latency(a, res["rep"], res["head"], dev)
     if rank == 0:
         out = res["out"]
         also = out.setdefault("also", {})
         sub = lambda so: {**{k: so[k] for k in ("value", "unit", "ms_per_step", "steps", "roofline",
-                                                 "roofline_gather_scatter", "roofline_htr_edge")},
+                                                 "roofline_gather_scatter", "roofline_htr_edge", "roofline_message_backward")},
                           "config": so["config"]["workload"]}
         if lat is not None:
             also["single_molecule_latency"] = lat
+        if fwd is not None:
+            if not a.no_cpu_baseline:
+                fwd["cpu_baseline"] = cpu_baseline(res["rep"], res["head"], a.workload, a.lmax, forces=False)
+            also["forward_only"] = fwd
         for mode, other in others.items():
             so = other["out"]
             also.setdefault("other_projection_modes", {})[mode] = {
@@ -265,10 +273,49 @@ def graph_latency(a, rep, head, dev, n_mol=1, iters=200):
             "note": "static topology (fixed edge list, new positions every step): the step's launches replayed as one hipGraph"}
 
 
+def forward_only(a, rep, head, dev, steps=20):
+    """The path's own API, forward only: representation forward + Atomwise energy, no force backward
+    (`EnergyForces(..., forces=False)`: ping-pong work buffers, nothing saved).  Same workload and model as the headline."""
+    from gotennet_amd import synthetic
+    from gotennet_amd.graph import distance
+    from gotennet_amd.outputs import molecule_ptr
+    from gotennet_amd.pipeline import EnergyForces
+    B = a.batch
+    pos, batch, z = synthetic.make_batch(a.workload, B, seed=0)
+    pos, batch, z = pos.to(dev), batch.to(dev), z.to(dev)
+    ei, ed, ev = distance(pos, batch, 5.0, 32)
+    mol_ptr = molecule_ptr(batch, B)
+    ef = EnergyForces(rep, head, check_edges=False)
+    for _ in range(3):
+        e, _ = ef(z, ei, ed, ev, batch, B, mol_ptr=mol_ptr, forces=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e, _ = ef(z, ei, ed, ev, batch, B, mol_ptr=mol_ptr, forces=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(e).all()
+    return {"metric": "molecules/sec (energy only: representation forward + Atomwise head, no forces)",
+            "value": round(B * steps / dt, 1), "unit": "molecules/s", "ms_per_step": round(1e3 * dt / steps, 3),
+            "steps": steps, "config": f"{a.workload} batch={B}, same model as the headline line"}
+
+
 #: launches of the GATA message stage (gotennet.py:452-559, 613-640): scores + segment softmax + message + aggregate.
 #: B_msg (SURVEY 8d) is the stage's algorithmic traffic, so the stage's launches are timed TOGETHER.
 MSG_STAGE = ("gn_attn_softmax", "gn_message_aggregate")
 HTR_TAG = "gn_htr_edge"
+MSGB_TAG = "gn_message_backward"
+
+
+def algorithmic_bytes_message_backward(N, E, F, M, D, H):
+    """Compulsory bytes of the message backward of one layer (the largest non-GEMM launch family of the force path):
+    every distinct element read once / written once.  Reads: eproj [E,(1+M)F] (t_attn pre-activation + t_filter),
+    a [E,H], rl [E,D], cut [E], four int32 index arrays, the node tables x, v [N,MF], q | k [N,2F], X_in, g_X1 [N,D,F],
+    g_h1 [N,F].  Writes: g_eproj [E,(1+M)F], g_s [E,H], g_rl [E,D], g_cut [E], g_x, g_v [N,MF], g_q | g_k [N,2F],
+    g_X [N,D,F]."""
+    edge = 4 * E * (2 * (1 + M) * F + 2 * H + 2 * D + 2) + 16 * E
+    node = 4 * N * (2 * M * F + 2 * F + 2 * D * F + F) + 4 * N * (2 * M * F + 2 * F + D * F)
+    return edge + node
 
 
 def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
@@ -333,7 +380,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
     # (the projection launches of a step are bracketed on the LAST timed step only, so that the event records do not
     # perturb `value`; the message-stage and HTR launches are bracketed on every step)
     dom_tags = {t for t in tot if family(t) == dominant}
-    always = stage_tags | {HTR_TAG}
+    always = stage_tags | {HTR_TAG, MSGB_TAG}
     kt = KernelTimer(wanted=set(always) if len(dom_tags) > 8 else dom_tags | always)
     _lib.TIMER = kt
     fence()
@@ -431,6 +478,21 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
                     note="bytes = 4N*2DF (EQ, EK tables) + E(4(F + D) + 16) (w written, rl, 2 x int64 index): the kernel's "
                          "own share of SURVEY 8d B_htr (the t read / t' write of the stage sit in the gated GEMM epilogue)")
 
+    def roof_msg_backward():
+        """gn_message_backward (by-target + by-source passes of one layer, timed together): compulsory bytes / duration."""
+        if MSGB_TAG not in tot:
+            return None
+        us = 1e3 * tot[MSGB_TAG] / cnt[MSGB_TAG]
+        nbytes = algorithmic_bytes_message_backward(N, E, F, M, D, H)
+        ach = nbytes / (us * 1e-6) / 1e9
+        return dict(kernel=MSGB_TAG + " (target + source passes of one layer)", bound="hbm", achieved=round(ach, 1),
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                    traffic=_pmc_traffic(MSGB_TAG, lmax, workload), us_per_launch=round(us, 2),
+                    launches_per_step=cnt[MSGB_TAG] // steps, algorithmic_bytes_per_launch=nbytes,
+                    note="bytes = eproj read ONCE + g_eproj written once + a, rl, cut, g_s, g_rl, g_cut + node tables "
+                         "(x, v, q|k, X_in, g_h1, g_X1 read; g_x, g_v, g_q|g_k, g_X written); the kernels read eproj in "
+                         "both passes, so PMC traffic above this figure is the second read")
+
     def roof_other(name):
         t_ms = sum(tot[t] for t in tot if family(t) == name)
         n = sum(cnt[t] for t in tot if family(t) == name)
@@ -455,7 +517,15 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
             (roof_message() if dominant in MSG_STAGE else roof_other(dominant)),
             "roofline_gather_scatter": roof_message(),
             "roofline_htr_edge": roof_htr(),
+            "roofline_message_backward": roof_msg_backward(),
         }
+        # the stage fractions again INSIDE `roofline` (a consumer that keeps only that object still sees them)
+        out["roofline"]["stages"] = {k: ({kk: out[k][kk] for kk in ("kernel", "bound", "achieved", "peak", "unit", "frac",
+                                                                       "us_per_launch", "algorithmic_bytes_per_launch", "traffic")}
+                                         if out[k] else None)
+                                     for k in ("roofline_gather_scatter", "roofline_htr_edge", "roofline_message_backward")}
+        out["roofline"]["traffic_source"] = ("committed rocprofv3 --pmc passes of this workload (profiles/pmc_traffic.json, "
+                                             "FETCH_SIZE x2 + WRITE_SIZE per the gfx950 note), not re-measured in this run")
     return {"out": out, "rep": rep, "head": head}
 
 
@@ -480,7 +550,7 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(rep, head, workload, lmax, n_mol=8, runs=5):
+def cpu_baseline(rep, head, workload, lmax, n_mol=8, runs=5, forces=True):
     """The CPU oracle (checker) timed on this box's host cores (BASELINE.md section 3 protocol): energy+forces via
     autograd on a bounded sample of the same workload and model, 1 warm-up + median of ``runs`` runs with all host
     cores (capped at 64 threads), plus a single-thread figure on a smaller sample."""
@@ -494,14 +564,22 @@ def cpu_baseline(rep, head, workload, lmax, n_mol=8, runs=5):
     cfg = orc.default_config(n_atom_basis=c.F, n_interactions=c.L, n_rbf=c.R, num_heads=c.H, scale_edge=c.scale_edge,
                              lmax=lmax, sep_dir=c.sep_dir, sep_tensor=c.sep_tensor, cutoff=c.cutoff)
 
+    def run_once(z, pos, batch, nm):
+        if forces:
+            return orc.energy_and_forces(sd, cfg, hsd, z, pos, batch, nm)
+        with torch.no_grad():                                            # energy only: forward + head, no autograd graph
+            ei, w, vec = orc.distance(pos, batch, cfg["cutoff"])
+            h, _ = orc.gotennet_forward(sd, cfg, z, ei, w, vec)
+            return orc.atomwise_energy(hsd, h, batch, nm, z=z)
+
     def timed(nm, nthreads, nruns):
         torch.set_num_threads(nthreads)
         pos, batch, z = synthetic.make_batch(workload, nm, seed=0)
-        orc.energy_and_forces(sd, cfg, hsd, z, pos, batch, nm)           # warm-up
+        run_once(z, pos, batch, nm)                                      # warm-up
         ts = []
         for _ in range(nruns):
             t0 = time.perf_counter()
-            orc.energy_and_forces(sd, cfg, hsd, z, pos.clone(), batch, nm)
+            run_once(z, pos.clone(), batch, nm)
             ts.append(time.perf_counter() - t0)
         ts.sort()
         return ts[len(ts) // 2]
@@ -512,8 +590,9 @@ def cpu_baseline(rep, head, workload, lmax, n_mol=8, runs=5):
             "cpu_model": _cpu_model(), "host_cores": cores, "torch": torch.__version__,
             "single_thread": {"value": round(2 / t_one, 3), "unit": "molecules/s", "cores": 1,
                               "sample": f"2 molecules of {workload}, median of 3 runs after 1 warm-up"},
-            "sample": f"{n_mol} molecules of {workload} (same model: F=256, L=6, lmax={lmax}), energy+forces by torch "
-                      f"autograd on the CPU oracle (oracle/gotennet_oracle.py), median of {runs} runs after 1 warm-up, "
+            "sample": f"{n_mol} molecules of {workload} (same model: F=256, L=6, lmax={lmax}), "
+                      + ("energy+forces by torch autograd" if forces else "energy only (forward + head, no_grad)")
+                      + f" on the CPU oracle (oracle/gotennet_oracle.py), median of {runs} runs after 1 warm-up, "
                       f"{threads} threads"}
 
 

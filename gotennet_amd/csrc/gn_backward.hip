@@ -49,9 +49,11 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT) void htr_bwd_target_kerne
     for (int m = 0; m < D; ++m) { eq[m] = ld4(EQ + ((size_t)i * D + m) * F + c0); acc[m] = zero4(); }
     for (int e = e0 + slot; e < e1; e += ns) {
         const float4 gte = ld4(gtp + (size_t)e * F + c0), pte = ld4(pre_t + (size_t)e * F + c0);
-        const float4 gw = gte * act4(pte, act);
+        float4 a_pt, d_pt;
+        act_pair4(pte, act, a_pt, d_pt);
+        const float4 gw = gte * a_pt;
         // t' = t + SiLU(pre_t) * w:  d/d pre_t, ready for the plain W_t^T product that follows
-        st4(g_pre_t + (size_t)e * F + c0, gte * ld4(w + (size_t)e * F + c0) * dact4(pte, act));
+        st4(g_pre_t + (size_t)e * F + c0, gte * ld4(w + (size_t)e * F + c0) * d_pt);
         const float* kj = EK + (size_t)src[e] * D * F + c0;
         const float* re = rl + (size_t)e * D;
         float part[KP];
@@ -291,8 +293,10 @@ __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, float* 
         const float gs = GS(e, hq);
         const float4 kj = ld4(qk_ + (size_t)src_[e] * p.ldqk + F + c0);
         const float4 pta = ld4_nt(eproj_ + (size_t)e * p.lde + c0);
-        gq = fma4(gs, kj * act4(pta, GN_ACT_SILU), gq);
-        st4_nt(g_eproj_ + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dact4(pta, GN_ACT_SILU));   // d/d(pre-activation of t_attn)
+        float4 a_ta, d_ta;
+        act_pair4(pta, GN_ACT_SILU, a_ta, d_ta);
+        gq = fma4(gs, kj * a_ta, gq);
+        st4_nt(g_eproj_ + (size_t)e * p.lde + c0, ((qi * kj) * gs) * d_ta);   // d/d(pre-activation of t_attn)
     }
     st4(&red[slot * F + c0], gq);
     __syncthreads();
@@ -524,8 +528,10 @@ __device__ __forceinline__ void attn_bwd_body(const MsgBwdArgs& p, const float* 
         const float gs = GS(e, hq);
         const float4 kj = ld4(p.qk + (size_t)p.src[e] * p.ldqk + F + c0);
         const float4 pta = ld4_nt(p.eproj + (size_t)e * p.lde + c0);
-        gq = fma4(gs, kj * act4(pta, GN_ACT_SILU), gq);
-        st4_nt(p.g_eproj + (size_t)e * p.lde + c0, ((qi * kj) * gs) * dact4(pta, GN_ACT_SILU));
+        float4 a_ta, d_ta;
+        act_pair4(pta, GN_ACT_SILU, a_ta, d_ta);
+        gq = fma4(gs, kj * a_ta, gq);
+        st4_nt(p.g_eproj + (size_t)e * p.lde + c0, ((qi * kj) * gs) * d_ta);
     }
     st4(&red[slot * F + c0], gq);
     __syncthreads();
@@ -642,8 +648,10 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT_G) void htr_bwd_target_gro
     for (int m = 0; m < XR; ++m) { eq[m] = ld4(EQ + ((size_t)i * D + M0 + m) * F + c0); acc[m] = zero4(); }
     for (int e = rowptr[i] + slot; e < rowptr[i + 1]; e += ns) {
         const float4 gte = ld4(gtp + (size_t)e * F + c0), pte = ld4(pre_t + (size_t)e * F + c0);
-        const float4 gw = gte * act4(pte, act);
-        if (FIRST) st4(g_pre_t + (size_t)e * F + c0, gte * ld4(w + (size_t)e * F + c0) * dact4(pte, act));
+        float4 a_pt, d_pt;
+        act_pair4(pte, act, a_pt, d_pt);
+        const float4 gw = gte * a_pt;
+        if (FIRST) st4(g_pre_t + (size_t)e * F + c0, gte * ld4(w + (size_t)e * F + c0) * d_pt);
         const float* kj = EK + (size_t)src[e] * D * F + c0;
         const float* re = rl + (size_t)e * D;
         float part[KP];
@@ -1049,8 +1057,8 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
         GN_HTRB(3, 1, 2, true); GN_HTRB(3, 3, 3, false);
     } else {
         GN_HTRB(4, 1, 2, true);
-        if (GN_HTRB_MERGE34_T) { GN_HTRB_T(4, 3, 4, false); } else { GN_HTRB_T(4, 3, 3, false); GN_HTRB_T(4, 4, 4, false); }
-        if (GN_HTRB_MERGE34_S) { GN_HTRB_S(4, 3, 4); } else { GN_HTRB_S(4, 3, 3); GN_HTRB_S(4, 4, 4); }
+        GN_HTRB_T(4, 3, 3, false); GN_HTRB_T(4, 4, 4, false);
+        GN_HTRB_S(4, 3, 3); GN_HTRB_S(4, 4, 4);
     }
     GN_LAUNCH_CHECK();
     return GN_OK;
@@ -1064,7 +1072,6 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
 
 extern "C" int gn_message_backward_groups(int lmax, int sep_dir, int sep_tensor, int act) {
     if (gn_use_highl(lmax) || act != GN_ACT_SILU) return 1;      // degree-sliced kernels (gn_highl.hip): one slice
-    if (lmax == 4 && sep_dir && sep_tensor && GN_MSGB_MERGE34_T) return 2;       // {scalar,1,2}, {3,4}
     return (lmax >= 3 && sep_dir && sep_tensor) ? lmax - 1 : 1;
 }
 
@@ -1101,10 +1108,10 @@ extern "C" int gn_message_backward(
             GN_MSGB_S(3, 1, 2, true); GN_MSGB_S(3, 3, 3, false);
         } else {
             GN_MSGB_T(4, 1, 2, true, 0);
-            if (GN_MSGB_MERGE34_T) { GN_MSGB_T(4, 3, 4, false, 1); } else { GN_MSGB_T(4, 3, 3, false, 1); GN_MSGB_T(4, 4, 4, false, 2); }
-            hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, GN_MSGB_MERGE34_T ? 2 : 3, gs);
+            GN_MSGB_T(4, 3, 3, false, 1); GN_MSGB_T(4, 4, 4, false, 2);
+            hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, 3, gs);
             GN_MSGB_S(4, 1, 2, true);
-            if (GN_MSGB_MERGE34_S) { GN_MSGB_S(4, 3, 4, false); } else { GN_MSGB_S(4, 3, 3, false); GN_MSGB_S(4, 4, 4, false); }
+            GN_MSGB_S(4, 3, 3, false); GN_MSGB_S(4, 4, 4, false);
         }
         GN_LAUNCH_CHECK();
         return GN_OK;

@@ -7,6 +7,7 @@
 // loads, register accumulation, fixed-order LDS reduction across slots (no atomics).
 // Workgroup -> target mapping is XCD-aware (gn::xcd_item) so the source rows of one
 // molecule are re-read through a single XCD's L2.
+#include <cstdlib>
 #include "gn_common.h"
 #include "gn_tune.h"
 #include "gn_highl.h"
@@ -66,14 +67,14 @@ __device__ __forceinline__ void attn_softmax_body(
         mx = wave_max(mx);
         float sm = 0.f;
         for (int e = e0 + lane; e < e1; e += 64) {
-            const float ex = expf(S(e, h) - mx);
+            const float ex = fast_exp(S(e, h) - mx);
             S(e, h) = ex;
             sm += ex;
         }
-        sm = wave_sum(sm) + 1e-16f;
+        const float rsm = __builtin_amdgcn_rcpf(wave_sum(sm) + 1e-16f);
         for (int e = e0 + lane; e < e1; e += 64) {
             const float nrm = outdeg ? sqrtf((float)outdeg[src[e]]) * inv_sqrt_f : inv_sqrt_f;
-            S(e, h) = S(e, h) / sm * nrm;
+            S(e, h) = S(e, h) * rsm * nrm;
         }
     }
     if constexpr (IN_LDS) {
@@ -98,6 +99,93 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_ATTN) void attn_softmax_kernel(
         attn_softmax_body<true, ASILU>(q, k, ldqk, ta, ldt, src, outdeg, i, e0, e1, F, H, inv_sqrt_f, a, sc, act);
     else
         attn_softmax_body<false, ASILU>(q, k, ldqk, ta, ldt, src, outdeg, i, e0, e1, F, H, inv_sqrt_f, a, sc, act);
+}
+
+// ---- one WAVE per target (F <= 256, H | 64): what ships for the default shapes.
+// Round-3 counters on the workgroup-per-target kernel above (C2: 29 us for 55 MB): VALU-bound -- 1080 VALU instructions
+// per wave, four waves per target, 20 % of the wave time issuing, the rest stalled on issue or parked at two barriers and
+// 24 ds_bpermute round trips of the per-head reductions.  Here a target is ONE wave: its edges are walked 64 / (F / 4)
+// at a time with the loads of eight steps in flight, the raw scores go to the wave's LDS strip, and the per-head max /
+// sum run over the strip with (edge, head) = strip index per lane: the head of a lane is lane % H for every pass
+// (H | 64), so the reductions are log2(64 / H) xor-shuffles, there is no barrier anywhere, and a[] is written once,
+// coalesced.  Targets whose scores exceed the strip use their a[] rows as the strip (same code, same order).
+constexpr int ATTN_W_STRIP = 512;                   // floats per wave: 64 incoming edges at 8 heads
+template <bool IN_LDS, bool ASILU>
+__device__ __forceinline__ void attn_softmax_wave_body(
+    const float* __restrict__ q, const float* __restrict__ k, int ldqk, const float* __restrict__ ta, int ldt,
+    const int* __restrict__ src, const int* __restrict__ outdeg, int i, int e0, int e1, int F, int H, float inv_sqrt_f,
+    float* __restrict__ a, float* sc, int act) {
+    const int lane = threadIdx.x & 63;
+    const int lps = F >> 2, ns = 64 / lps;          // lanes per edge, edges per step
+    const int slot = lane / lps, lp = lane % lps, c0 = lp * 4;
+    const int lph = lps / H;                        // lanes per head
+    float* const S = IN_LDS ? sc : a + (size_t)e0 * H;            // strip: S[(e - e0) * H + h]
+    const int n = (e1 - e0) * H;
+    const float4 qi = ld4(q + (size_t)i * ldqk + c0);
+    constexpr int U = 8;                            // steps per trip: U (index -> row) chains and U streamed rows in flight
+    for (int eb = e0; eb < e1; eb += U * ns) {      // (a 20-neighbour target is three trips = three memory round trips)
+        float4 kj[U], te[U];
+        int ee[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = eb + u * ns + slot;
+            ee[u] = e < e1 ? e : e1 - 1;            // clamped: a valid row, its score is not stored
+            kj[u] = ld4(k + (size_t)src[ee[u]] * ldqk + c0);
+            te[u] = ld4_nt(ta + (size_t)ee[u] * ldt + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float4 t4 = act4(te[u], act);     // stored pre-activation: t_attn = act(.)
+            float p = qi.x * kj[u].x * t4.x;
+            p += qi.y * kj[u].y * t4.y;
+            p += qi.z * kj[u].z * t4.z;
+            p += qi.w * kj[u].w * t4.w;
+            p = group_sum(p, lph);
+            if ((lp & (lph - 1)) == 0 && eb + u * ns + slot < e1) S[(ee[u] - e0) * H + lp / lph] = p;
+        }
+    }
+    if constexpr (!IN_LDS) __builtin_amdgcn_s_waitcnt(0);         // the strip is this target's a[] rows: stores done before the loads
+    __builtin_amdgcn_wave_barrier();
+    // per-head max and sum over the strip; lane's head = lane % H in every pass
+    float mx = -INFINITY;
+    for (int idx = lane; idx < n; idx += 64) mx = fmaxf(mx, S[idx]);
+    for (int o = H; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sm = 0.f;
+    for (int idx = lane; idx < n; idx += 64) {
+        const float ex = fast_exp(S[idx] - mx);
+        S[idx] = ex;
+        sm += ex;
+    }
+    for (int o = H; o < 64; o <<= 1) sm += __shfl_xor(sm, o, 64);
+    const float rsm = __builtin_amdgcn_rcpf(sm + 1e-16f);
+    if constexpr (!IN_LDS) __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    for (int idx = lane; idx < n; idx += 64) {
+        const float nrm = outdeg ? sqrtf((float)outdeg[src[e0 + idx / H]]) * inv_sqrt_f : inv_sqrt_f;
+        a[(size_t)e0 * H + idx] = S[idx] * rsm * nrm;
+    }
+}
+
+template <bool ASILU>
+__global__ __launch_bounds__(256) void attn_softmax_wave_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, int ldqk,
+    const float* __restrict__ ta, int ldt,
+    const int* __restrict__ rowptr, const int* __restrict__ src, const int* __restrict__ outdeg,
+    int N, int F, int H, float inv_sqrt_f, float* __restrict__ a, int act_rt) {
+    __shared__ float strips[4 * ATTN_W_STRIP];
+    const int act = ASILU ? (int)GN_ACT_SILU : act_rt;
+    const int grp = xcd_item(blockIdx.x, (N + 3) >> 2);           // four consecutive targets per workgroup, one per wave
+    if (grp < 0) return;
+    const int wave = threadIdx.x >> 6;
+    const int i = 4 * grp + wave;
+    if (i >= N) return;
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    if (e1 == e0) return;
+    float* sc = strips + wave * ATTN_W_STRIP;
+    if ((e1 - e0) * H <= ATTN_W_STRIP)
+        attn_softmax_wave_body<true, ASILU>(q, k, ldqk, ta, ldt, src, outdeg, i, e0, e1, F, H, inv_sqrt_f, a, sc, act);
+    else
+        attn_softmax_wave_body<false, ASILU>(q, k, ldqk, ta, ldt, src, outdeg, i, e0, e1, F, H, inv_sqrt_f, a, sc, act);
 }
 
 // ------------------------------------------------------------------ K6 message + aggregate (lmax <= 2: one launch)
@@ -358,6 +446,20 @@ extern "C" int gn_attn_softmax(const float* q, const float* k, int ldqk, const f
         return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     const float inv_sqrt_f = (float)(1.0 / sqrt((double)F));
+    // one wave per target where a wave covers an edge row and the strip's head-per-lane map holds (GN_ATTN_WAVE=0: the
+    // workgroup-per-target kernel, for an A/B)
+    static const bool wave_off = getenv("GN_ATTN_WAVE") && atoi(getenv("GN_ATTN_WAVE")) == 0;
+    if (!wave_off && F <= 256 && H <= 64) {
+        const dim3 grid(gn::xcd_grid((N + 3) / 4)), block(256);
+        if (act == GN_ACT_SILU)
+            hipLaunchKernelGGL(gn::attn_softmax_wave_kernel<true>, grid, block, 0, (hipStream_t)stream,
+                               q, k, ldqk, t_attn, ldt, rowptr, src, outdeg, N, F, H, inv_sqrt_f, a, act);
+        else
+            hipLaunchKernelGGL(gn::attn_softmax_wave_kernel<false>, grid, block, 0, (hipStream_t)stream,
+                               q, k, ldqk, t_attn, ldt, rowptr, src, outdeg, N, F, H, inv_sqrt_f, a, act);
+        GN_LAUNCH_CHECK();
+        return GN_OK;
+    }
     if (act == GN_ACT_SILU)
         hipLaunchKernelGGL(gn::attn_softmax_kernel<true>, dim3(gn::xcd_grid(N)), dim3(256), 0, (hipStream_t)stream,
                            q, k, ldqk, t_attn, ldt, rowptr, src, outdeg, N, F, H, inv_sqrt_f, a, act);

@@ -19,7 +19,7 @@ struct GemmArgs {
     // K-segmented A operand: columns [s * a_seg, (s+1) * a_seg) of the logical A come from A / A2 / A3 (same lda,
     // same row addressing): sums up to three products that share their output rows.  a_seg = 0: plain A.
     const float* A2; const float* A3; int a_seg;
-    int nt_store;                   // outputs far larger than the L2s are written with non-temporal stores
+    int nt_store;                   // first output column written with non-temporal stores (outputs far larger than the L2s; INT_MAX: none)
     int act_kind;                   // GN_ACT_*: the activation of the epilogue columns, of gate_mode 1 and of the prologues
 };
 
@@ -110,7 +110,3 @@ __device__ __forceinline__ int phys_row(const GemmArgs& p, int r) {
 // split = 1: 3 x bf16-split MFMA, W = the fragment-major bf16 planes written by gn_split_bf16x3;
 // split = 2: 2 x fp16-split MFMA with block exponents, W = the planes (+ header) written by gn_split_f16x2
 int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split);
-
-// row-stationary kernel for the K = 256 products in the 2 x fp16 arithmetic (gn_gemm_rs.hip)
-bool gn_gemm_rs_eligible(const gn::GemmArgs* g, int n);
-int gn_gemm_rs_launch(const gn::GemmArgs* g, int n, hipStream_t st, double nt_min_bytes);

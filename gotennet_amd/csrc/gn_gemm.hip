@@ -639,7 +639,7 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
 #if GN_SPLIT_NOSTORE
                     if (v.x == 123456.f) st4(p.C + off, v);
 #else
-                    if (p.nt_store) st4_nt(p.C + off, v); else st4(p.C + off, v);
+                    if (gn >= p.nt_store) st4_nt(p.C + off, v); else st4(p.C + off, v);
 #endif
                 }
             }
@@ -774,11 +774,14 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     // outputs of 100 MB and more (the [E, (1+M)F] edge projection) are stored non-temporally: they are consumed by
     // later kernels from HBM anyway and would only evict the node tables (K6 +5 %); GN_GEMM_NT_MB overrides
     static const double nt_min = (getenv("GN_GEMM_NT_MB") ? atof(getenv("GN_GEMM_NT_MB")) : 100.0) * 1048576.0;
-    // K = F = 256 products in the default arithmetic: operand rows stationary in registers (gn_gemm_rs.hip)
-    if (split == 2 && gn_gemm_rs_eligible(g, n)) return gn_gemm_rs_launch(g, n, st, nt_min);
     for (int i = 0; i < gn::GN_MAX_GROUP; ++i) {
         ga.g[i] = g[i < n ? i : n - 1];
-        ga.g[i].nt_store = (double)ga.g[i].M * ga.g[i].N * 4.0 >= nt_min;
+        // (nt_store = first column written non-temporally.  The first K columns of a large output stay on the normal
+        //  path: for the edge projection [W_re | W_rs] that is the attention block, which the segment softmax re-reads
+        //  right away -- measured 23.3 -> 20.6 us for it at C2, the message kernel unchanged; GN_GEMM_NT_LO overrides)
+        static const int nt_lo_env = getenv("GN_GEMM_NT_LO") ? atoi(getenv("GN_GEMM_NT_LO")) : -1;
+        const int nt_lo = nt_lo_env >= 0 ? nt_lo_env : ga.g[i].K;
+        ga.g[i].nt_store = (double)ga.g[i].M * ga.g[i].N * 4.0 >= nt_min ? (ga.g[i].N > nt_lo ? nt_lo : 0) : 0x7fffffff;
         if (i < n) end += use_big ? (long)((g[i].M + BMB - 1) / BMB) * ((g[i].N + BNB - 1) / BNB)
                                   : (long)((g[i].M + 63) / 64) * ((g[i].N + 63) / 64);
         ga.tile_end[i] = (int)end;

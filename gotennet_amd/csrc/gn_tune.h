@@ -50,24 +50,13 @@
 #ifndef GN_W_K6_G34
 #define GN_W_K6_G34 2      // ... at 2 waves/SIMD (3: 275.6 us, spills; no hint: 325 us)
 #endif
-// lmax = 4 backward: degrees 3 and 4 of a pass in ONE launch (16 gradient rows) instead of two (0 = two launches).
-// Measured on MI355X (C2, lmax = 4, us per layer; message backward 676-680, HTR backward 381 with all four off):
-// MSGB_T 682 (neutral), MSGB_S 716, HTRB_T 413, HTRB_S 423, all four 724 / 479 -- unlike the forward message kernel
-// (GN_K6_MERGE34: 124 -> 112 us) the backward passes lose more to the 16 extra live rows than they save in re-reads.
-#ifndef GN_MSGB_MERGE34_T
-#define GN_MSGB_MERGE34_T 0
-#endif
-#ifndef GN_MSGB_MERGE34_S
-#define GN_MSGB_MERGE34_S 0
-#endif
-#ifndef GN_HTRB_MERGE34_T
-#define GN_HTRB_MERGE34_T 0
-#endif
-#ifndef GN_HTRB_MERGE34_S
-#define GN_HTRB_MERGE34_S 0
-#endif
+// (lmax = 4 backward: the same {3,4} merge was measured for the four backward passes in round 2 and lost -- message
+// backward 676 -> 682 / 716 us per layer for the target / source pass, HTR backward 381 -> 413 / 423 us: 16 extra live
+// gradient rows cost more than the saved re-reads; the switches are gone, the passes run one degree per launch.)
 #ifndef GN_K6G_CH
-#define GN_K6G_CH 9        // message_aggregate_group_kernel: accumulator rows reduced per LDS pass (4 KiB per row)
+#define GN_K6G_CH 16       // message_aggregate_group_kernel: accumulator rows reduced per LDS pass (4 KiB per row): 16 = the
+                           // {3,4} group in ONE pass (round 3: 204.5 -> 203.0 us per lmax=4 stage; 5: 209.3; the 64 KiB
+                           // cost nothing, the kernel sits at 2 waves/SIMD on registers)
 #endif
 
 #define GN_TUNE_CAT_(a, b) a##b

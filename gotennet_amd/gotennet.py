@@ -262,8 +262,9 @@ class GATA(_LayerPackCache, nn.Module):
         hs, ts = h.shape, t_ij.shape
         N, E = h.shape[0], edge_index.shape[1]
         f32c = lambda t: t.to(torch.float32).contiguous()
-        h2, X2, t2 = f32c(h.reshape(N, -1)), f32c(X), f32c(t_ij.reshape(E, -1))
-        rl, r = f32c(rl_ij.reshape(E, -1)), f32c(r_ij.reshape(-1))
+        F_, D_ = self.n_atom_basis, (self.lmax + 1) ** 2 - 1          # (explicit widths: E may be 0)
+        h2, X2, t2 = f32c(h.reshape(N, F_)), f32c(X), f32c(t_ij.reshape(E, F_))
+        rl, r = f32c(rl_ij.reshape(E, D_)), f32c(r_ij.reshape(-1))
         edge_index = edge_index.contiguous()
         if E == 0:                                   # no messages, no edge update: only the input norms act (gotennet.py:397-398)
             ho, Xo = engine.gata_input_norms(cfg, lw, h2, X2)

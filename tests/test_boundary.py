@@ -406,3 +406,69 @@ def test_qm9_heads_on_the_representation_match_oracle():
         inp.representation, inp.vector_representation = net(inp)
         assert rel_err(dip(inp)["mu"].cpu(), y_mu) < 1e-4
         assert rel_err(ese(inp)["r2"].cpu(), y_r2) < 1e-4
+
+
+@pytest.mark.gpu
+def test_energy_forces_topology_cache():
+    """EnergyForces keeps the CSR / CSC arrays of the last edge list: a second call with the SAME edge_index tensor and
+    new geometry gives exactly what a cache-less instance gives; an in-place edit of the tensor (version counter) or
+    another tensor rebuilds; a shuffled list keeps its sort permutation across the cached call."""
+    from tests.test_hip_forces import _head_from_case
+    from gotennet_amd.pipeline import EnergyForces
+    cfg, sd, head_sd, t = load_case("l2_sep_f32")
+    net, head = _mirror(cfg, sd), _head_from_case(cfg, head_sd)
+    z, batch = t["z"].cuda(), t["batch"].cuda()
+    ei, ed, ev = t["edge_index"].cuda(), t["edge_diff"].cuda(), t["edge_vec"].cuda()
+    cached, plain = EnergyForces(net, head), EnergyForces(net, head, cache_topology=False)
+    e0, f0 = (v.clone() for v in cached(z, ei, ed, ev, batch, cfg["n_mol"]))
+    g_first = cached._topo[2]
+    # new geometry on the same list: scaled vectors (self-loops stay at zero length)
+    ev2, ed2 = ev * 0.97, ed * 0.97
+    e1, f1 = (v.clone() for v in cached(z, ei, ed2, ev2, batch, cfg["n_mol"]))
+    assert cached._topo[2] is g_first                                    # topology reused
+    e1p, f1p = plain(z, ei, ed2, ev2, batch, cfg["n_mol"])
+    assert torch.equal(e1, e1p) and torch.equal(f1, f1p)
+    assert not torch.equal(e1, e0)
+    # forward-only call on the cached topology, then forces again
+    e2, none = cached(z, ei, ed, ev, batch, cfg["n_mol"], forces=False)
+    assert none is None and rel_err(e2.cpu(), e0.cpu()) < 1e-6
+    e3, f3 = cached(z, ei, ed, ev, batch, cfg["n_mol"])
+    assert torch.equal(e3, e0) and torch.equal(f3, f0)
+    # a shuffled list: the cached call re-applies the stored permutation to the new geometry
+    E = ei.shape[1]
+    order = torch.randperm(E, generator=torch.Generator().manual_seed(3)).cuda()
+    eis = ei[:, order].contiguous()
+    e4, f4 = (v.clone() for v in cached(z, eis, ed[order], ev[order], batch, cfg["n_mol"]))
+    g_shuf = cached._topo[2]
+    e5, f5 = cached(z, eis, ed2[order], ev2[order], batch, cfg["n_mol"])
+    assert cached._topo[2] is g_shuf
+    assert rel_err(f4.cpu(), f0.cpu()) < 1e-5 and rel_err(f5.cpu(), f1.cpu()) < 1e-5
+    # an in-place edit of the edge list is seen (version counter): dropping the last edge's twin changes the result
+    eis.add_(0)
+    cached(z, eis, ed[order], ev[order], batch, cfg["n_mol"])
+    assert cached._topo[2] is not g_shuf
+
+
+@pytest.mark.gpu
+def test_gata_module_edge_cases():
+    """GATA.forward: no edges -> the (normalised) inputs come back; an n_edges that is not the out-degree of the
+    sources raises instead of being ignored."""
+    cfg, sd, _, t = load_case("l3_sep_scale_f32")                      # scale_edge=True: n_edges matters
+    net = _mirror(cfg, sd)
+    gata = net.gata_list[0]
+    N, F_ = t["z"].shape[0], cfg["n_atom_basis"]
+    D = (cfg["lmax"] + 1) ** 2 - 1
+    g = torch.Generator().manual_seed(0)
+    h, X = torch.randn(N, 1, F_, generator=g).cuda(), torch.randn(N, D, F_, generator=g).cuda()
+    empty = torch.zeros((2, 0), dtype=torch.long, device="cuda")
+    h1, X1, t1 = gata(empty, h, X, torch.zeros(0, D, device="cuda"), torch.zeros(0, F_, device="cuda"),
+                      torch.zeros(0, device="cuda"))
+    assert torch.equal(h1, h) and torch.equal(X1, X) and t1.shape == (0, F_)
+    ei, ed = t["edge_index"].cuda(), t["edge_diff"].cuda()
+    E = ei.shape[1]
+    from oracle import gotennet_oracle as orc
+    _, _, tr = orc.gotennet_forward(sd, cfg, t["z"], t["edge_index"], t["edge_diff"], t["edge_vec"], return_trace=True)
+    rl, tij = tr["rl"].cuda(), torch.randn(E, F_, generator=g).cuda()
+    if cfg["scale_edge"]:
+        with pytest.raises(ValueError):
+            gata(ei, h, X, rl, tij, ed, torch.full((E, 1), 3.0, device="cuda"))

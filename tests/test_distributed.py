@@ -99,3 +99,34 @@ def test_bench_self_launches_one_rank_per_gpu():
     val = torch.zeros(2 * B, dtype=torch.float64).index_add_(0, batch, z.double() * (pos.double() ** 2).sum(1)).float()
     assert abs(two["energy_checksum"] - float(val.double().sum())) < 1e-3 * abs(float(val.double().sum()))
     assert abs(one["energy_checksum"] - float(val[:B].double().sum())) < 1e-3 * abs(float(val[:B].double().sum()))
+
+
+def test_bench_eight_ranks_as_the_driver_launches_them():
+    """The exact command line of the 8-GPU scaling run -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 --steps K --warmup W` -- with --selftest-dist (gloo, no
+    kernel): eight ranks rendezvous, every rank's shard lands exactly once in the all-reduced vector, ONE JSON line."""
+    import json
+    import subprocess
+    import sys
+    from gotennet_amd import synthetic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    B, world = 2, 8
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+           "--gpus", str(world), "--steps", "2", "--warmup", "1", "--selftest-dist", "--batch", str(B),
+           "--workload", "qm9_small"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_ranks_seen"] == world and d["global_batch"] == world * B and d["energy_vector_len"] == world * B
+    assert d["shards_consistent"] is True
+    pos, batch, z = synthetic.make_batch("qm9_small", world * B, seed=0)
+    val = torch.zeros(world * B, dtype=torch.float64).index_add_(0, batch, z.double() * (pos.double() ** 2).sum(1)).float()
+    assert abs(d["energy_checksum"] - float(val.double().sum())) < 1e-3 * abs(float(val.double().sum()))
+    # and the self-launching form the driver falls back to: `python bench.py --gpus 8`
+    eight = _bench_selftest(world, B)
+    assert eight["n_ranks_seen"] == world and abs(eight["energy_checksum"] - d["energy_checksum"]) < 1e-6 * abs(d["energy_checksum"])

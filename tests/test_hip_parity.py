@@ -337,3 +337,121 @@ def test_fp16_block_exponent_products_on_hostile_operands():
         assert torch.isfinite(out[100]).all()                     # other 8-row blocks are untouched
     finally:
         engine.GEMM_MODE = old
+
+
+def test_fp16_block_exponent_per_row_bound():
+    """The default arithmetic scales the activation rows a WAVE stages by one running exponent: rows 8 q .. 8 q + 7 of
+    every 32-row MFMA tile of the workgroup tile (wave q of four), i.e. 16 rows of a 64-row tile or 32 rows of a 128-row
+    tile share it.  A row far below its group keeps fewer bits OF ITS OWN scale.  The bound, per row (d = log2 of the
+    group's maximum over the row's own maximum): an element keeps 22 significand bits while it sits within 2^18 of the
+    group maximum and loses one bit per binade beyond that (the low fp16 plane bottoms out at 2^-24 of the scaled
+    group; past 2^40 the row is flushed), i.e.
+
+        max_n |C[r, n] - ref[r, n]|  <=  32 * max(2^-23, 2^(d_r - 41)) * max_n |ref[r, n]|
+
+    (32 ~ 2 sqrt(K) for K = 256: the worst-case growth of K element errors in a dot product of random operands).  Checked
+    on rows spread over TEN decades inside their groups, in both tile shapes; rows within 2^18 of their group -- every
+    row of a batch of molecules -- are held to 4e-6 of their own max-norm."""
+    from gotennet_amd import engine
+    if engine.GEMM_MODE != "f16x2":
+        pytest.skip("bound of the fp16 block-exponent arithmetic")
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    K = 256
+    for M, N, BM in ((704, 192, 64), (9728, 1536, 128)):       # 64 x 64 tiles; the 128 x 128 tile (912 >= 900 big tiles)
+        W = rn(N, K) * 0.1
+        dec = torch.randint(-10, 1, (M, 1), device="cuda", generator=g).float()
+        A = rn(M, K) * (10.0 ** dec)
+        C = torch.empty(M, N, device="cuda")
+        engine.gemm_group([dict(A=A, lda=K, W=W, C=C, ldc=N, rows=M, nout=N, K=K)])
+        torch.cuda.synchronize()
+        ref = A.double() @ W.double().t()
+        err = (C.double() - ref).abs().amax(1) / ref.abs().amax(1)
+        row_max = A.abs().amax(1).double()
+        r = torch.arange(M, device="cuda")
+        group = (r // BM) * 4 + (r % 32) // 8                   # (workgroup tile, staging wave)
+        grp_max = torch.zeros(int(group.max()) + 1, dtype=torch.float64, device="cuda").scatter_reduce_(
+            0, group, row_max, "amax", include_self=True)[group]
+        d = torch.log2(grp_max / row_max)
+        bound = 32.0 * torch.maximum(torch.full_like(d, 2.0 ** -23), 2.0 ** (d - 41))
+        assert bool((err <= bound).all()), (float((err / bound).max()), float(d[(err / bound).argmax()]))
+        near = d <= 18
+        assert bool(near.any()) and float(err[near].max()) < 4e-6
+        # the bound is not vacuous: the rows it loosens are the rows that need it
+        assert float(err[d > 28].max()) > float(err[near].max())
+
+
+def test_small_feature_molecule_in_a_normal_batch():
+    """A molecule whose edges all sit just inside the cutoff (cosine cutoff ~1e-4: its messages are four decades below
+    its batch-mates') between two ordinary molecules: its rows share 8-row exponent blocks with theirs at the seams.
+    Per-MOLECULE energy and forces against the fp64 oracle, each within 1e-4 of that molecule's own max-norm."""
+    import gotennet_amd
+    from oracle import gotennet_oracle as orc
+    from gotennet_amd.graph import distance
+    from gotennet_amd.outputs import Atomwise
+    from gotennet_amd.pipeline import EnergyForces
+    torch.manual_seed(7)
+    F, L = 128, 3
+    net = gotennet_amd.GotenNet(n_atom_basis=F, n_interactions=L, n_rbf=32, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
+                                num_heads=8, scale_edge=False, lmax=2, sep_dir=True, sep_tensor=True)
+    head = Atomwise(n_in=F, n_hidden=64, derivative="forces", activation="silu")
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    hsd = {k: v.clone() for k, v in head.state_dict().items()}
+    cfg = orc.default_config(n_atom_basis=F, n_interactions=L, n_rbf=32, num_heads=8, scale_edge=False, lmax=2,
+                             sep_dir=True, sep_tensor=True)
+    g = torch.Generator().manual_seed(1)
+    normal = lambda off: torch.rand((13, 3), generator=g) * 4.0 + off
+    # an equilateral triangle of side 4.97 A: every pair inside the 5 A cutoff by 0.03 A, C(r) = 0.5 (cos(pi r / 5) + 1) ~ 9e-5
+    s = 4.97
+    far = torch.tensor([[0.0, 0.0, 0.0], [s, 0.0, 0.0], [s / 2, s * 3 ** 0.5 / 2, 0.0]]) + 50.0
+    pos = torch.cat([normal(0.0), far, normal(100.0)])
+    batch = torch.tensor([0] * 13 + [1] * 3 + [2] * 13)
+    z = torch.randint(1, 9, (29,), generator=g)
+    e64, f64, _ = orc.energy_and_forces({k: v.double() for k, v in sd.items()}, cfg, {k: v.double() for k, v in hsd.items()},
+                                        z, pos.double(), batch, 3)
+    ei, w, vec = distance(pos.cuda(), batch.cuda(), 5.0, 32)
+    e, f = EnergyForces(net.cuda().eval(), head.cuda().eval())(z.cuda(), ei, w, vec, batch.cuda(), 3)
+    e, f = e.cpu().double(), f.cpu().double()
+    assert float((ei[0] != ei[1]).sum()) > 6                   # the triangle's six directed edges are in the graph
+    for m in range(3):
+        rows = batch == m
+        assert abs(float(e[m] - e64[m])) <= 1e-4 * abs(float(e64[m])), m
+        assert float((f[rows] - f64[rows]).abs().max()) <= 1e-4 * float(f64[rows].abs().max()), m
+    # the triangle's forces really are small next to its neighbours' (the point of the case)
+    assert float(f64[batch == 1].abs().max()) < 1e-2 * float(f64[batch == 0].abs().max())
+
+
+def test_softmax_beyond_the_lds_capacity():
+    """A 300-neighbour target at 8 heads (2400 scores > the 2048 the workgroup keeps in LDS) next to ordinary targets:
+    the forward softmax and the backward's head gradients take their global-memory form for that target and the LDS
+    form for the others; energy and forces against the oracle."""
+    import gotennet_amd
+    from oracle import gotennet_oracle as orc
+    from gotennet_amd.outputs import Atomwise
+    torch.manual_seed(5)
+    F = 64
+    net = gotennet_amd.GotenNet(n_atom_basis=F, n_interactions=2, n_rbf=16, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
+                                num_heads=8, scale_edge=True, lmax=2, sep_dir=True, sep_tensor=True)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    cfg = orc.default_config(n_atom_basis=F, n_interactions=2, n_rbf=16, num_heads=8, scale_edge=True, lmax=2,
+                             sep_dir=True, sep_tensor=True)
+    n = 301
+    g = torch.Generator().manual_seed(2)
+    pos = torch.rand((n, 3), generator=g) * 2.5
+    z = torch.randint(1, 9, (n,), generator=g)
+    src = torch.cat([torch.arange(0, n), torch.arange(1, n)])          # star: everyone -> atom 0, plus self-loops
+    dst = torch.cat([torch.zeros(n, dtype=torch.long), torch.arange(1, n)])
+    ei = torch.stack([src, dst])
+    vec = (pos[src] - pos[dst]).requires_grad_(True)
+    w = torch.where(src != dst, vec.norm(dim=1), torch.zeros(src.numel()))
+    h_ref, X_ref = orc.gotennet_forward(sd, cfg, z, ei, w, vec)
+    loss_ref = (h_ref ** 2).sum() + (X_ref ** 2).sum()
+    (g_ref,) = torch.autograd.grad(loss_ref, vec)
+    net = net.cuda().eval()
+    vec_d = vec.detach().cuda().requires_grad_(True)
+    w_d = torch.where((src != dst).cuda(), vec_d.norm(dim=1), torch.zeros(src.numel(), device="cuda"))
+    h, X = net(z.cuda(), ei.cuda(), w_d, vec_d)
+    assert rel_err(h.detach().cpu(), h_ref.detach()) < TOL and rel_err(X.detach().cpu(), X_ref.detach()) < TOL
+    (g_hip,) = torch.autograd.grad((h ** 2).sum() + (X ** 2).sum(), vec_d)
+    real = src != dst                                  # (a self-loop's vector is pos[i] - pos[i]: its gradient never reaches a position)
+    assert rel_err(g_hip.cpu()[real], g_ref[real]) < TOL
