@@ -426,7 +426,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
                 big = (tag, tot[tag], us, fl / (us * 1e-6) / 1e12)
         ach = flops / (t_ms * 1e-3) / 1e12
         exact = _engine_mode() == "f32"
-        common = dict(traffic=_pmc_traffic("gn_gemm_family_avg", lmax, workload),
+        common = dict(traffic=_pmc_traffic("gn_gemm_family_avg", lmax, workload, B),
                       us_per_launch=round(1e3 * t_ms / n, 2), launches_per_step=n // dom_steps,
                       algorithmic_flops_per_step=flops / dom_steps)
         if exact:
@@ -461,7 +461,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
         nbytes = algorithmic_bytes_message(N, E, F, M, D)
         ach = nbytes / (us * 1e-6) / 1e9
         return dict(kernel="+".join(tags), bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic("message_stage", lmax, workload),
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic("message_stage", lmax, workload, B),
                     us_per_launch=round(us, 2), us_by_kernel={t: round(1e3 * tot[t] / cnt[t], 2) for t in tags},
                     launches_per_step=layers, algorithmic_bytes_per_launch=nbytes)
 
@@ -473,7 +473,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
         nbytes = 4 * N * 2 * D * F + E * (4 * (F + D) + 16)
         ach = nbytes / (us * 1e-6) / 1e9
         return dict(kernel=HTR_TAG, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic(HTR_TAG, lmax, workload), us_per_launch=round(us, 2),
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic(HTR_TAG, lmax, workload, B), us_per_launch=round(us, 2),
                     launches_per_step=cnt[HTR_TAG] // steps, algorithmic_bytes_per_launch=nbytes,
                     note="bytes = 4N*2DF (EQ, EK tables) + E(4(F + D) + 16) (w written, rl, 2 x int64 index): the kernel's "
                          "own share of SURVEY 8d B_htr (the t read / t' write of the stage sit in the gated GEMM epilogue)")
@@ -487,7 +487,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
         ach = nbytes / (us * 1e-6) / 1e9
         return dict(kernel=MSGB_TAG + " (target + source passes of one layer)", bound="hbm", achieved=round(ach, 1),
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                    traffic=_pmc_traffic(MSGB_TAG, lmax, workload), us_per_launch=round(us, 2),
+                    traffic=_pmc_traffic(MSGB_TAG, lmax, workload, B), us_per_launch=round(us, 2),
                     launches_per_step=cnt[MSGB_TAG] // steps, algorithmic_bytes_per_launch=nbytes,
                     note="bytes = eproj read ONCE + g_eproj written once + a, rl, cut, g_s, g_rl, g_cut + node tables "
                          "(x, v, q|k, X_in, g_h1, g_X1 read; g_x, g_v, g_q|g_k, g_X written); the kernels read eproj in "
@@ -529,13 +529,13 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
     return {"out": out, "rep": rep, "head": head}
 
 
-def _pmc_traffic(tag, lmax, workload="rmd17_aspirin"):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), if present."""
-    if workload != "rmd17_aspirin":
-        return None
+def _pmc_traffic(tag, lmax, workload="rmd17_aspirin", batch=128):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), if present for this
+    workload, batch and lmax."""
+    key = f"lmax{lmax}" if (workload == "rmd17_aspirin" and batch == 128) else f"{workload}_b{batch}_lmax{lmax}"
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        return d.get(f"lmax{lmax}", {}).get(tag)
+        return d.get(key, {}).get(tag)
     except Exception:
         return None
 

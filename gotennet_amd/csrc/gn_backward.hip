@@ -74,13 +74,13 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT) void htr_bwd_target_kerne
                 pb = fma4(r[mm], ek[mm], pb);
                 rr = fmaf(r[mm], r[mm], rr);
             }
+            // gw factored out of the per-row terms: u = -c gw pb, v = -c gw pa, s = 2 gw pa pb
             const float c = 2.0f - rr;
-            const float4 papb = pa * pb;
+            const float4 u = gw * pb * (-c), v = gw * pa * (-c), s2 = gw * (pa * pb) * 2.0f;
 #pragma unroll
             for (int mm = 0; mm < 2 * l + 1; ++mm) {
-                acc[m0 + mm] = fma4(gw, ek[mm] + pb * (-c * r[mm]), acc[m0 + mm]);
-                const float4 t4 = gw * ((eq[m0 + mm] * pb + pa * ek[mm]) * (-c) + papb * (2.0f * r[mm]));
-                part[m0 + mm] = hsum4(t4);
+                acc[m0 + mm] = fma4(r[mm], u, fma4(gw, ek[mm], acc[m0 + mm]));
+                part[m0 + mm] = hsum4(fma4(r[mm], s2, fma4(v, ek[mm], u * eq[m0 + mm])));
             }
             m0 += 2 * l + 1;
         }
@@ -136,10 +136,10 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_SRC) void htr_bwd_source_kerne
                 pa = fma4(r[mm], eq[mm], pa);
                 rr = fmaf(r[mm], r[mm], rr);
             }
-            const float c = 2.0f - rr;
+            const float4 v = gw * pa * (rr - 2.0f);
 #pragma unroll
             for (int mm = 0; mm < 2 * l + 1; ++mm)
-                acc[m0 + mm] = fma4(gw, eq[mm] + pa * (-c * r[mm]), acc[m0 + mm]);
+                acc[m0 + mm] = fma4(r[mm], v, fma4(gw, eq[mm], acc[m0 + mm]));
             m0 += 2 * l + 1;
         }
     }
@@ -673,11 +673,11 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT_G) void htr_bwd_target_gro
                 rr = fmaf(r[mm], r[mm], rr);
             }
             const float c = 2.0f - rr;
-            const float4 papb = pa * pb;
+            const float4 u = gw * pb * (-c), v = gw * pa * (-c), s2 = gw * (pa * pb) * 2.0f;
 #pragma unroll
             for (int mm = 0; mm < 2 * l + 1; ++mm) {
-                acc[b0 + mm] = fma4(gw, ek[mm] + pb * (-c * r[mm]), acc[b0 + mm]);
-                part[b0 + mm] = hsum4(gw * ((eq[b0 + mm] * pb + pa * ek[mm]) * (-c) + papb * (2.0f * r[mm])));
+                acc[b0 + mm] = fma4(r[mm], u, fma4(gw, ek[mm], acc[b0 + mm]));
+                part[b0 + mm] = hsum4(fma4(r[mm], s2, fma4(v, ek[mm], u * eq[b0 + mm])));
             }
         }
         if (lps >= KP) {

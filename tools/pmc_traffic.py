@@ -11,7 +11,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def counters(path):
@@ -28,25 +28,42 @@ def pick(tab, *needles):
 
 
 res = {"_comment": __doc__.split("\n\n")[1].replace("\n", " ")}
-for L in (2, 4):
-    f = counters(os.path.join(ROOT, "profiles", f"{R}_pmc_fetch_size_lmax{L}.txt"))
-    w = counters(os.path.join(ROOT, "profiles", f"{R}_pmc_write_size_lmax{L}.txt"))
+
+
+def entry_for(fetch_path, write_path):
+    f, w = counters(fetch_path), counters(write_path)
     byt = lambda k: int((2 * f[k][0] + w[k][0]) * 1024)
     msg = [k for k, _ in pick(f, "message_aggregate")]                     # 1 kernel at lmax 2, the degree groups above
-    soft = pick(f, "attn_softmax_kernel")[0][0]
-    htr = pick(f, "htr_edge_kernel")[0][0]
+    soft = pick(f, "attn_softmax")[0][0]
+    htr = [k for k, _ in pick(f, "htr_edge")]
     gem = [k for k, _ in pick(f, "gn::gemm_") if "split" not in k]           # the projection kernels of the default mode
     n = sum(f[k][1] for k in gem)
+    # message backward of one layer: the target and source passes (all degree groups) + the separate attention
+    # backward of the grouped path; launches per layer from the kernel that runs once per layer
+    mb = [k for k in f if "msg_bwd_" in k or "attn_bwd_kernel" in k]
+    once = [k for k in mb if "attn_bwd_kernel" in k] or [k for k in mb if "msg_bwd_target_kernel" in k]
+    layers = sum(f[k][1] for k in once)
     entry = {
-        "gn_message_aggregate": sum(byt(k) for k in msg),
+        "gn_message_aggregate": int(sum(byt(k) * f[k][1] for k in msg) / max(f[k][1] for k in msg)),
         "gn_attn_softmax": byt(soft),
-        "gn_htr_edge": byt(htr),
+        "gn_htr_edge": int(sum(byt(k) * f[k][1] for k in htr) / max(f[k][1] for k in htr)),
         "gn_gemm_family_avg": int(sum(byt(k) * f[k][1] for k in gem) / n),
+        "gn_message_backward": int(sum(byt(k) * f[k][1] for k in mb) / layers) if layers else None,
         "_detail": {k[:110]: {"FETCH_SIZE_KiB": f[k][0], "WRITE_SIZE_KiB": w[k][0], "launches": f[k][1]}
-                    for k in msg + [soft, htr] + gem},
+                    for k in msg + [soft] + htr + mb + gem},
     }
     entry["message_stage"] = entry["gn_message_aggregate"] + entry["gn_attn_softmax"]
-    res[f"lmax{L}"] = entry
-json.dump(res, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    return entry
+
+
+P = lambda name: os.path.join(ROOT, "profiles", name)
 for L in (2, 4):
-    print(L, {k: v for k, v in res[f"lmax{L}"].items() if k != "_detail"})
+    res[f"lmax{L}"] = entry_for(P(f"{R}_pmc_fetch_size_lmax{L}.txt"), P(f"{R}_pmc_write_size_lmax{L}.txt"))
+for wl in ("md22_ac_ala3_b64_lmax2", "md22_nanotube_b8_lmax3"):             # BASELINE configs[2], configs[4]
+    if os.path.exists(P(f"{R}_pmc_fetch_size_{wl}.txt")):
+        res[wl] = entry_for(P(f"{R}_pmc_fetch_size_{wl}.txt"), P(f"{R}_pmc_write_size_{wl}.txt"))
+res["_round"] = R
+json.dump(res, open(P("pmc_traffic.json"), "w"), indent=1)
+for k, v in res.items():
+    if isinstance(v, dict):
+        print(k, {a: b for a, b in v.items() if a != "_detail"})
