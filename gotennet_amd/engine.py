@@ -103,11 +103,11 @@ def _stream() -> int:
 
 
 #: projection arithmetic (env GN_GEMM_MODE overrides; every GPU parity test runs in all three):
-#:   "f16x2" (default) -- every fp32 operand as two fp16 planes scaled by block exponents (A: per 8 rows x 32 columns,
-#:       running maximum, accumulators rescaled when it grows; W: per tensor), THREE fp16 MFMAs per product, fp32
-#:       accumulate: <= 3e-7 of the output's max-norm vs an fp64 product.  Results depend on how rows fall into 8-row
-#:       blocks at the 1e-7 level (a molecule's energy moves by ~1e-6 relative when its position in the batch changes);
-#:       identical inputs give identical bits.
+#:   "f16x2" (default) -- every fp32 operand as two fp16 planes scaled by block exponents (A: per staging wave and
+#:       32-column K-slab = 16 or 32 neighbouring rows of the workgroup tile, running maximum, accumulators rescaled when
+#:       it grows; W: per tensor), THREE fp16 MFMAs per product, fp32 accumulate: <= 3e-7 of the output's max-norm vs an
+#:       fp64 product.  Results depend on which rows share a group at the 1e-7 level (a molecule's energy moves by ~1e-6
+#:       relative when its position in the batch, or the batch size, changes); identical inputs give identical bits.
 #:   "split" -- three bf16 planes, six bf16 MFMAs per product: same error class, row-wise arithmetic independent of the
 #:       batch layout (bit-exact batch independence), 14 % slower on the C2 step.
 #:   "f32"   -- exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain), 40 % slower.

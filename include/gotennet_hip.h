@@ -181,8 +181,12 @@ int gn_gemm_group_split(const gn_gemm_desc* problems, int n, void* stream);
 /* 2 x fp16 split variant with block exponents: the same contract again, every weight passed as the buffer written
  * ONCE per weight by gn_split_f16x2 (a 256-byte header holding the tensor's binary exponent, then two fp16 planes
  * hi + lo of w * 2^-exponent in the same fragment-major order; gn_split_f16x2_size(N, K) 16-bit elements; the amax is
- * found on the device, no host read-back).  A is scaled per 8-row x 32-column block by the running maximum of the
- * block's binary exponent (exact powers of two, accumulators rescaled when it grows), split into two fp16 planes, and
+ * found on the device, no host read-back).  A is scaled per (staging wave, K-slab of 32 columns) by the running maximum
+ * of that block's binary exponent (exact powers of two, accumulators rescaled when it grows): wave q of four stages rows
+ * 8q..8q+7 of every 32-row MFMA tile of the workgroup tile, so 16 rows (64-row tiles) or 32 rows (128-row tiles) share
+ * an exponent -- results are bit-reproducible but depend at the 1e-7 level on which rows are neighbours (INTEGRATION.md:
+ * batch-position contract; per-row bound: tests/test_hip_parity.py::test_fp16_block_exponent_per_row_bound).  Each scaled
+ * operand is split into two fp16 planes, and
  * the product accumulated in fp32 from THREE plane pairs on v_mfma_f32_32x32x16_f16 -- half the matrix work of the
  * bf16 split; 22 significand bits per operand: <= 2e-7 of the output's max-norm against an fp64 product. */
 long gn_split_f16x2_size(int N, int K);
