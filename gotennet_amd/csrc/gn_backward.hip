@@ -168,7 +168,9 @@ struct MsgShape {
 // and reach the global g_s rows (read by the by-source pass) in ONE coalesced copy; otherwise they go through those rows
 // like in round 2 (three dependent global round trips per workgroup).  Same arithmetic, same order in both forms.
 constexpr int GS_CAP = 2048;
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, bool GS_LDS>
+// FIRST: X_in is identically zero (first interaction): every tensor-gate term vanishes -- those blocks of eproj / x / v
+// are not read, their g_eproj columns not written (the W_e^T product that follows takes the K-prefix).
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, bool GS_LDS, bool FIRST>
 __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, float* gsl, float* red, float* hsum, const float* __restrict__ x_, const float* __restrict__ v_, const float* __restrict__ eproj_, const float* __restrict__ a_, const float* __restrict__ qk_, const float* __restrict__ X_in_, const float* __restrict__ rl_, const float* __restrict__ cut_, const int* __restrict__ outdeg_, const float* __restrict__ g_h1_, const float* __restrict__ g_X1_, const int* __restrict__ rowptr_, const int* __restrict__ src_, float* __restrict__ g_eproj_, float* __restrict__ g_s_, float* __restrict__ g_nproj_, float* __restrict__ g_rl_, float* __restrict__ g_cut_) {
     using S = MsgShape<LMAX, SEP_DIR, SEP_TENSOR>;
     constexpr int D = S::D, M = S::M;
@@ -209,6 +211,7 @@ __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, float* 
         float rlp[D];
 #pragma unroll
         for (int b = 0; b < M; ++b) {
+            if (FIRST && b > 0 && !S::is_dir(b)) { pa_h[b] = 0.f; continue; }
             float4 go;
             if (b == 0) {
                 go = gdh;
@@ -303,7 +306,7 @@ __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, float* 
     if (slot == 0) st4(g_nproj_ + (size_t)i * p.ldn + c0, red4(red, c0, F, ns));
 }
 
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, bool FIRST = false>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_TGT) void msg_bwd_target_kernel(const MsgBwdArgs p) {
     __shared__ __attribute__((aligned(16))) float red[1024];
     __shared__ float hsum[256 * MsgShape<LMAX, SEP_DIR, SEP_TENSOR>::M];
@@ -311,17 +314,19 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_TGT) void msg_bwd_target_kerne
     const int i = xcd_item(blockIdx.x, p.N);
     if (i < 0) return;
     if ((p.rowptr[i + 1] - p.rowptr[i]) * p.H <= GS_CAP)      // workgroup-uniform, decided once
-        msg_bwd_target_body<LMAX, SEP_DIR, SEP_TENSOR, true>(p, gsl, red, hsum, p.x, p.v, p.eproj, p.a, p.qk, p.X_in, p.rl, p.cut, p.outdeg, p.g_h1, p.g_X1, p.rowptr, p.src, p.g_eproj, p.g_s, p.g_nproj, p.g_rl, p.g_cut);
+        msg_bwd_target_body<LMAX, SEP_DIR, SEP_TENSOR, true, FIRST>(p, gsl, red, hsum, p.x, p.v, p.eproj, p.a, p.qk, p.X_in, p.rl, p.cut, p.outdeg, p.g_h1, p.g_X1, p.rowptr, p.src, p.g_eproj, p.g_s, p.g_nproj, p.g_rl, p.g_cut);
     else
-        msg_bwd_target_body<LMAX, SEP_DIR, SEP_TENSOR, false>(p, gsl, red, hsum, p.x, p.v, p.eproj, p.a, p.qk, p.X_in, p.rl, p.cut, p.outdeg, p.g_h1, p.g_X1, p.rowptr, p.src, p.g_eproj, p.g_s, p.g_nproj, p.g_rl, p.g_cut);
+        msg_bwd_target_body<LMAX, SEP_DIR, SEP_TENSOR, false, FIRST>(p, gsl, red, hsum, p.x, p.v, p.eproj, p.a, p.qk, p.X_in, p.rl, p.cut, p.outdeg, p.g_h1, p.g_X1, p.rowptr, p.src, p.g_eproj, p.g_s, p.g_nproj, p.g_rl, p.g_cut);
 }
 
 // by-source pass: g_x, g_v, g_k, and g_X (tensor-gate path) of the gathered source rows
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
+// FIRST (X_in == 0): no g_X rows (nothing consumes the gradient of a constant), tensor-gate blocks of g_x / g_v are zero
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, bool FIRST = false>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kernel(const MsgBwdArgs p) {
     using S = MsgShape<LMAX, SEP_DIR, SEP_TENSOR>;
     constexpr int D = S::D, M = S::M;
-    constexpr int ROWS = 2 * M + D + 1;
+    constexpr int XD = FIRST ? 0 : D;                 // g_X rows carried
+    constexpr int ROWS = 2 * M + XD + 1;
     constexpr int CH = ROWS < 9 ? ROWS : 9;
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
     const int N = p.N, F = p.F, H = p.H;
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kerne
 #pragma unroll
     for (int b = 0; b < M; ++b) hb[b] = (b * F + c0) / per_head;
 
-    // rows: [0,M) g_x, [M,2M) g_v, [2M, 2M+D) g_X, 2M+D g_k
+    // rows: [0,M) g_x, [M,2M) g_v, [2M, 2M+XD) g_X, 2M+XD g_k
     float4 acc[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) acc[r] = zero4();
@@ -356,6 +361,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kerne
         const float* gXi = p.g_X1 + (size_t)i * D * F + c0;
 #pragma unroll
         for (int b = 0; b < M; ++b) {
+            if (FIRST && b > 0 && !S::is_dir(b)) continue;
             const float4 tfb = ld4_nt(tr + b * F);
             const float ab = ar[hb[b]];
             float4 go;
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kerne
                         const float4 gx = ld4(gXi + (size_t)m * F);
                         if (S::is_dir(b)) {
                             go = fma4(re[m], gx, go);
-                        } else {
+                        } else if constexpr (!FIRST) {
                             go = fma4(gx, ld4(Xj + (size_t)m * F), go);
                             acc[2 * M + m] = fma4(gx, ot, acc[2 * M + m]);
                         }
@@ -384,12 +390,12 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kerne
         const float gs = p.g_s[(size_t)e * H + hq];
         const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
         const float4 ta = act4(ld4_nt(p.eproj + (size_t)e * p.lde + c0), GN_ACT_SILU);
-        acc[2 * M + D] = fma4(gs, qi * ta, acc[2 * M + D]);
+        acc[2 * M + XD] = fma4(gs, qi * ta, acc[2 * M + XD]);
     }
     reduce_rows<ROWS>(acc, red, slot, c0, F, ns, [&](int row, float4 s) {
         if (row < M) st4(p.g_x + (size_t)j * p.ldxv + row * F + c0, s);
         else if (row < 2 * M) st4(p.g_v + (size_t)j * p.ldxv + (row - M) * F + c0, s);
-        else if (row < 2 * M + D) {
+        else if (row < 2 * M + XD) {
             const size_t off = ((size_t)j * D + (row - 2 * M)) * F + c0;
             st4(p.g_X_out + off, ld4(p.g_X1 + off) + s);
         } else st4(p.g_nproj + (size_t)j * p.ldn + F + c0, s);
@@ -1064,8 +1070,16 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
     return GN_OK;
 }
 
+// X_in == NULL: the zero-X_in instantiations (compiled for lmax <= 2, where one launch covers all degrees)
 #define GN_MSGB_LAUNCH(L, SD, ST)                                                                        \
     do {                                                                                                  \
+        if constexpr (L <= 2) {                                                                           \
+            if (!X_in) {                                                                                  \
+                hipLaunchKernelGGL((gn::msg_bwd_target_kernel<L, SD, ST, true>), grid, block, 0, st, p);  \
+                hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST, true>), grid, block, 0, st, p);  \
+                break;                                                                                    \
+            }                                                                                             \
+        }                                                                                                 \
         hipLaunchKernelGGL((gn::msg_bwd_target_kernel<L, SD, ST>), grid, block, 0, st, p);                \
         hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST>), grid, block, 0, st, p);                \
     } while (0)
@@ -1086,6 +1100,7 @@ extern "C" int gn_message_backward(
     if (!bwd_dim_ok(F) || N < 0 || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || lmax < 1 || lmax > 8 ||
         (ldxv & 3) || (lde & 3) || (ldqk & 3) || (ldn & 3) || g_X_out == g_X1 || act < 0 || act >= GN_ACT_COUNT)
         return GN_ERR_BAD_ARG;
+    if (!X_in && (lmax > 2 || act != GN_ACT_SILU || gn_use_highl(lmax))) return GN_ERR_BAD_ARG;   // zero-X_in form: one-launch SiLU kernels only
     if (N == 0) return GN_OK;
     gn::MsgBwdArgs p{x, v, ldxv, eproj, lde, a, qk, ldqk, X_in, rl, cut, outdeg, g_h1, g_X1,
                      rowptr, src, dst, colptr, perm, g_eproj, g_s, g_nproj, ldn, g_x, g_v, g_X_out, g_rl, g_cut,

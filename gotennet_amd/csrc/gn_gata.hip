@@ -191,7 +191,10 @@ __global__ __launch_bounds__(256) void attn_softmax_wave_kernel(
 // ------------------------------------------------------------------ K6 message + aggregate (lmax <= 2: one launch)
 // M F-wide blocks of the value vector: 0 = scalar; direction gate of degree l: block
 // (SEP_DIR ? l : 1); tensor gate: block TB0 + (SEP_TENSOR ? l-1 : 0), TB0 = 1 + (SEP_DIR ? LMAX : 1).
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
+// FIRST: X_in is identically zero (the first interaction of GotenNet.forward, gotennet.py:992): the tensor-gate blocks
+// of t_filter / x / v and the X_in rows are not read (0 * gate contributes nothing) and X_out = the aggregated update.
+// Same bits as the general kernel on a zero X_in.
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, bool FIRST = false>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
     const float* __restrict__ x, const float* __restrict__ v, int ldxv,
     const float* __restrict__ tf, int ldt, const float* __restrict__ a,
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
         const float* re = rl + (size_t)e * D;
         float4 o[M];
 #pragma unroll
-        for (int b = 0; b < M; ++b) {
+        for (int b = 0; b < (FIRST ? 1 + ND : M); ++b) {
             // gotennet.py:516-529: (t_filter * x_j) * cutoff + attn * v_j
             const float4 sp = (ld4_nt(tr + b * F) * ld4(xr + b * F)) * ce;
             const float ab = ar[hb[b]];
@@ -244,11 +247,13 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
 #pragma unroll
         for (int l = 1; l <= LMAX; ++l) {
             const float4 od = o[SEP_DIR ? l : 1];
-            const float4 ot = o[1 + ND + (SEP_TENSOR ? l - 1 : 0)];
 #pragma unroll
             for (int mm = 0; mm < 2 * l + 1; ++mm, ++m) {
                 // gotennet.py:538-558: rl * o_d + X_j * o_t
-                acc[1 + m] = acc[1 + m] + fma4(ld4(Xj + (size_t)m * F), ot, od * re[m]);
+                if constexpr (FIRST)
+                    acc[1 + m] = acc[1 + m] + od * re[m];
+                else
+                    acc[1 + m] = acc[1 + m] + fma4(ld4(Xj + (size_t)m * F), o[1 + ND + (SEP_TENSOR ? l - 1 : 0)], od * re[m]);
             }
         }
     }
@@ -268,7 +273,8 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
                 st4(h_out + (size_t)i * F + c0, ld4(h_in + (size_t)i * F + c0) + s);
             } else {
                 const size_t off = ((size_t)i * D + (row - 1)) * F + c0;
-                st4(X_out + off, ld4(X_in + off) + s);
+                if constexpr (FIRST) st4(X_out + off, s);
+                else st4(X_out + off, ld4(X_in + off) + s);
             }
         }
     }
@@ -476,9 +482,14 @@ extern "C" int gn_attn_softmax(const float* q, const float* k, int ldqk, const f
                        h_out, X_out, N, F, H)
 // degree groups per lmax: {scalar,1..min(lmax,2)}, {3}, {4} (lmax = 4: {3,4} in one launch, GN_K6_MERGE34)
 #define GN_MSG_MONO(L, SD, ST)                                                                              \
-    hipLaunchKernelGGL((gn::message_aggregate_kernel<L, SD, ST>), dim3(gn::xcd_grid(N)), dim3(256), 0,         \
-                       (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in,     \
-                       h_out, X_out, N, F, H)
+    if (X_in)                                                                                                   \
+        hipLaunchKernelGGL((gn::message_aggregate_kernel<L, SD, ST, false>), dim3(gn::xcd_grid(N)), dim3(256), 0, \
+                           (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in, \
+                           h_out, X_out, N, F, H);                                                              \
+    else                                                                                                        \
+        hipLaunchKernelGGL((gn::message_aggregate_kernel<L, SD, ST, true>), dim3(gn::xcd_grid(N)), dim3(256), 0,  \
+                           (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in, \
+                           h_out, X_out, N, F, H)
 #define GN_MSG_LAUNCH(L, SD, ST)                                          \
     do {                                                                  \
         if constexpr (L <= 2) { GN_MSG_MONO(L, SD, ST); }                 \
@@ -503,6 +514,7 @@ extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, co
                                     int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream) {
     if (!feature_dim_ok(F) || N < 0 || H <= 0 || lmax < 1 || lmax > 8 || (ldxv & 3) || (ldt & 3) || X_in == X_out)
         return GN_ERR_BAD_ARG;
+    if (!X_in && (lmax > 2 || gn_use_highl(lmax))) return GN_ERR_BAD_ARG;   // the zero-X_in form: one-launch kernels only
     const int M = 1 + (sep_dir ? lmax : 1) + (sep_tensor ? lmax : 1);
     if ((M * F) % H || ((M * F) / H) % 4) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;

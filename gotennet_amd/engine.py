@@ -58,6 +58,29 @@ class PackedWeights:
     T: dict = field(default_factory=dict)
 
 
+#: GN_FORCE_HIGHL=1 (test switch, read once per process like the library does): no zero-X_in kernels on that path
+_FORCE_HIGHL = os.environ.get("GN_FORCE_HIGHL", "")[:1] == "1"
+
+
+#: A/B and test switch: False runs the first interaction through the general kernels on the zero tensor
+ZERO_X_FIRST = os.environ.get("GN_ZERO_X_FIRST", "1") != "0"
+
+
+def zero_X_in(cfg: "Config", li: int) -> bool:
+    """Layer ``li`` of ``forward`` sees the all-zero X that forward itself creates (gotennet.py:992) and the kernels have
+    the zero-X_in form (one-launch SiLU kernels, lmax <= 2): every tensor-gate term of that layer is 0 * gate, so its
+    blocks of the edge projection are neither computed nor read, and nothing consumes the gradient w.r.t. X_in."""
+    return ZERO_X_FIRST and li == 0 and cfg.lmax <= 2 and cfg.act == 0 and not cfg.steerable_norm and not _FORCE_HIGHL
+
+
+def _We_first(cfg: "Config", lw) -> Tuple[torch.Tensor, torch.Tensor, int]:
+    """Rows of [W_re; W_rs] without the tensor-gate blocks (a prefix: attention, scalar, direction gates)."""
+    n0 = (2 + (cfg.lmax if cfg.sep_dir else 1)) * cfg.F
+    if getattr(lw, "We0", None) is None:
+        lw.We0, lw.be0 = lw.We[:n0], (lw.be[:n0] if lw.be is not None else None)
+    return lw.We0, lw.be0, n0
+
+
 def _T(holder, name: str) -> torch.Tensor:
     """Transposed copy ([in, out] -> the GEMM's [out', in'] layout for input-gradients), cached."""
     t = holder.T.get(name)
@@ -367,13 +390,15 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
         # launch (its 168 tiles fill the tail of the 5100-tile grid).  SiLU of the two hidden blocks is applied ONCE by
         # the epilogue (a SiLU prologue in the two products below would redo it for each of their 4M column tiles); the
         # pre-activation copy is what the backward needs.
-        gemm_group([dict(A=t, lda=F_, W=lw.We, bias=lw.be, C=eproj, ldc=lde, rows=E, nout=lde, K=F_),
+        first = zero_X_in(cfg, li)                  # X is the zero tensor made above: no tensor-gate blocks
+        We, be, ne = _We_first(cfg, lw) if first else (lw.We, lw.be, lde)
+        gemm_group([dict(A=t, lda=F_, W=We, bias=be, C=eproj, ldc=lde, rows=E, nout=ne, K=F_),
                     dict(A=h, lda=F_, W=lw.Wn1, bias=lw.bn1, C=nact, ldc=4 * F_, rows=N, nout=4 * F_, K=F_,
                          act=(2 * F_, 4 * F_), pre_out=nproj if save else None)])
         gemm_group([dict(A=nact, lda=4 * F_, W=lw.Ws2, bias=lw.bs2, C=xs, ldc=M * F_, rows=N, nout=M * F_, K=F_, a_off=2 * F_),
                     dict(A=nact, lda=4 * F_, W=lw.Wv2, bias=lw.bv2, C=vs, ldc=M * F_, rows=N, nout=M * F_, K=F_, a_off=3 * F_)])
         # ---- message / softmax / aggregate / residual (452-559, 613-640, 426-427)
-        message_stage(cfg, g, nact, xs, vs, eproj, attn, h, X, h2, X2)
+        message_stage(cfg, g, nact, xs, vs, eproj, attn, h, None if first else X, h2, X2)
         h, h2 = h2, h
         X, X2 = X2, X
         # every product of the updated X (X W_vu^T for EQFF; EQ and the per-degree EK_l for HTR) in one launch
@@ -626,6 +651,7 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
     for li in reversed(range(len(pw.layers))):
         lw, lt = pw.layers[li], tape.layers[li]
         last = lw.Wt is None
+        first = zero_X_in(cfg, li)
         # ---- EQFF backward, first half; HTR backward kernels (independent of it)
         call("gn_eqff_backward_a", ptr(gh), ptr(gX), ptr(lt.mm), ptr(lt.Xp), N, F_, D, ptr(gm), ptr(gXp), _stream())
         m1 = dict(A=gm, lda=2 * F_, W=_T(lw, "Wm1"), C=g_g1, ldc=F_, rows=N, nout=F_, K=2 * F_,
@@ -687,14 +713,18 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
                     break
         # ---- message backward
         call("gn_message_backward", ptr(lt.xs), ptr(lt.vs), M * F_, ptr(lt.eproj), lde, ptr(lt.attn),
-             ptr(lt.nproj), 4 * F_, ptr(lt.X_in), ptr(g.rl), ptr(g.cut), ptr(g.outdeg),
+             ptr(lt.nproj), 4 * F_, None if first else ptr(lt.X_in), ptr(g.rl), ptr(g.cut), ptr(g.outdeg),
              ptr(gh1), ptr(gX1), ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm),
-             ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), ptr(gX2), rl_slice(li), cut_slice(G * li),
+             ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), None if first else ptr(gX2),
+             rl_slice(li), cut_slice(G * li),
              ptr(ga_parts), E,
              N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act, _stream())
         # the edge-sized W_e^T product leaves 0.7 of its last tile round idle: the two K-heavy atom-sized products
         # (g_x W_s2, g_v W_v2; 60 us as a launch of their own) ride there; W_n1^T needs their output and follows alone
-        gemm_group([dict(A=g_eproj, lda=lde, W=_T(lw, "We"), C=gt_b, ldc=F_, rows=E, nout=F_, K=lde, res=gt_in),
+        if first:                                  # the tensor-gate columns of g_eproj were not written: K-prefix
+            _, _, ke = _We_first(cfg, lw)
+        gemm_group([dict(A=g_eproj, lda=lde, W=_T(lw, "We0" if first else "We"), C=gt_b, ldc=F_, rows=E, nout=F_,
+                         K=ke if first else lde, res=gt_in),
                     dict(A=g_x, lda=M * F_, W=_T(lw, "Ws2"), C=g_nproj, ldc=4 * F_, rows=N, nout=F_, K=M * F_,
                          c_off=2 * F_, dgate=lt.nproj, g_off=2 * F_),
                     dict(A=g_v, lda=M * F_, W=_T(lw, "Wv2"), C=g_nproj, ldc=4 * F_, rows=N, nout=F_, K=M * F_,

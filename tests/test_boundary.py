@@ -450,6 +450,38 @@ def test_energy_forces_topology_cache():
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures("gemm_mode")
+@pytest.mark.parametrize("case", ["l1_nosep_scale_f32", "l2_sep_f32", "l2_mixed_f64ch", "c2_model_3mol_seeded"])
+def test_first_interaction_without_tensor_gate_blocks(case):
+    """GotenNet.forward starts from X = 0 (gotennet.py:992), so the first interaction's tensor-gate terms are 0 * gate:
+    the engine skips those blocks of the edge projection (forward N-prefix, backward K-prefix), of x / v, and the X_in
+    gathers (X_in = NULL forms of gn_message_aggregate / gn_message_backward).  Same energies and forces as the general
+    kernels run on the zero tensor: bit-identical where the GEMM tile shape does not change with the narrower product,
+    else at the arithmetic's own batch-layout noise (<= 2e-6)."""
+    from tests.test_hip_forces import _head_from_case
+    from gotennet_amd import engine
+    from gotennet_amd.pipeline import EnergyForces
+    cfg, sd, head_sd, t = load_case(case)
+    net, head = _mirror(cfg, sd), _head_from_case(cfg, head_sd)
+    z, batch = t["z"].cuda(), t["batch"].cuda()
+    ei, ed, ev = t["edge_index"].cuda(), t["edge_diff"].cuda(), t["edge_vec"].cuda()
+    out = {}
+    for flag in (True, False):
+        old = engine.ZERO_X_FIRST
+        engine.ZERO_X_FIRST = flag
+        try:
+            e, f = EnergyForces(net, head, cache_topology=False)(z, ei, ed, ev, batch, cfg["n_mol"])
+            h, X = net(z, ei, ed, ev)
+            out[flag] = (e.cpu(), f.cpu(), h.detach().cpu(), X.detach().cpu())
+        finally:
+            engine.ZERO_X_FIRST = old
+    for a, b in zip(out[True], out[False]):
+        assert rel_err(a, b) < 2e-6
+    if engine.GEMM_MODE != "f16x2":                  # row-wise arithmetics: the narrower products give the same bits
+        assert all(torch.equal(a, b) for a, b in zip(out[True], out[False]))
+
+
+@pytest.mark.gpu
 def test_gata_module_edge_cases():
     """GATA.forward: no edges -> the (normalised) inputs come back; an n_edges that is not the out-degree of the
     sources raises instead of being ignored."""
