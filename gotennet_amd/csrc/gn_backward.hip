@@ -1070,15 +1070,14 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
     return GN_OK;
 }
 
-// X_in == NULL: the zero-X_in instantiations (compiled for lmax <= 2, where one launch covers all degrees)
+// X_in == NULL: the zero-X_in instantiations (one target + one source launch at every lmax <= 4: without the tensor-gate
+// rows the register budget that forces the degree groups is gone; g_cut then uses ONE slice, the caller zeroes the rest)
 #define GN_MSGB_LAUNCH(L, SD, ST)                                                                        \
     do {                                                                                                  \
-        if constexpr (L <= 2) {                                                                           \
-            if (!X_in) {                                                                                  \
-                hipLaunchKernelGGL((gn::msg_bwd_target_kernel<L, SD, ST, true>), grid, block, 0, st, p);  \
-                hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST, true>), grid, block, 0, st, p);  \
-                break;                                                                                    \
-            }                                                                                             \
+        if (!X_in) {                                                                                      \
+            hipLaunchKernelGGL((gn::msg_bwd_target_kernel<L, SD, ST, true>), grid, block, 0, st, p);      \
+            hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST, true>), grid, block, 0, st, p);      \
+            break;                                                                                        \
         }                                                                                                 \
         hipLaunchKernelGGL((gn::msg_bwd_target_kernel<L, SD, ST>), grid, block, 0, st, p);                \
         hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST>), grid, block, 0, st, p);                \
@@ -1100,7 +1099,7 @@ extern "C" int gn_message_backward(
     if (!bwd_dim_ok(F) || N < 0 || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || lmax < 1 || lmax > 8 ||
         (ldxv & 3) || (lde & 3) || (ldqk & 3) || (ldn & 3) || g_X_out == g_X1 || act < 0 || act >= GN_ACT_COUNT)
         return GN_ERR_BAD_ARG;
-    if (!X_in && (lmax > 2 || act != GN_ACT_SILU || gn_use_highl(lmax))) return GN_ERR_BAD_ARG;   // zero-X_in form: one-launch SiLU kernels only
+    if (!X_in && (act != GN_ACT_SILU || gn_use_highl(lmax))) return GN_ERR_BAD_ARG;   // zero-X_in form: register-tiled SiLU kernels only
     if (N == 0) return GN_OK;
     gn::MsgBwdArgs p{x, v, ldxv, eproj, lde, a, qk, ldqk, X_in, rl, cut, outdeg, g_h1, g_X1,
                      rowptr, src, dst, colptr, perm, g_eproj, g_s, g_nproj, ldn, g_x, g_v, g_X_out, g_rl, g_cut,
@@ -1108,7 +1107,7 @@ extern "C" int gn_message_backward(
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(gn::xcd_grid(N)), block(256);
     if (gn_use_highl(lmax) || act != GN_ACT_SILU) return gn_highl_message_backward(p, lmax, sep_dir, sep_tensor, st);
-    if (gn_message_backward_groups(lmax, sep_dir, sep_tensor, act) > 1) {
+    if (X_in && gn_message_backward_groups(lmax, sep_dir, sep_tensor, act) > 1) {
         // degree groups: target passes (head sums and cut slices per group) -> attention backward -> source passes
         if (ga_parts == nullptr || E <= 0) return GN_ERR_BAD_ARG;
         const size_t gs = (size_t)E * H;

@@ -492,7 +492,7 @@ extern "C" int gn_attn_softmax(const float* q, const float* k, int ldqk, const f
                            h_out, X_out, N, F, H)
 #define GN_MSG_LAUNCH(L, SD, ST)                                          \
     do {                                                                  \
-        if constexpr (L <= 2) { GN_MSG_MONO(L, SD, ST); }                 \
+        if (L <= 2 || !X_in) { GN_MSG_MONO(L, SD, ST); }  /* zero X_in: 1 + D rows of rl * o_d only, one launch */ \
         else {                                                            \
             GN_MSG_ONE(L, SD, ST, 1, 2, true);                            \
             if constexpr (L >= 4 && GN_K6_MERGE34) {                      \
@@ -514,7 +514,7 @@ extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, co
                                     int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream) {
     if (!feature_dim_ok(F) || N < 0 || H <= 0 || lmax < 1 || lmax > 8 || (ldxv & 3) || (ldt & 3) || X_in == X_out)
         return GN_ERR_BAD_ARG;
-    if (!X_in && (lmax > 2 || gn_use_highl(lmax))) return GN_ERR_BAD_ARG;   // the zero-X_in form: one-launch kernels only
+    if (!X_in && gn_use_highl(lmax)) return GN_ERR_BAD_ARG;   // the zero-X_in form: register-tiled kernels only (lmax <= 4)
     const int M = 1 + (sep_dir ? lmax : 1) + (sep_tensor ? lmax : 1);
     if ((M * F) % H || ((M * F) / H) % 4) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;

@@ -68,9 +68,9 @@ ZERO_X_FIRST = os.environ.get("GN_ZERO_X_FIRST", "1") != "0"
 
 def zero_X_in(cfg: "Config", li: int) -> bool:
     """Layer ``li`` of ``forward`` sees the all-zero X that forward itself creates (gotennet.py:992) and the kernels have
-    the zero-X_in form (one-launch SiLU kernels, lmax <= 2): every tensor-gate term of that layer is 0 * gate, so its
+    the zero-X_in form (register-tiled SiLU kernels, lmax <= 4): every tensor-gate term of that layer is 0 * gate, so its
     blocks of the edge projection are neither computed nor read, and nothing consumes the gradient w.r.t. X_in."""
-    return ZERO_X_FIRST and li == 0 and cfg.lmax <= 2 and cfg.act == 0 and not cfg.steerable_norm and not _FORCE_HIGHL
+    return ZERO_X_FIRST and li == 0 and cfg.lmax <= 4 and cfg.act == 0 and not cfg.steerable_norm and not _FORCE_HIGHL
 
 
 def _We_first(cfg: "Config", lw) -> Tuple[torch.Tensor, torch.Tensor, int]:
@@ -712,6 +712,8 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
                 if joint:
                     break
         # ---- message backward
+        if first and G > 1:                        # one launch instead of G degree groups: one g_cut slice is written
+            g_cut_parts[G * li + 1:G * li + G].zero_()
         call("gn_message_backward", ptr(lt.xs), ptr(lt.vs), M * F_, ptr(lt.eproj), lde, ptr(lt.attn),
              ptr(lt.nproj), 4 * F_, None if first else ptr(lt.X_in), ptr(g.rl), ptr(g.cut), ptr(g.outdeg),
              ptr(gh1), ptr(gX1), ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm),

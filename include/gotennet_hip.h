@@ -215,7 +215,7 @@ int gn_attn_softmax(const float* q, const float* k, int ldqk, const float* t_att
  *   X_out[i,m,:] = X_in[i,m,:] + sum_e ( rl[e,m] * o[dblk(l(m))] + X_in[j,m,:] * o[tblk(l(m))] )
  * with dblk/tblk the F-wide block of the direction / tensor gate of degree l (sep_dir / sep_tensor).
  * x, v rows of ldxv floats; t_filter rows of ldt floats.  X_out must not alias X_in.
- * X_in == NULL (lmax <= 2) means "X_in is identically zero" -- the first interaction of GotenNet.forward, which starts
+ * X_in == NULL (lmax <= 4) means "X_in is identically zero" -- the first interaction of GotenNet.forward, which starts
  * from X = 0 (gotennet.py:992): the tensor-gate blocks of t_filter / x / v are then NOT READ (they may be unwritten)
  * and X_out = the aggregated update; same bits as passing a zero tensor. */
 int gn_message_aggregate(const float* x, const float* v, int ldxv, const float* t_filter, int ldt,
@@ -268,7 +268,7 @@ int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* w, co
  * column F; X_in [N,D,F]; upstream g_h1 [N,F], g_X1 [N,D,F].  Outputs: g_eproj [E,(1+M)F] (gradient w.r.t.
  * the t_attn pre-activation | t_filter), g_s [E,H] scratch, g_nproj rows (ldn) with g_q at column 0 and g_k
  * at column F, g_x, g_v [N,MF], g_X_out = g_X1 + (tensor-gate path), g_rl [E,D] and g_cut [E] slices.
- * X_in == NULL (lmax <= 2, SiLU): X_in identically zero (first interaction).  The tensor-gate blocks of eproj / x / v
+ * X_in == NULL (lmax <= 4, SiLU): X_in identically zero (first interaction); one g_cut slice is written (not one per degree group).  The tensor-gate blocks of eproj / x / v
  * are not read, the tensor-gate columns of g_eproj are NOT WRITTEN (take the K-prefix (2 + ND) F of the W_e^T product
  * that consumes it), those blocks of g_x / g_v are written as zeros, g_X_out is not written (may be NULL). */
 int gn_message_backward(const float* x, const float* v, int ldxv, const float* eproj, int lde, const float* a,

@@ -451,11 +451,13 @@ def test_energy_forces_topology_cache():
 
 @pytest.mark.gpu
 @pytest.mark.usefixtures("gemm_mode")
-@pytest.mark.parametrize("case", ["l1_nosep_scale_f32", "l2_sep_f32", "l2_mixed_f64ch", "c2_model_3mol_seeded"])
+@pytest.mark.parametrize("case", ["l1_nosep_scale_f32", "l2_sep_f32", "l2_mixed_f64ch", "c2_model_3mol_seeded",
+                                  "l3_sep_scale_f32", "l4_sep_f32", "c2_model_lmax4_1mol_seeded"])
 def test_first_interaction_without_tensor_gate_blocks(case):
     """GotenNet.forward starts from X = 0 (gotennet.py:992), so the first interaction's tensor-gate terms are 0 * gate:
     the engine skips those blocks of the edge projection (forward N-prefix, backward K-prefix), of x / v, and the X_in
-    gathers (X_in = NULL forms of gn_message_aggregate / gn_message_backward).  Same energies and forces as the general
+    gathers (X_in = NULL forms of gn_message_aggregate / gn_message_backward; at lmax 3-4 one launch instead of the degree
+    groups).  Same energies and forces as the general
     kernels run on the zero tensor: bit-identical where the GEMM tile shape does not change with the narrower product,
     else at the arithmetic's own batch-layout noise (<= 2e-6)."""
     from tests.test_hip_forces import _head_from_case
@@ -478,7 +480,11 @@ def test_first_interaction_without_tensor_gate_blocks(case):
     for a, b in zip(out[True], out[False]):
         assert rel_err(a, b) < 2e-6
     if engine.GEMM_MODE != "f16x2":                  # row-wise arithmetics: the narrower products give the same bits
-        assert all(torch.equal(a, b) for a, b in zip(out[True], out[False]))
+        e1, f1, h1, X1 = out[True]
+        e0, f0, h0, X0 = out[False]
+        assert torch.equal(e1, e0) and torch.equal(h1, h0) and torch.equal(X1, X0)
+        if cfg["lmax"] <= 2:                         # above, the general backward sums its g_cut per degree group
+            assert torch.equal(f1, f0)
 
 
 @pytest.mark.gpu
