@@ -81,6 +81,14 @@ def _We_first(cfg: "Config", lw) -> Tuple[torch.Tensor, torch.Tensor, int]:
     return lw.We0, lw.be0, n0
 
 
+def _value_first(cfg: "Config", lw) -> int:
+    """Rows of gamma_s.1 / gamma_v.1 without the tensor-gate blocks (a prefix: scalar, direction gates)."""
+    n0 = (1 + (cfg.lmax if cfg.sep_dir else 1)) * cfg.F
+    if getattr(lw, "Ws20", None) is None:
+        lw.Ws20, lw.Wv20 = lw.Ws2[:n0], lw.Wv2[:n0]
+    return n0
+
+
 def _T(holder, name: str) -> torch.Tensor:
     """Transposed copy ([in, out] -> the GEMM's [out', in'] layout for input-gradients), cached."""
     t = holder.T.get(name)
@@ -395,8 +403,11 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
         gemm_group([dict(A=t, lda=F_, W=We, bias=be, C=eproj, ldc=lde, rows=E, nout=ne, K=F_),
                     dict(A=h, lda=F_, W=lw.Wn1, bias=lw.bn1, C=nact, ldc=4 * F_, rows=N, nout=4 * F_, K=F_,
                          act=(2 * F_, 4 * F_), pre_out=nproj if save else None)])
-        gemm_group([dict(A=nact, lda=4 * F_, W=lw.Ws2, bias=lw.bs2, C=xs, ldc=M * F_, rows=N, nout=M * F_, K=F_, a_off=2 * F_),
-                    dict(A=nact, lda=4 * F_, W=lw.Wv2, bias=lw.bv2, C=vs, ldc=M * F_, rows=N, nout=M * F_, K=F_, a_off=3 * F_)])
+        nv = _value_first(cfg, lw) if first else M * F_
+        gemm_group([dict(A=nact, lda=4 * F_, W=lw.Ws20 if first else lw.Ws2, bias=lw.bs2, C=xs, ldc=M * F_, rows=N, nout=nv,
+                         K=F_, a_off=2 * F_),
+                    dict(A=nact, lda=4 * F_, W=lw.Wv20 if first else lw.Wv2, bias=lw.bv2, C=vs, ldc=M * F_, rows=N, nout=nv,
+                         K=F_, a_off=3 * F_)])
         # ---- message / softmax / aggregate / residual (452-559, 613-640, 426-427)
         message_stage(cfg, g, nact, xs, vs, eproj, attn, h, None if first else X, h2, X2)
         h, h2 = h2, h
@@ -727,9 +738,10 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
             _, _, ke = _We_first(cfg, lw)
         gemm_group([dict(A=g_eproj, lda=lde, W=_T(lw, "We0" if first else "We"), C=gt_b, ldc=F_, rows=E, nout=F_,
                          K=ke if first else lde, res=gt_in),
-                    dict(A=g_x, lda=M * F_, W=_T(lw, "Ws2"), C=g_nproj, ldc=4 * F_, rows=N, nout=F_, K=M * F_,
-                         c_off=2 * F_, dgate=lt.nproj, g_off=2 * F_),
-                    dict(A=g_v, lda=M * F_, W=_T(lw, "Wv2"), C=g_nproj, ldc=4 * F_, rows=N, nout=F_, K=M * F_,
+                    dict(A=g_x, lda=M * F_, W=_T(lw, "Ws20" if first else "Ws2"), C=g_nproj, ldc=4 * F_, rows=N, nout=F_,
+                         K=_value_first(cfg, lw) if first else M * F_, c_off=2 * F_, dgate=lt.nproj, g_off=2 * F_),
+                    dict(A=g_v, lda=M * F_, W=_T(lw, "Wv20" if first else "Wv2"), C=g_nproj, ldc=4 * F_, rows=N, nout=F_,
+                         K=_value_first(cfg, lw) if first else M * F_,
                          c_off=3 * F_, dgate=lt.nproj, g_off=3 * F_)])
         gemm(g_nproj, 4 * F_, _T(lw, "Wn1"), None, gh2, F_, N, F_, 4 * F_, res=gh1)
         gh, gh2 = gh2, gh
