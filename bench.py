@@ -73,8 +73,13 @@ def family(tag):
     return "gn_gemm" if tag.startswith("gn_gemm[") else tag
 
 
-def algorithmic_bytes_message(N, E, F, M, D):
-    """SURVEY.md 8(d) B_msg: every distinct input element read once, every output written once."""
+def algorithmic_bytes_message(N, E, F, M, D, first_nd=None):
+    """SURVEY.md 8(d) B_msg: every distinct input element read once, every output written once.
+    ``first_nd`` (the number of direction-gate blocks): the launch of the FIRST interaction, whose X_in is identically
+    zero -- no tensor-gate blocks of t_filter / x / v and no X_in table (gotennet_amd.engine.zero_X_in)."""
+    if first_nd is not None:
+        Mv = 1 + first_nd
+        return 4 * N * (2 * F + 2 * Mv * F) + E * (4 * (F + Mv * F + D + 2) + 16) + 4 * N * (F + D * F)
     return 4 * N * (2 * F + 2 * M * F + D * F) + E * (4 * (F + M * F + D + 2) + 16) + 4 * N * (F + D * F)
 
 
@@ -318,6 +323,15 @@ def algorithmic_bytes_message_backward(N, E, F, M, D, H):
     return edge + node
 
 
+def algorithmic_bytes_message_backward_first(N, E, F, ND, D, H):
+    """The same for the first interaction (X_in identically zero): no tensor-gate blocks in eproj / g_eproj / x / v / g_x /
+    g_v, no X_in table, no g_X rows."""
+    Mv = 1 + ND
+    edge = 4 * E * (2 * (1 + Mv) * F + 2 * H + 2 * D + 2) + 16 * E
+    node = 4 * N * (2 * Mv * F + 2 * F + D * F + F) + 4 * N * (2 * Mv * F + 2 * F)
+    return edge + node
+
+
 def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
     import gotennet_amd
     from gotennet_amd import _lib, synthetic
@@ -363,6 +377,8 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
     torch.cuda.synchronize()
     _lib.TIMER = None
     tot, cnt = kt.summary()
+    from gotennet_amd import engine as _eng
+    zero_first = _eng.zero_X_in(rep.config(), 0)
     fam = {}
     for tag, t in tot.items():
         fam[family(tag)] = fam.get(family(tag), 0.0) + t
@@ -458,12 +474,20 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
         tags = sorted(t for t in tot if t in MSG_STAGE)
         layers = cnt[tags[0]] // steps if tags else 0
         us = sum(1e3 * tot[t] / cnt[t] for t in tags)              # per layer: one launch of each stage kernel
-        nbytes = algorithmic_bytes_message(N, E, F, M, D)
+        full = algorithmic_bytes_message(N, E, F, M, D)
+        first = algorithmic_bytes_message(N, E, F, M, D, first_nd=lmax) if zero_first and layers else None
+        nbytes = (full * (layers - 1) + first) / layers if first else full      # launch-weighted mean over the layers
         ach = nbytes / (us * 1e-6) / 1e9
-        return dict(kernel="+".join(tags), bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic("message_stage", lmax, workload, B),
-                    us_per_launch=round(us, 2), us_by_kernel={t: round(1e3 * tot[t] / cnt[t], 2) for t in tags},
-                    launches_per_step=layers, algorithmic_bytes_per_launch=nbytes)
+        out = dict(kernel="+".join(tags), bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                   frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic("message_stage", lmax, workload, B),
+                   us_per_launch=round(us, 2), us_by_kernel={t: round(1e3 * tot[t] / cnt[t], 2) for t in tags},
+                   launches_per_step=layers, algorithmic_bytes_per_launch=int(nbytes))
+        if first:
+            out.update(algorithmic_bytes_general_launch=full, algorithmic_bytes_first_launch=first,
+                       note="the first interaction starts from X = 0: its launch skips the tensor-gate blocks and the X_in "
+                            "table and is priced with its own, smaller byte count; bytes and time are means over the "
+                            f"{layers} launches of a step")
+        return out
 
     def roof_htr():
         """K7 gn_htr_edge: the kernel's own compulsory bytes (EQ / EK tables, rl, index, w written) / its duration."""
@@ -483,7 +507,10 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
         if MSGB_TAG not in tot:
             return None
         us = 1e3 * tot[MSGB_TAG] / cnt[MSGB_TAG]
+        layers = cnt[MSGB_TAG] // steps
         nbytes = algorithmic_bytes_message_backward(N, E, F, M, D, H)
+        if zero_first and layers:                                    # the first interaction's launch pair moves less
+            nbytes = int((nbytes * (layers - 1) + algorithmic_bytes_message_backward_first(N, E, F, lmax, D, H)) / layers)
         ach = nbytes / (us * 1e-6) / 1e9
         return dict(kernel=MSGB_TAG + " (target + source passes of one layer)", bound="hbm", achieved=round(ach, 1),
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),

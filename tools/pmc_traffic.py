@@ -38,13 +38,12 @@ def entry_for(fetch_path, write_path):
     htr = [k for k, _ in pick(f, "htr_edge")]
     gem = [k for k, _ in pick(f, "gn::gemm_") if "split" not in k]           # the projection kernels of the default mode
     n = sum(f[k][1] for k in gem)
-    # message backward of one layer: the target and source passes (all degree groups) + the separate attention
-    # backward of the grouped path; launches per layer from the kernel that runs once per layer
+    # message stage / message backward of one layer: all kernels of the family (general kernels, degree groups, the
+    # zero-X_in kernels of the first interaction), mean over the layers
     mb = [k for k in f if "msg_bwd_" in k or "attn_bwd_kernel" in k]
-    once = [k for k in mb if "attn_bwd_kernel" in k] or [k for k in mb if "msg_bwd_target_kernel" in k]
-    layers = sum(f[k][1] for k in once)
+    layers = f[soft][1]                       # the softmax runs once per interaction: launches = layers x steps
     entry = {
-        "gn_message_aggregate": int(sum(byt(k) * f[k][1] for k in msg) / max(f[k][1] for k in msg)),
+        "gn_message_aggregate": int(sum(byt(k) * f[k][1] for k in msg) / layers),
         "gn_attn_softmax": byt(soft),
         "gn_htr_edge": int(sum(byt(k) * f[k][1] for k in htr) / max(f[k][1] for k in htr)),
         "gn_gemm_family_avg": int(sum(byt(k) * f[k][1] for k in gem) / n),
