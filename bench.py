@@ -191,7 +191,7 @@ def worker(a):
     from gotennet_amd import engine
     res = measure(a, a.workload, a.batch, a.lmax, a.steps, a.warmup, rank, world, dev, dist)
     sides = world == 1                              # side measurements only on the single-GPU line
-    side = lat = None
+    side = lat = lat_batch = None
     wl = {}
     if sides and a.lmax != 4 and not a.no_lmax4 and a.workload == "rmd17_aspirin":
         # the north-star's "L=4" target shape (lmax = 4): the gather/scatter target is quoted on it
@@ -217,6 +217,7 @@ def worker(a):
         fwd = forward_only(a, res["rep"], res["head"], dev)
     if sides and not a.no_graph:
         lat = graph_latency(a, res["rep"], res["head"], dev)
+        lat_batch = graph_latency(a, res["rep"], res["head"], dev, n_mol=a.batch, iters=20)
     if rank == 0:
         out = res["out"]
         also = out.setdefault("also", {})
@@ -225,6 +226,8 @@ def worker(a):
                           "config": so["config"]["workload"]}
         if lat is not None:
             also["single_molecule_latency"] = lat
+        if lat_batch is not None:                  # the headline batch as ONE hipGraph replay per step (fixed edge list)
+            also["hipgraph_replay_full_batch"] = lat_batch
         if fwd is not None:
             if not a.no_cpu_baseline:
                 fwd["cpu_baseline"] = cpu_baseline(res["rep"], res["head"], a.workload, a.lmax, forces=False)
