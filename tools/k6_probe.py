@@ -1,6 +1,7 @@
 """Where is K6 bound?  The same launch with (a) the real source indices, (b) every edge's source = its target (the
 gathered rows then come from L1/L2-hot lines: no L2 -> CU gather traffic to speak of), (c) sources shuffled over the
-whole batch (no L2 locality)."""
+whole batch (no L2 locality), (d) every edge reading the SAME t_filter row (row stride 0: the per-edge stream costs nothing --
+what a perfect prefetch of that stream could reach)."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from gotennet_amd import synthetic
@@ -16,8 +17,8 @@ r = lambda *s: torch.randn(*s, device="cuda")
 x, v, tf, a, rl, cut = r(N, M * F), r(N, M * F), r(E, (1 + M) * F), r(E, H), r(E, D), r(E)
 h, X, h2, X2 = r(N, F), r(N, D, F), torch.empty(N, F, device="cuda"), torch.empty(N, D, F, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
-def run(s):
-    f = lambda: call("gn_message_aggregate", ptr(x), ptr(v), M * F, tf.data_ptr() + 4 * F, (1 + M) * F, ptr(a), ptr(rl), ptr(cut),
+def run(s, ldt=(1 + M) * F):
+    f = lambda: call("gn_message_aggregate", ptr(x), ptr(v), M * F, tf.data_ptr() + 4 * F, ldt, ptr(a), ptr(rl), ptr(cut),
                      ptr(rowptr), ptr(s), ptr(h), ptr(X), ptr(h2), ptr(X2), N, F, H, lmax, 1, 1, st)
     for _ in range(3): f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -28,3 +29,4 @@ def run(s):
 print("real sources      : %.1f us" % run(src))
 print("source = target   : %.1f us" % run(dst.clone()))
 print("shuffled sources  : %.1f us" % run(src[torch.randperm(E, device="cuda")].contiguous()))
+print("one t_filter row  : %.1f us (real sources, row stride 0)" % run(src, 0))
