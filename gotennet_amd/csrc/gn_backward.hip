@@ -268,6 +268,18 @@ __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, float* 
             }
         }
     }
+    // phase 3's rows of this slot's first PF3 edges are requested HERE, ahead of the two barriers of phase 2: they do not
+    // depend on it, and fetched inside phase 3 each trip exposes one HBM round trip (t_attn row) with two loads in flight
+    constexpr int PF3 = GN_MSGB_PF3;
+    float4 kj_pf[PF3 ? PF3 : 1], pta_pf[PF3 ? PF3 : 1];
+    if (PF3 && e1 > e0) {
+#pragma unroll
+        for (int u = 0; u < PF3; ++u) {
+            const int e = e0 + slot + u * ns, ec = e < e1 ? e : e1 - 1;
+            kj_pf[u] = ld4(qk_ + (size_t)src_[ec] * p.ldqk + F + c0);
+            pta_pf[u] = ld4_nt(eproj_ + (size_t)ec * p.lde + c0);
+        }
+    }
     __syncthreads();
     // ---- phase 2: softmax backward per head:  g_s = a g_a - (a / nrm) sum_e' a g_a
     {
@@ -292,15 +304,20 @@ __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, float* 
         const int n = (e1 - e0) * H;
         for (int idx = threadIdx.x; idx < n; idx += 256) g_s_[(size_t)e0 * H + idx] = gsl[idx];
     }
-    for (int e = e0 + slot; e < e1; e += ns) {
+    auto score_bwd = [&](int e, float4 kj, float4 pta) {
         const float gs = GS(e, hq);
-        const float4 kj = ld4(qk_ + (size_t)src_[e] * p.ldqk + F + c0);
-        const float4 pta = ld4_nt(eproj_ + (size_t)e * p.lde + c0);
         float4 a_ta, d_ta;
         act_pair4(pta, GN_ACT_SILU, a_ta, d_ta);
         gq = fma4(gs, kj * a_ta, gq);
         st4_nt(g_eproj_ + (size_t)e * p.lde + c0, ((qi * kj) * gs) * d_ta);   // d/d(pre-activation of t_attn)
+    };
+#pragma unroll
+    for (int u = 0; u < PF3; ++u) {
+        const int e = e0 + slot + u * ns;
+        if (e < e1) score_bwd(e, kj_pf[u], pta_pf[u]);
     }
+    for (int e = e0 + slot + PF3 * ns; e < e1; e += ns)
+        score_bwd(e, ld4(qk_ + (size_t)src_[e] * p.ldqk + F + c0), ld4_nt(eproj_ + (size_t)e * p.lde + c0));
     st4(&red[slot * F + c0], gq);
     __syncthreads();
     if (slot == 0) st4(g_nproj_ + (size_t)i * p.ldn + c0, red4(red, c0, F, ns));

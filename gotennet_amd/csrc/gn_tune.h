@@ -59,6 +59,11 @@
                            // cost nothing, the kernel sits at 2 waves/SIMD on registers)
 #endif
 
+#ifndef GN_MSGB_PF3
+#define GN_MSGB_PF3 4      // message backward, target pass: trips of the score-backward phase whose rows are requested before
+                           // the softmax-backward barriers (0: none)
+#endif
+
 #define GN_TUNE_CAT_(a, b) a##b
 #define GN_TUNE_CAT(a, b) GN_TUNE_CAT_(a, b)
 #define GN_WPE_SEL_0
