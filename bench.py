@@ -395,18 +395,20 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
             print(f"  {tag:42s} {tot[tag]:8.3f} ms/step {cnt[tag]:3d} calls {1e3 * tot[tag] / cnt[tag]:8.1f} us/call "
                   f"{100 * tot[tag] / ssum:5.1f}%", file=sys.stderr)
 
-    # ---- timed region: exactly K steps, events only around the dominant + message-stage + HTR kernels
-    # (the projection launches of a step are bracketed on the LAST timed step only, so that the event records do not
-    # perturb `value`; the message-stage and HTR launches are bracketed on every step)
+    # ---- timed region: exactly K steps.  HIP events bracket the message-stage / HTR / message-backward launches on the
+    # LAST `ev_steps` timed steps and the projection launches on the last one only: bracketing those ~23 launches on
+    # every step cost 0.115 ms/step (8.11 vs 7.995 ms, same process), i.e. the measurement perturbed `value` by 1.4 %;
+    # the per-launch averages are the same either way (111.1 us for the message stage in both).
     dom_tags = {t for t in tot if family(t) == dominant}
     always = stage_tags | {HTR_TAG, MSGB_TAG}
-    kt = KernelTimer(wanted=set(always) if len(dom_tags) > 8 else dom_tags | always)
+    ev_steps = min(3, steps)
+    kt = KernelTimer(wanted=set())
     _lib.TIMER = kt
     fence()
     t0 = time.perf_counter()
     for it in range(steps):
-        if it == steps - 1:
-            kt.wanted = dom_tags | always
+        if it >= steps - ev_steps:
+            kt.wanted = (dom_tags | always) if it == steps - 1 else set(always)
         e, f = step()
     fence()
     dt = time.perf_counter() - t0
@@ -425,7 +427,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
 
     tot, cnt = kt.summary()
 
-    dom_steps = 1 if len(dom_tags) > 8 else steps
+    dom_steps = 1
 
     def roof_gemm_family():
         """All projection launches of the timed region: algorithmic flops / summed launch time."""
@@ -475,7 +477,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
         """GATA message STAGE: SURVEY 8d B_msg over the summed duration of the stage's launches (one fused launch,
         or scores/softmax + message/aggregate)."""
         tags = sorted(t for t in tot if t in MSG_STAGE)
-        layers = cnt[tags[0]] // steps if tags else 0
+        layers = cnt[tags[0]] // ev_steps if tags else 0
         us = sum(1e3 * tot[t] / cnt[t] for t in tags)              # per layer: one launch of each stage kernel
         full = algorithmic_bytes_message(N, E, F, M, D)
         first = algorithmic_bytes_message(N, E, F, M, D, first_nd=lmax) if zero_first and layers else None
@@ -501,7 +503,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
         ach = nbytes / (us * 1e-6) / 1e9
         return dict(kernel=HTR_TAG, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic(HTR_TAG, lmax, workload, B), us_per_launch=round(us, 2),
-                    launches_per_step=cnt[HTR_TAG] // steps, algorithmic_bytes_per_launch=nbytes,
+                    launches_per_step=cnt[HTR_TAG] // ev_steps, algorithmic_bytes_per_launch=nbytes,
                     note="bytes = 4N*2DF (EQ, EK tables) + E(4(F + D) + 16) (w written, rl, 2 x int64 index): the kernel's "
                          "own share of SURVEY 8d B_htr (the t read / t' write of the stage sit in the gated GEMM epilogue)")
 
@@ -510,7 +512,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
         if MSGB_TAG not in tot:
             return None
         us = 1e3 * tot[MSGB_TAG] / cnt[MSGB_TAG]
-        layers = cnt[MSGB_TAG] // steps
+        layers = cnt[MSGB_TAG] // ev_steps
         nbytes = algorithmic_bytes_message_backward(N, E, F, M, D, H)
         if zero_first and layers:                                    # the first interaction's launch pair moves less
             nbytes = int((nbytes * (layers - 1) + algorithmic_bytes_message_backward_first(N, E, F, lmax, D, H)) / layers)
@@ -518,7 +520,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
         return dict(kernel=MSGB_TAG + " (target + source passes of one layer)", bound="hbm", achieved=round(ach, 1),
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                     traffic=_pmc_traffic(MSGB_TAG, lmax, workload, B), us_per_launch=round(us, 2),
-                    launches_per_step=cnt[MSGB_TAG] // steps, algorithmic_bytes_per_launch=nbytes,
+                    launches_per_step=cnt[MSGB_TAG] // ev_steps, algorithmic_bytes_per_launch=nbytes,
                     note="bytes = eproj read ONCE + g_eproj written once + a, rl, cut, g_s, g_rl, g_cut + node tables "
                          "(x, v, q|k, X_in, g_h1, g_X1 read; g_x, g_v, g_q|g_k, g_X written); the kernels read eproj in "
                          "both passes, so PMC traffic above this figure is the second read")
