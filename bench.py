@@ -51,13 +51,22 @@ class KernelTimer:
             return "gn_gemm[" + "+".join(f"{args[0][i].M}x{args[0][i].N}x{args[0][i].K}" for i in range(args[1])) + "]"
         return name
 
+    #: X_in argument of the two message entries: None = the zero-X_in launch of the first interaction
+    X_IN_ARG = {"gn_message_aggregate": 11, "gn_message_backward": 8}
+
     def want(self, name, args):
         tag = self.tag_of(name, args)
-        return tag if (self.wanted is None or tag in self.wanted) else None
+        if self.wanted is not None and tag not in self.wanted:
+            return None
+        k = self.X_IN_ARG.get(name)
+        return tag + "|first" if (k is not None and args[k] is None) else tag
 
-    def summary(self):
+    def summary(self, split_first=False):
+        """Total ms and launch count per tag; ``split_first`` keeps the first interaction's launches apart."""
         tot, cnt = {}, {}
         for tag, e0, e1 in self.events:
+            if not split_first:
+                tag = tag.split("|")[0]
             tot[tag] = tot.get(tag, 0.0) + e0.elapsed_time(e1)
             cnt[tag] = cnt.get(tag, 0) + 1
         return tot, cnt
@@ -492,6 +501,15 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
                        note="the first interaction starts from X = 0: its launch skips the tensor-gate blocks and the X_in "
                             "table and is priced with its own, smaller byte count; bytes and time are means over the "
                             f"{layers} launches of a step")
+            tot_s, cnt_s = kt.summary(split_first=True)
+            k6, k6f, sm = "gn_message_aggregate", "gn_message_aggregate|first", "gn_attn_softmax"
+            if k6 in tot_s and k6f in tot_s and sm in tot_s:
+                us_sm = 1e3 * tot_s[sm] / cnt_s[sm]
+                us_g, us_f = us_sm + 1e3 * tot_s[k6] / cnt_s[k6], us_sm + 1e3 * tot_s[k6f] / cnt_s[k6f]
+                out.update(general_launches=dict(us_per_launch=round(us_g, 2),
+                                                 frac=round(full / (us_g * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)),
+                           first_launch=dict(us_per_launch=round(us_f, 2),
+                                             frac=round(first / (us_f * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)))
         return out
 
     def roof_htr():
