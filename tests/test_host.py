@@ -151,3 +151,37 @@ def test_synthetic_shards_are_consistent():
         assert torch.equal(torch.cat([p for p, _ in parts]), pos)
         assert torch.equal(torch.cat([q for _, q in parts]), z)
     assert pos.shape == (8 * 21, 3) and int(batch.max()) == 7
+
+
+def test_bench_line_fits_driver_tail():
+    """The driver parses the LAST stdout line out of an 8 KB tail (round 3's 21 KB line was not parsed).  Build the
+    compact line from a canned full record (the committed round-3 run, the largest record the bench ever produced)
+    and hold it to the budget and the contract keys."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    assert len(json.dumps(full)) > 8000                      # the canned record is the oversized one
+    line = bench.compact_line(full)
+    assert "\n" not in line and len(line) < bench.LINE_BUDGET < 8000
+    out = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_gather_scatter", "roofline_htr_edge",
+              "roofline_message_backward", "cpu_baseline", "also"):
+        assert k in out, k
+    assert "workload" in out["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in out["roofline"], k
+        assert k in out["roofline_gather_scatter"], k
+    assert not any(isinstance(v, dict) and "stages" in v for v in out.values())     # one level, no nested copies
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in out["cpu_baseline"], k
+    # the side workloads keep their four family fractions
+    for wl in ("lmax4", "md22_ac_ala3_b64", "md22_nanotube_b8_lmax3"):
+        for k in ("value", "ms_per_step", "gather_frac", "htr_frac", "msg_bwd_frac", "gemm_frac"):
+            assert k in out["also"][wl], (wl, k)
+    assert out["value"] == full["value"] and out["ms_per_step"] == full["ms_per_step"]
+    # a pathological record (a huge `also`) sheds `also`, never the contract keys
+    fat = dict(full)
+    fat["also"] = {f"w{i}": dict(full["also"]["lmax4"], config="x" * 80) for i in range(40)}
+    line = bench.compact_line(fat)
+    assert len(line) < bench.LINE_BUDGET and "roofline" in json.loads(line) and "cpu_baseline" in json.loads(line)
