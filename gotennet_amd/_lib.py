@@ -14,7 +14,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GN_LIB_PATH") or os.path.join(_PKG, "libgotennet_hip.so")
 
 GN_ERR_BAD_ARG = 10001
-ABI_VERSION = 6
+ABI_VERSION = 7
+LMAX_SLICED = 0x100      # GN_LMAX_SLICED: OR-ed into the lmax argument of the message / HTR entry points
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 

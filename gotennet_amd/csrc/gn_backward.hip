@@ -1052,13 +1052,15 @@ static bool bwd_dim_ok(int F) { return F >= 16 && F <= 256 && gn::is_pow2(F); }
 extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const float* w, const float* w_raw,
                                const float* EQ,
                                const float* EK, const float* rl, const int* rowptr, const int* src, const int* dst,
-                               const int* colptr, const int* perm, int N, int F, int lmax, int mode,
+                               const int* colptr, const int* perm, int N, int F, int lmax_arg, int mode,
                                float* gEQ, float* gEK, float* g_rl, float* g_pre_t, int act, void* stream) {
-    if (!bwd_dim_ok(F) || N < 0 || lmax < 1 || lmax > 8 || mode < 0 || mode > 31 || act < 0 || act >= GN_ACT_COUNT)
+    const int lmax = lmax_arg & 0xff;               // GN_LMAX_SLICED may ride in the argument (gn_use_highl)
+    if ((lmax_arg & ~(0xff | GN_LMAX_SLICED)) || !bwd_dim_ok(F) || N < 0 || lmax < 1 || lmax > 8 || mode < 0 || mode > 31 ||
+        act < 0 || act >= GN_ACT_COUNT)
         return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (gn_use_highl(lmax) || (!mode && act != GN_ACT_SILU))
+    if (gn_use_highl(lmax_arg) || (!mode && act != GN_ACT_SILU))
         return gn_highl_htr_backward(g_t_out, pre_t, w, w_raw, EQ, EK, rl, rowptr, src, dst, colptr, perm, N, F, lmax,
                                      mode, gEQ, gEK, g_rl, g_pre_t, act, st);
     if (mode)
@@ -1100,8 +1102,9 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
         hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST>), grid, block, 0, st, p);                \
     } while (0)
 
-extern "C" int gn_message_backward_groups(int lmax, int sep_dir, int sep_tensor, int act) {
-    if (gn_use_highl(lmax) || act != GN_ACT_SILU) return 1;      // degree-sliced kernels (gn_highl.hip): one slice
+extern "C" int gn_message_backward_groups(int lmax_arg, int sep_dir, int sep_tensor, int act) {
+    const int lmax = lmax_arg & 0xff;
+    if (gn_use_highl(lmax_arg) || act != GN_ACT_SILU) return 1;      // degree-sliced kernels (gn_highl.hip): one slice
     return (lmax >= 3 && sep_dir && sep_tensor) ? lmax - 1 : 1;
 }
 
@@ -1112,19 +1115,20 @@ extern "C" int gn_message_backward(
     const int* rowptr, const int* src, const int* dst, const int* colptr, const int* perm,
     float* g_eproj, float* g_s, float* g_nproj, int ldn, float* g_x, float* g_v, float* g_X_out,
     float* g_rl, float* g_cut, float* ga_parts, long E,
-    int N, int F, int H, int lmax, int sep_dir, int sep_tensor, int act, void* stream) {
-    if (!bwd_dim_ok(F) || N < 0 || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || lmax < 1 || lmax > 8 ||
+    int N, int F, int H, int lmax_arg, int sep_dir, int sep_tensor, int act, void* stream) {
+    const int lmax = lmax_arg & 0xff;
+    if ((lmax_arg & ~(0xff | GN_LMAX_SLICED)) || !bwd_dim_ok(F) || N < 0 || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || lmax < 1 || lmax > 8 ||
         (ldxv & 3) || (lde & 3) || (ldqk & 3) || (ldn & 3) || g_X_out == g_X1 || act < 0 || act >= GN_ACT_COUNT)
         return GN_ERR_BAD_ARG;
-    if (!X_in && (act != GN_ACT_SILU || gn_use_highl(lmax))) return GN_ERR_BAD_ARG;   // zero-X_in form: register-tiled SiLU kernels only
+    if (!X_in && (act != GN_ACT_SILU || gn_use_highl(lmax_arg))) return GN_ERR_BAD_ARG;   // zero-X_in form: register-tiled SiLU kernels only
     if (N == 0) return GN_OK;
     gn::MsgBwdArgs p{x, v, ldxv, eproj, lde, a, qk, ldqk, X_in, rl, cut, outdeg, g_h1, g_X1,
                      rowptr, src, dst, colptr, perm, g_eproj, g_s, g_nproj, ldn, g_x, g_v, g_X_out, g_rl, g_cut,
                      N, F, H, (float)(1.0 / sqrt((double)F)), act};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(gn::xcd_grid(N)), block(256);
-    if (gn_use_highl(lmax) || act != GN_ACT_SILU) return gn_highl_message_backward(p, lmax, sep_dir, sep_tensor, st);
-    if (X_in && gn_message_backward_groups(lmax, sep_dir, sep_tensor, act) > 1) {
+    if (gn_use_highl(lmax_arg) || act != GN_ACT_SILU) return gn_highl_message_backward(p, lmax, sep_dir, sep_tensor, st);
+    if (X_in && gn_message_backward_groups(lmax_arg, sep_dir, sep_tensor, act) > 1) {
         // degree groups: target passes (head sums and cut slices per group) -> attention backward -> source passes
         if (ga_parts == nullptr || E <= 0) return GN_ERR_BAD_ARG;
         const size_t gs = (size_t)E * H;

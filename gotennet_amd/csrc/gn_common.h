@@ -24,8 +24,12 @@ namespace gn {
 
 // sigmoid on the hardware transcendentals: v_exp_f32 (2^x) and v_rcp_f32, ~1 ulp each -- 4 VALU instead of the ~20 of
 // expf + an IEEE division.  Round-3 counters: the segment softmax was VALU-bound (1080 VALU instructions per wave, 23 of
-// its 29 us), SiLU / SiLU' are a quarter of the VALU work of the HTR and message backward passes.  Error ~3e-7
-// relative, against the path's 1e-4 tolerance; forward and backward use the same functions.
+// its 29 us), SiLU / SiLU' are a quarter of the VALU work of the HTR and message backward passes.  Error: the argument
+// x * log2(e) is rounded to fp32 BEFORE the exponential, so exp carries a relative error of ~6e-8 * |x| on top of the
+// 1-ulp instruction error: 3e-7 for |x| <= 4 (every sigmoid argument that matters: beyond, s is within 2e-2 of 0 / 1 and
+// the error of SiLU is relative to x), up to ~5e-6 at |x| = 80 (softmax arguments are <= 0 and that far down the weight
+// itself is e^-80).  Inside the path's 1e-4 tolerance by more than a decade everywhere; forward and backward use the same
+// functions.  A two-term split of x * log2(e) (hi / lo) would remove the |x| term if fp64-level agreement is ever wanted.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(1.44269504088896341f * x); }
 __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
 __device__ __forceinline__ float silu(float x) { return x * sigmoid_fast(x); }

@@ -7,7 +7,6 @@
 // loads, register accumulation, fixed-order LDS reduction across slots (no atomics).
 // Workgroup -> target mapping is XCD-aware (gn::xcd_item) so the source rows of one
 // molecule are re-read through a single XCD's L2.
-#include <cstdlib>
 #include "gn_common.h"
 #include "gn_tune.h"
 #include "gn_highl.h"
@@ -452,10 +451,9 @@ extern "C" int gn_attn_softmax(const float* q, const float* k, int ldqk, const f
         return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     const float inv_sqrt_f = (float)(1.0 / sqrt((double)F));
-    // one wave per target where a wave covers an edge row and the strip's head-per-lane map holds (GN_ATTN_WAVE=0: the
-    // workgroup-per-target kernel, for an A/B)
-    static const bool wave_off = getenv("GN_ATTN_WAVE") && atoi(getenv("GN_ATTN_WAVE")) == 0;
-    if (!wave_off && F <= 256 && H <= 64) {
+    // one wave per target where a wave covers an edge row and the strip's head-per-lane map holds (-DGN_ATTN_WAVE=0
+    // builds the workgroup-per-target kernel only, for an A/B: tools/variants.py)
+    if (GN_ATTN_WAVE && F <= 256 && H <= 64) {
         const dim3 grid(gn::xcd_grid((N + 3) / 4)), block(256);
         if (act == GN_ACT_SILU)
             hipLaunchKernelGGL(gn::attn_softmax_wave_kernel<true>, grid, block, 0, (hipStream_t)stream,
@@ -511,14 +509,16 @@ extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, co
                                     const float* a, const float* rl, const float* cut,
                                     const int* rowptr, const int* src,
                                     const float* h_in, const float* X_in, float* h_out, float* X_out,
-                                    int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream) {
-    if (!feature_dim_ok(F) || N < 0 || H <= 0 || lmax < 1 || lmax > 8 || (ldxv & 3) || (ldt & 3) || X_in == X_out)
+                                    int N, int F, int H, int lmax_arg, int sep_dir, int sep_tensor, void* stream) {
+    const int lmax = lmax_arg & 0xff;               // GN_LMAX_SLICED may ride in the argument (gn_use_highl)
+    if ((lmax_arg & ~(0xff | GN_LMAX_SLICED)) || !feature_dim_ok(F) || N < 0 || H <= 0 || lmax < 1 || lmax > 8 ||
+        (ldxv & 3) || (ldt & 3) || X_in == X_out)
         return GN_ERR_BAD_ARG;
-    if (!X_in && gn_use_highl(lmax)) return GN_ERR_BAD_ARG;   // the zero-X_in form: register-tiled kernels only (lmax <= 4)
+    if (!X_in && gn_use_highl(lmax_arg)) return GN_ERR_BAD_ARG;   // the zero-X_in form: register-tiled kernels only (lmax <= 4)
     const int M = 1 + (sep_dir ? lmax : 1) + (sep_tensor ? lmax : 1);
     if ((M * F) % H || ((M * F) / H) % 4) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
-    if (gn_use_highl(lmax))                            // degrees 5..8: one launch per degree (gn_highl.hip)
+    if (gn_use_highl(lmax_arg))                        // degrees 5..8: one launch per degree (gn_highl.hip)
         return gn_highl_message(x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in, h_out, X_out, N, F, H,
                                 lmax, sep_dir, sep_tensor, (hipStream_t)stream);
     const int key = lmax * 4 + (sep_dir ? 2 : 0) + (sep_tensor ? 1 : 0);
@@ -542,11 +542,13 @@ extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, co
 }
 
 extern "C" int gn_htr_edge(const float* EQ, const float* EK, const float* rl, const int* rowptr, const int* src,
-                           int N, int F, int lmax, int mode, float* w_raw, float* w, void* stream) {
-    if (!feature_dim_ok(F) || N < 0 || lmax < 1 || lmax > 8 || mode < 0 || mode > 15) return GN_ERR_BAD_ARG;
+                           int N, int F, int lmax_arg, int mode, float* w_raw, float* w, void* stream) {
+    const int lmax = lmax_arg & 0xff;
+    if ((lmax_arg & ~(0xff | GN_LMAX_SLICED)) || !feature_dim_ok(F) || N < 0 || lmax < 1 || lmax > 8 || mode < 0 || mode > 15)
+        return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (gn_use_highl(lmax)) return gn_highl_htr_edge(EQ, EK, rl, rowptr, src, N, F, lmax, mode, w_raw, w, st);
+    if (gn_use_highl(lmax_arg)) return gn_highl_htr_edge(EQ, EK, rl, rowptr, src, N, F, lmax, mode, w_raw, w, st);
     if (mode) return gn_htr_edge_general(EQ, EK, rl, rowptr, src, N, F, lmax, mode, w_raw, w, st);
     const dim3 grid(gn::xcd_grid(N)), block(256);
     switch (lmax) {

@@ -22,45 +22,19 @@
 //   1: A <- SiLU(A)                 (activations are stored pre-activation, consumers apply SiLU)
 //   2: A <- A * SiLU'(P)            (backward through an activation; P = stored pre-activation)
 //   and, for every column, A <- A * G when a_gate != NULL.
-#include <cstdlib>
 #include <type_traits>
 #include "gn_gemm.h"
+#include "gn_tune.h"
 
 #ifndef GN_SPLIT_LOOP
 #define GN_SPLIT_LOOP 2        // 2: branch-free A fetch two slabs ahead (exact s_waitcnt); 0: conditional loads
 #endif
-#ifndef GN_SPLIT_SKEW
-#define GN_SPLIT_SKEW 0        // > 0: workgroups start de-phased by up to this many kilocycles (epilogue store bursts)
-#endif
-#ifndef GN_SPLIT_NOSTORE
-#define GN_SPLIT_NOSTORE 0     // probe only: skip the global stores of the epilogue
-#endif
-#ifndef GN_SPLIT_ABL
-#define GN_SPLIT_ABL 0         // probe builds only (wrong results): 1 no weight loads, 2 one A fragment address, 4 no split/stash, 32 three of six MFMA terms,
-#endif                         // 8 no A fetch, 16 no barrier in the K loop -- what each part of the split main loop costs
 #ifndef GN_SPLIT_MINW
 #define GN_SPLIT_MINW 2        // minimum waves per SIMD of the split kernel (register cap 512 / n)
 #endif
-#ifndef GN_SPLIT_SCHED
-#define GN_SPLIT_SCHED 0       // > 0: sched_group_barrier pattern [1 MFMA, n VALU] in the split main loop (tools/variants.py)
-#endif
-
-#ifndef GN_SPLIT_TRACE
-#define GN_SPLIT_TRACE 0       // probe builds only: per-tile phase timestamps of the first workgroups (gn_debug_trace)
-#endif
-#if GN_SPLIT_TRACE
-__device__ long long gn_trace_buf[64 * 16 * 8];
-#define GN_TR(slot)                                                                              \
-    do {                                                                                         \
-        if (SPLIT && tid == 0 && blockIdx.x < 64 && tile_no < 16)                                \
-            gn_trace_buf[(blockIdx.x * 16 + tile_no) * 8 + (slot)] = __builtin_readcyclecounter(); \
-    } while (0)
-extern "C" int gn_debug_trace(long long* host_out) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(gn_trace_buf), sizeof(gn_trace_buf));
-}
-#else
-#define GN_TR(slot) do {} while (0)
-#endif
+// (The timing-probe paths of rounds 2-3 -- term / load / barrier ablations that produce wrong results, the no-store
+//  build, per-tile cycle stamps, start skew -- are gone from the product translation unit; what they measured is
+//  recorded in DESIGN.md 5.3 and profiles/r0[23]_*.)
 
 namespace gn {
 
@@ -380,20 +354,11 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
     // multiplied and is refilled with slab kt+1+PF right after it has been written to LDS
     int idx = blockIdx.x >> 3;
     if (idx >= tile_stop) return;
-#if GN_SPLIT_SKEW
-    if constexpr (SPLIT) {
-        const unsigned hsh = (blockIdx.x * 2654435761u) >> 22;                       // 0 .. 1023, uniform over the workgroups
-        const long long until = __builtin_readcyclecounter() + (long long)hsh * GN_SPLIT_SKEW;   // SKEW kilocycles ~ 1024 SKEW cycles max
-        while (__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(16);
-    }
-#endif
     select(idx);
     set_tile(idx);
     fetch(0, pa[0], pb[0]);
   // persistent over tiles: workgroup b walks the tiles base + b/8, base + b/8 + gridDim/8, ... of ITS XCD's range
-  int tile_no = 0;
-  for (;; ++tile_no) {
-    GN_TR(0);
+  for (;;) {
     const int nk = (p.K + BK - 1) / BK;
     const int m0 = ((idx - g_begin) / tiles_n) * BM;
     const int n0 = ((idx - g_begin) % tiles_n) * BN;
@@ -414,7 +379,6 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
         load_b(0, bq[0]);
     }
     __syncthreads();
-    GN_TR(1);
     const int khalf = (lane >> 5) * 16;
     const int frow = lane & 31;
     if constexpr (SPLIT) {
@@ -456,7 +420,7 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
             constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
             constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int t = (GN_SPLIT_ABL & 32) ? 3 : 0; t < 6; ++t)       // ablation 32: three of the six terms (timing probe)
+            for (int t = 0; t < 6; ++t)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -474,18 +438,18 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
             auto slab = [&](int kt, auto SET, auto LAST) {
                 constexpr int set = decltype(SET)::value;            // register set of slab kt (= kt & 1)
                 constexpr bool last = decltype(LAST)::value;
-                const __bf16* Ap = Abase + ((GN_SPLIT_ABL & 2) ? 0 : set * STAGE_S);
-                if (!(GN_SPLIT_ABL & 1)) load_b(2 * kt + 1, bq[1]);
-                if constexpr (!last) { if (!(GN_SPLIT_ABL & 8)) fetchA((kt + 2) * BK, qa2[set], kok2[set]); }   // slab kt + 2 -> the set slab kt came from
+                const __bf16* Ap = Abase + set * STAGE_S;
+                load_b(2 * kt + 1, bq[1]);
+                if constexpr (!last) fetchA((kt + 2) * BK, qa2[set], kok2[set]);   // slab kt + 2 -> the set slab kt came from
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (F16) rescale(set);
                 kstep(Ap, 0, bq[0]);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!last) { if (!(GN_SPLIT_ABL & 1)) load_b(2 * kt + 2, bq[0]); }
-                kstep(Ap, (GN_SPLIT_ABL & 2) ? 0 : 1, bq[(GN_SPLIT_ABL & 1) ? 0 : 1]);
+                if constexpr (!last) load_b(2 * kt + 2, bq[0]);
+                kstep(Ap, 1, bq[1]);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!last) { if (!(GN_SPLIT_ABL & 4)) stashA(set ^ 1, qa2[set ^ 1], kok2[set ^ 1]); }  // slab kt + 1 -> the other LDS buffer
-                if (!(GN_SPLIT_ABL & 16) || last) __syncthreads();
+                if constexpr (!last) stashA(set ^ 1, qa2[set ^ 1], kok2[set ^ 1]);  // slab kt + 1 -> the other LDS buffer
+                __syncthreads();
             };
             using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>;
             using No = std::false_type; using Yes = std::true_type;
@@ -571,7 +535,6 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
         fetch(0, pa[0], pb[0]);
     }
 
-    GN_TR(2);
     // (An epilogue straight from the accumulators -- a lane owns one column of each 32 x 32 tile, so a store instruction
     // would write two full 128-byte row segments with no LDS round trip -- measured 2x SLOWER per tile: 64 dword stores
     // per lane instead of 16 dwordx4; tools/gemm_trace.py.)
@@ -590,7 +553,6 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
                 smem[row * CP + wn * 32 * TN + j * 32 + (lane & 31)] = v;
             }
     __syncthreads();
-    GN_TR(3);
     {
         constexpr int C4 = BN / 4;                  // 256 % C4 == 0: a thread keeps ONE column group
         const int cc = (tid % C4) * 4, gn = n0 + cc;
@@ -636,19 +598,13 @@ __device__ __forceinline__ void gemm_body(const GroupArgs ga) {
                     const size_t off = (size_t)phys_row(p, gm) * p.ldc + gn;
                     if (p.pre_out) st4(p.pre_out + off, v);
                     if (act) v = act4(v, ASILU ? (int)GN_ACT_SILU : p.act_kind);
-#if GN_SPLIT_NOSTORE
-                    if (v.x == 123456.f) st4(p.C + off, v);
-#else
                     if (gn >= p.nt_store) st4_nt(p.C + off, v); else st4(p.C + off, v);
-#endif
                 }
             }
         }
     }
-    GN_TR(4);
     __syncthreads();                                // LDS is reused by the next tile's first slab
     }
-    GN_TR(5);
     if (!has_next) break;
     if (!same) {                                    // first tile of the next problem
         select(next);
@@ -765,22 +721,22 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
         small += (long)((g[i].M + 63) / 64) * ((g[i].N + 63) / 64);
         pro = pro || g[i].pro_mode != 0 || g[i].a_gate != nullptr;
     }
-    // 128x128 tiles from 900 tiles up (measured switch-over, GN_GEMM_BIG_MIN overrides for a sweep): the [E x 256 x K]
-    // products (850 tiles = 1.66 rounds on 512 resident workgroups) run 4-20 % faster as 3400 64x64 tiles, the
-    // [E x 1536 x 256] product (5100 tiles) and the four-problem X group (1008) want the big tile
-    static const long big_min = getenv("GN_GEMM_BIG_MIN") ? atol(getenv("GN_GEMM_BIG_MIN")) : 900;
-    const bool use_big = big >= big_min;
+    // 128x128 tiles from GN_GEMM_BIG_MIN = 900 tiles up (measured switch-over; a build-time constant of gn_tune.h, swept
+    // with tools/variants.py): the [E x 256 x K] products (850 tiles = 1.66 rounds on 512 resident workgroups) run
+    // 4-20 % faster as 3400 64x64 tiles, the [E x 1536 x 256] product (5100 tiles) and the four-problem X group (1008)
+    // want the big tile
+    const bool use_big = big >= (long)GN_GEMM_BIG_MIN;
     long end = 0;
     // outputs of 100 MB and more (the [E, (1+M)F] edge projection) are stored non-temporally: they are consumed by
-    // later kernels from HBM anyway and would only evict the node tables (K6 +5 %); GN_GEMM_NT_MB overrides
-    static const double nt_min = (getenv("GN_GEMM_NT_MB") ? atof(getenv("GN_GEMM_NT_MB")) : 100.0) * 1048576.0;
+    // later kernels from HBM anyway and would only evict the node tables (K6 +5 %); GN_GEMM_NT_MB (gn_tune.h)
+    const double nt_min = (double)GN_GEMM_NT_MB * 1048576.0;
     for (int i = 0; i < gn::GN_MAX_GROUP; ++i) {
         ga.g[i] = g[i < n ? i : n - 1];
         // (nt_store = first column written non-temporally.  The first K columns of a large output stay on the normal
         //  path: for the edge projection [W_re | W_rs] that is the attention block, which the segment softmax re-reads
-        //  right away -- measured 23.3 -> 20.6 us for it at C2, the message kernel unchanged; GN_GEMM_NT_LO overrides)
-        static const int nt_lo_env = getenv("GN_GEMM_NT_LO") ? atoi(getenv("GN_GEMM_NT_LO")) : -1;
-        const int nt_lo = nt_lo_env >= 0 ? nt_lo_env : ga.g[i].K;
+        //  right away -- measured 23.3 -> 20.6 us for it at C2, the message kernel unchanged; GN_GEMM_NT_LO >= 0 (gn_tune.h)
+        //  fixes the column instead)
+        const int nt_lo = GN_GEMM_NT_LO >= 0 ? GN_GEMM_NT_LO : ga.g[i].K;
         ga.g[i].nt_store = (double)ga.g[i].M * ga.g[i].N * 4.0 >= nt_min ? (ga.g[i].N > nt_lo ? nt_lo : 0) : 0x7fffffff;
         if (i < n) end += use_big ? (long)((g[i].M + BMB - 1) / BMB) * ((g[i].N + BNB - 1) / BNB)
                                   : (long)((g[i].M + 63) / 64) * ((g[i].N + 63) / 64);

@@ -69,8 +69,10 @@ __device__ __forceinline__ float4 dgate4(float4 v, int k) { return make_float4(d
 
 }  // namespace gn
 
-// lmax > 4 (or GN_FORCE_HIGHL=1, a test switch: the degree-sliced kernels at lmax <= 4 against the tuned ones)
-bool gn_use_highl(int lmax);
+// lmax > 4, or the caller OR-ed GN_LMAX_SLICED into the lmax ARGUMENT of the entry point (an explicit per-call request
+// for the degree-sliced kernel family at lmax <= 4: the tests hold the two families against each other).  No
+// process-wide switch: the choice travels with the call.
+bool gn_use_highl(int lmax_arg);
 int gn_highl_message(const float* x, const float* v, int ldxv, const float* t_filter, int ldt, const float* a,
                      const float* rl, const float* cut, const int* rowptr, const int* src, const float* h_in,
                      const float* X_in, float* h_out, float* X_out, int N, int F, int H, int lmax, int sep_dir,

@@ -416,10 +416,7 @@ __global__ __launch_bounds__(256) void hl_htr_bwd_source_kernel(
 }  // namespace gn
 
 // ====================================================================================== launchers
-bool gn_use_highl(int lmax) {
-    static const bool forced = [] { const char* e = getenv("GN_FORCE_HIGHL"); return e && e[0] == '1'; }();
-    return lmax > 4 || forced;
-}
+bool gn_use_highl(int lmax_arg) { return (lmax_arg & 0xff) > 4 || (lmax_arg & GN_LMAX_SLICED) != 0; }
 
 // KERNEL<L> for L = 1..lmax (lmax <= 8), one launch per degree
 #define GN_HL_PER_DEGREE(KERNEL, ...)                                                                 \

@@ -64,6 +64,21 @@
                            // the softmax-backward barriers (0: none)
 #endif
 
+// ---- launcher constants (formerly environment variables read inside the extern "C" entry points: the ABI promises
+// no hidden process state, so they are build-time constants now; tools/variants.py builds a library per value)
+#ifndef GN_GEMM_BIG_MIN
+#define GN_GEMM_BIG_MIN 900    // 128 x 128 projection tiles from this many tiles up (below: 64 x 64)
+#endif
+#ifndef GN_GEMM_NT_MB
+#define GN_GEMM_NT_MB 100.0    // outputs of this many MiB and more are stored non-temporally ...
+#endif
+#ifndef GN_GEMM_NT_LO
+#define GN_GEMM_NT_LO (-1)     // ... from this column on (-1: the first K columns stay on the normal path)
+#endif
+#ifndef GN_ATTN_WAVE
+#define GN_ATTN_WAVE 1         // 1: one wave per target in gn_attn_softmax where the shape allows; 0: workgroup per target
+#endif
+
 #define GN_TUNE_CAT_(a, b) a##b
 #define GN_TUNE_CAT(a, b) GN_TUNE_CAT_(a, b)
 #define GN_WPE_SEL_0

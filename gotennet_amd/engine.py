@@ -44,6 +44,9 @@ class LayerWeights:
     t_ln_w: Optional[torch.Tensor] = None; t_ln_b: Optional[torch.Tensor] = None   # its LayerNorm (edge_ln)
     Wedp: Optional[torch.Tensor] = None; bedp: Optional[torch.Tensor] = None   # W_edp
     w_ln_w: Optional[torch.Tensor] = None; w_ln_b: Optional[torch.Tensor] = None   # LayerNorm before / after W_edp
+    # prefixes for the first interaction (X_in = 0: no tensor-gate blocks), views made on first use
+    We0: Optional[torch.Tensor] = None; be0: Optional[torch.Tensor] = None
+    Ws20: Optional[torch.Tensor] = None; Wv20: Optional[torch.Tensor] = None
     T: dict = field(default_factory=dict)         # lazily built transposes for the backward
 
 
@@ -58,10 +61,6 @@ class PackedWeights:
     T: dict = field(default_factory=dict)
 
 
-#: GN_FORCE_HIGHL=1 (test switch, read once per process like the library does): no zero-X_in kernels on that path
-_FORCE_HIGHL = os.environ.get("GN_FORCE_HIGHL", "")[:1] == "1"
-
-
 #: A/B and test switch: False runs the first interaction through the general kernels on the zero tensor
 ZERO_X_FIRST = os.environ.get("GN_ZERO_X_FIRST", "1") != "0"
 
@@ -70,13 +69,13 @@ def zero_X_in(cfg: "Config", li: int) -> bool:
     """Layer ``li`` of ``forward`` sees the all-zero X that forward itself creates (gotennet.py:992) and the kernels have
     the zero-X_in form (register-tiled SiLU kernels, lmax <= 4): every tensor-gate term of that layer is 0 * gate, so its
     blocks of the edge projection are neither computed nor read, and nothing consumes the gradient w.r.t. X_in."""
-    return ZERO_X_FIRST and li == 0 and cfg.lmax <= 4 and cfg.act == 0 and not cfg.steerable_norm and not _FORCE_HIGHL
+    return ZERO_X_FIRST and li == 0 and cfg.lmax <= 4 and cfg.act == 0 and not cfg.steerable_norm and not cfg.sliced
 
 
 def _We_first(cfg: "Config", lw) -> Tuple[torch.Tensor, torch.Tensor, int]:
     """Rows of [W_re; W_rs] without the tensor-gate blocks (a prefix: attention, scalar, direction gates)."""
     n0 = (2 + (cfg.lmax if cfg.sep_dir else 1)) * cfg.F
-    if getattr(lw, "We0", None) is None:
+    if lw.We0 is None:
         lw.We0, lw.be0 = lw.We[:n0], (lw.be[:n0] if lw.be is not None else None)
     return lw.We0, lw.be0, n0
 
@@ -84,7 +83,7 @@ def _We_first(cfg: "Config", lw) -> Tuple[torch.Tensor, torch.Tensor, int]:
 def _value_first(cfg: "Config", lw) -> int:
     """Rows of gamma_s.1 / gamma_v.1 without the tensor-gate blocks (a prefix: scalar, direction gates)."""
     n0 = (1 + (cfg.lmax if cfg.sep_dir else 1)) * cfg.F
-    if getattr(lw, "Ws20", None) is None:
+    if lw.Ws20 is None:
         lw.Ws20, lw.Wv20 = lw.Ws2[:n0], lw.Wv2[:n0]
     return n0
 
@@ -133,6 +132,8 @@ class Config:
     act: int = 0              # GN_ACT_* kind of the ``activation`` argument (0 = SiLU / swish, the reference default)
     evec: int = 0             # evec_dim: width of EQ / EK / w (0 = F; != F needs W_edp to map back to F)
     emlp: int = 0             # emlp_dim: hidden width of the 2-layer gamma_t (0 = F)
+    gemm_mode: str = ""       # projection arithmetic of THIS model ("f16x2" | "split" | "f32"; "" = engine.GEMM_MODE, the default)
+    sliced: bool = False      # run lmax <= 4 on the degree-sliced kernel family too (GN_LMAX_SLICED in the lmax argument)
 
     @property
     def Fe(self) -> int:
@@ -146,12 +147,20 @@ class Config:
     def D(self) -> int:
         return (self.lmax + 1) ** 2 - 1
 
+    @property
+    def lmax_arg(self) -> int:
+        """The ``lmax`` argument of the message / HTR entry points: GN_LMAX_SLICED rides in it."""
+        return self.lmax | (_lib.LMAX_SLICED if self.sliced else 0)
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-#: projection arithmetic (env GN_GEMM_MODE overrides; every GPU parity test runs in all three):
+#: DEFAULT projection arithmetic of a model that does not choose one (``GotenNet.gemm_mode = None``; env GN_GEMM_MODE
+#: sets the default at import; every GPU parity test runs in all three).  The arithmetic and the activation kind of a
+#: call are carried by ``Config`` (``cfg.gemm_mode``, ``cfg.act``) and bound per call by ``_Proj`` -- there is no
+#: per-call module state, so two models with different arithmetics can run from two threads.
 #:   "f16x2" (default) -- every fp32 operand as two fp16 planes scaled by block exponents (A: per staging wave and
 #:       32-column K-slab = 16 or 32 neighbouring rows of the workgroup tile, running maximum, accumulators rescaled when
 #:       it grows; W: per tensor), THREE fp16 MFMAs per product, fp32 accumulate: <= 3e-7 of the output's max-norm vs an
@@ -161,6 +170,7 @@ def _stream() -> int:
 #:       batch layout (bit-exact batch independence), 14 % slower on the C2 step.
 #:   "f32"   -- exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain), 40 % slower.
 GEMM_MODE = os.environ.get("GN_GEMM_MODE", "f16x2")
+MODES = ("f16x2", "split", "f32")
 
 
 #: projection arithmetic -> (single-product entry point, grouped entry point, weight packer, its size query, dtype)
@@ -168,15 +178,23 @@ _PLANE_MODES = {"split": ("gn_gemm_split", "gn_gemm_group_split", "gn_split_bf16
                 "f16x2": ("gn_gemm_f16x2", "gn_gemm_group_f16x2", "gn_split_f16x2", "gn_split_f16x2_size", torch.float16)}
 
 
-def split_weight(W: torch.Tensor) -> torch.Tensor:
-    """Operand planes of a weight [N, K] for the current GEMM_MODE in MFMA-fragment-major order (gn_split_bf16x3: bf16
+def resolve_mode(mode: Optional[str]) -> str:
+    mode = mode or GEMM_MODE
+    if mode not in MODES:
+        raise ValueError(f"projection arithmetic {mode!r}: one of {MODES}")
+    return mode
+
+
+def split_weight(W: torch.Tensor, mode: Optional[str] = None) -> torch.Tensor:
+    """Operand planes of a weight [N, K] for the arithmetic ``mode`` in MFMA-fragment-major order (gn_split_bf16x3: bf16
     hi/mid/lo; gn_split_f16x2: header + fp16 hi/lo), cached ON the tensor object per mode (the packed weights are
     long-lived; GotenNet.invalidate_packed() drops them with the pack)."""
-    key = "_gn_split_" + GEMM_MODE
+    mode = resolve_mode(mode)
+    key = "_gn_split_" + mode
     cached = getattr(W, key, None)
     if cached is not None and cached[0] == W._version and cached[1] == W.data_ptr():
         return cached[2]
-    _, _, packer, sizer, dt = _PLANE_MODES[GEMM_MODE]
+    _, _, packer, sizer, dt = _PLANE_MODES[mode]
     N, K = W.shape
     planes = torch.empty(getattr(_lib.load(), sizer)(N, K), dtype=dt, device=W.device)
     call(packer, ptr(W.contiguous()), N, K, ptr(planes), _stream())
@@ -186,24 +204,28 @@ def split_weight(W: torch.Tensor) -> torch.Tensor:
 
 def gemm(A, lda, W, bias, C, ldc, rows, nout, K, act=(0, 0), rowmap=(1, 1, 0), res=None, gate=None,
          a_off=0, c_off=0, pre_out=None, pro=(0, 0, 0), a_pre=None, ldp=0, p_off=0, a_gate=None, ldg=0,
-         dgate=None, g_off=0, kind=None):
-    """C = epi(pro(A) W^T + bias); ``kind``: GN_ACT_* of the activated columns / SiLU' gates / prologues.  ``a_off`` / ``c_off`` / ``p_off`` / ``g_off``: float offsets of the first
-    column.  ``dgate``: multiply the output by SiLU'(dgate) (same addressing as C)."""
+         dgate=None, g_off=0, kind=None, mode=None):
+    """C = epi(pro(A) W^T + bias); ``kind``: GN_ACT_* of the activated columns / SiLU' gates / prologues (None = SiLU);
+    ``mode``: projection arithmetic (None = the module default).  ``a_off`` / ``c_off`` / ``p_off`` / ``g_off``: float
+    offsets of the first column.  ``dgate``: multiply the output by SiLU'(dgate) (same addressing as C)."""
+    mode = resolve_mode(mode)
     name = "gn_gemm_ex"
-    if GEMM_MODE in _PLANE_MODES:
-        name, W = _PLANE_MODES[GEMM_MODE][0], split_weight(W)
+    if mode in _PLANE_MODES:
+        name, W = _PLANE_MODES[mode][0], split_weight(W, mode)
     call(name, A.data_ptr() + 4 * a_off, lda, ptr(W), ptr(bias), C.data_ptr() + 4 * c_off, ldc,
          rows, nout, K, act[0], act[1], rowmap[0], rowmap[1], rowmap[2], ptr(res),
          (dgate.data_ptr() + 4 * g_off) if dgate is not None else ptr(gate), 1 if dgate is not None else 0, ptr(pre_out),
          pro[0], pro[1], pro[2], (a_pre.data_ptr() + 4 * p_off) if a_pre is not None else None, ldp,
-         ptr(a_gate), ldg, ACT if kind is None else kind, _stream())
+         ptr(a_gate), ldg, 0 if kind is None else kind, _stream())
 
 
-def gemm_group(problems):
+def gemm_group(problems, mode=None, kind=None):
     """Several INDEPENDENT ``gemm(...)`` calls (a list of argument dicts) as ONE launch (gn_gemm_group, or
-    gn_gemm_group_split with the weights replaced by their cached bf16 planes)."""
+    gn_gemm_group_split / _f16x2 with the weights replaced by their cached planes)."""
+    mode = resolve_mode(mode)
+    kind = 0 if kind is None else kind
     problems = [q for q in problems if q is not None]
-    split = GEMM_MODE in _PLANE_MODES
+    split = mode in _PLANE_MODES
     for i0 in range(0, len(problems), 4):
         chunk = problems[i0:i0 + 4]
         arr = (_lib.GemmDesc * len(chunk))()
@@ -212,7 +234,7 @@ def gemm_group(problems):
             act, rowmap, pro = g("act", (0, 0)), g("rowmap", (1, 1, 0)), g("pro", (0, 0, 0))
             dgate = g("dgate")
             d.A = q["A"].data_ptr() + 4 * g("a_off", 0); d.lda = q["lda"]
-            d.W = ptr(split_weight(q["W"]) if split else q["W"]); d.bias = ptr(g("bias"))
+            d.W = ptr(split_weight(q["W"], mode) if split else q["W"]); d.bias = ptr(g("bias"))
             d.C = q["C"].data_ptr() + 4 * g("c_off", 0); d.ldc = q["ldc"]
             d.M, d.N, d.K = q["rows"], q["nout"], q["K"]
             d.act_lo, d.act_hi = act
@@ -227,26 +249,24 @@ def gemm_group(problems):
             d.ldp = g("ldp", 0)
             d.a_gate = ptr(g("a_gate")); d.ldg = g("ldg", 0)
             d.A2, d.A3, d.a_seg = ptr(g("A2")), ptr(g("A3")), g("a_seg", 0)
-            d.act_kind = g("kind", ACT)
-        call(_PLANE_MODES[GEMM_MODE][1] if split else "gn_gemm_group", arr, len(chunk), _stream())
+            d.act_kind = g("kind", kind)
+        call(_PLANE_MODES[mode][1] if split else "gn_gemm_group", arr, len(chunk), _stream())
 
 
-#: GN_ACT_* kind the grouped GEMM descriptors default to: set by ``forward`` / ``backward`` / ``gata_layer`` / ``eqff_layer``
-#: from ``cfg.act`` for the duration of the call (one model's activation applies to every projection of its step)
-ACT = 0
+class _Proj:
+    """The projection launchers bound to ONE model's arithmetic and activation kind (``cfg.gemm_mode``, ``cfg.act``)."""
+    __slots__ = ("mode", "act")
 
+    def __init__(self, cfg: "Config"):
+        self.mode, self.act = resolve_mode(cfg.gemm_mode), cfg.act
 
-class _act_scope:
-    def __init__(self, kind):
-        self.kind = kind
+    def gemm(self, *args, **kw):
+        kw.setdefault("kind", self.act)
+        kw.setdefault("mode", self.mode)
+        return gemm(*args, **kw)
 
-    def __enter__(self):
-        global ACT
-        self.old, ACT = ACT, self.kind
-
-    def __exit__(self, *exc):
-        global ACT
-        ACT = self.old
+    def group(self, problems):
+        return gemm_group(problems, mode=self.mode, kind=self.act)
 
 
 def validate_edges(edge_index: torch.Tensor, n_atoms: int) -> int:
@@ -354,6 +374,8 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
     F_, R, H, D, M, lmax = cfg.F, cfg.R, cfg.H, cfg.D, cfg.M, cfg.lmax
     Fe = cfg.Fe
     N, E = g.N, g.E
+    proj = _Proj(cfg)
+    gemm, gemm_group = proj.gemm, proj.group
     dev = z32.device
     f32 = dict(dtype=torch.float32, device=dev)
     new = lambda *shape: torch.empty(shape, **f32)
@@ -450,7 +472,7 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
         m0 = dict(A=ctx, lda=2 * F_, W=lw.Wm0, bias=lw.bm0, C=g1act, ldc=F_, rows=N, nout=F_, K=2 * F_, act=(0, F_),
                   pre_out=pre_g1 if save else None)
         if not last:
-            call("gn_htr_edge", ptr(EQ), ptr(EK), ptr(g.rl), ptr(g.rowptr), ptr(g.src), N, Fe, lmax, cfg.htr_mode,
+            call("gn_htr_edge", ptr(EQ), ptr(EK), ptr(g.rl), ptr(g.rowptr), ptr(g.src), N, Fe, cfg.lmax_arg, cfg.htr_mode,
                  ptr(lt.w_raw) if save else None, ptr(w), _stream())
             if cfg.composed_update:
                 upd = _edge_update_composed(cfg, lw, t, w, t2, E, lt.pre_t if save else None)
@@ -490,6 +512,8 @@ def _gata_layer_impl(cfg: Config, lw: LayerWeights, g: "Graph", h: torch.Tensor,
     launches into the grouped GEMMs).  ``g`` carries the CSR view, rl and the cosine cutoff.  -> (h', X', t')."""
     F_, H, D, M, lmax, Fe = cfg.F, cfg.H, cfg.D, cfg.M, cfg.lmax, cfg.Fe
     N, E = g.N, g.E
+    proj = _Proj(cfg)
+    gemm, gemm_group = proj.gemm, proj.group
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=h.device)
     last = lw.Wt is None
     if cfg.layernorm:
@@ -525,7 +549,7 @@ def _gata_layer_impl(cfg: Config, lw: LayerWeights, g: "Graph", h: torch.Tensor,
                                rowmap=(cnt, D, off)))
             off += cnt
     gemm_group(xprods)
-    call("gn_htr_edge", ptr(EQ), ptr(EK), ptr(g.rl), ptr(g.rowptr), ptr(g.src), N, Fe, lmax, cfg.htr_mode, None, ptr(w),
+    call("gn_htr_edge", ptr(EQ), ptr(EK), ptr(g.rl), ptr(g.rowptr), ptr(g.src), N, Fe, cfg.lmax_arg, cfg.htr_mode, None, ptr(w),
          _stream())
     if cfg.composed_update:
         _edge_update_composed(cfg, lw, t, w, t2, E, None)
@@ -539,6 +563,7 @@ def _eqff_layer_impl(cfg: Config, lw: LayerWeights, h: torch.Tensor, X: torch.Te
     Returns NEW tensors (h', X')."""
     F_, D = cfg.F, cfg.D
     N = h.shape[0]
+    gemm = _Proj(cfg).gemm
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=h.device)
     Xp, ctx, g1, mm = new(N, D, F_), new(N, 2 * F_), new(N, F_), new(N, 2 * F_)
     gemm(X, F_, lw.Wvu, None, Xp, F_, N * D, F_, F_)
@@ -560,7 +585,7 @@ def message_stage(cfg: Config, g: "Graph", nact, xs, vs, eproj, attn, h, X, h2, 
          ptr(g.rowptr), ptr(g.src), ptr(g.outdeg), g.N, F_, H, ptr(attn), cfg.act, _stream())
     call("gn_message_aggregate", ptr(xs), ptr(vs), M * F_, eproj.data_ptr() + 4 * F_, lde,
          ptr(attn), ptr(g.rl), ptr(g.cut), ptr(g.rowptr), ptr(g.src),
-         ptr(h), ptr(X), ptr(h2), ptr(X2), g.N, F_, H, cfg.lmax, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
+         ptr(h), ptr(X), ptr(h2), ptr(X2), g.N, F_, H, cfg.lmax_arg, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
 
 
 def _edge_update_composed(cfg: Config, lw: LayerWeights, t, w_raw, t2, E: int, pre_t):
@@ -569,6 +594,7 @@ def _edge_update_composed(cfg: Config, lw: LayerWeights, t, w_raw, t2, E: int, p
     gamma_t = Dense -> [LayerNorm edge_ln] -> SiLU -> Dense [-> SiLU unless "mlp"]  ("mlp"/"mlpa"), or the
     default SiLU(Dense).  Returns the intermediates the backward needs."""
     F_, Fe, Fm = cfg.F, cfg.Fe, cfg.Fm
+    gemm = _Proj(cfg).gemm
     new = lambda width=F_: torch.empty((E, width), dtype=torch.float32, device=t.device)
     st = _stream()
     u = dict(w_raw=w_raw)
@@ -610,6 +636,7 @@ def _edge_update_composed(cfg: Config, lw: LayerWeights, t, w_raw, t2, E: int, p
 def _edge_update_composed_backward(cfg: Config, lw: LayerWeights, lt, gt, gt_a, E: int):
     """Input-gradients of _edge_update_composed: writes gt_a = gt + (d/dt through gamma_t) and returns dL/dw [E,F]."""
     F_, Fe, Fm = cfg.F, cfg.Fe, cfg.Fm
+    gemm = _Proj(cfg).gemm
     new = lambda width=F_: torch.empty((E, width), dtype=torch.float32, device=gt.device)
     st = _stream()
     u = lt.upd
@@ -652,6 +679,8 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
     F_, R, H, D, M, lmax = cfg.F, cfg.R, cfg.H, cfg.D, cfg.M, cfg.lmax
     Fe = cfg.Fe
     N, E = g.N, g.E
+    proj = _Proj(cfg)
+    gemm, gemm_group = proj.gemm, proj.group
     f32 = dict(dtype=torch.float32, device=z32.device)
     new = lambda *shape: torch.empty(shape, **f32)
     colptr, perm = g.csc()
@@ -659,7 +688,7 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
 
     # every contributing kernel writes its own slice; the geometry backward sums them in a fixed order
     L = len(pw.layers)
-    G = _lib.load().gn_message_backward_groups(lmax, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act)
+    G = _lib.load().gn_message_backward_groups(cfg.lmax_arg, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act)
     n_rl, n_cut = L + sum(lw.Wt is not None for lw in pw.layers), G * L + 1
     g_rl_parts, g_cut_parts = new(n_rl, E, D), new(n_cut, E)
     ga_parts = new(G, E, H) if G > 1 else None
@@ -691,12 +720,12 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
             if cfg.composed_update:                # gt_a = gt + gamma_t backward; g_w = gamma_w backward
                 g_w = _edge_update_composed_backward(cfg, lw, lt, gt, gt_a, E)
                 call("gn_htr_backward", ptr(g_w), None, None, None, ptr(lt.EQ), ptr(lt.EK), ptr(g.rl),
-                     ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm), N, Fe, lmax, cfg.htr_mode | 16,
+                     ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm), N, Fe, cfg.lmax_arg, cfg.htr_mode | 16,
                      ptr(gEQ), ptr(gEK), rl_slice(L + li), None, cfg.act, _stream())
                 gemm_group([m1])
             else:
                 call("gn_htr_backward", ptr(gt), ptr(lt.pre_t), ptr(lt.w), ptr(lt.w_raw), ptr(lt.EQ), ptr(lt.EK),
-                     ptr(g.rl), ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm), N, Fe, lmax,
+                     ptr(g.rl), ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm), N, Fe, cfg.lmax_arg,
                      cfg.htr_mode, ptr(gEQ), ptr(gEK), rl_slice(L + li), ptr(g_pre_t), cfg.act, _stream())
                 # gt_a = gt + ((gt * w) * SiLU'(pre_t)) Wt; the atom-sized gamma_m product rides in its launch
                 gemm_group([dict(A=g_pre_t, lda=F_, W=_T(lw, "Wt"), C=gt_a, ldc=F_, rows=E, nout=F_, K=F_, res=gt), m1])
@@ -749,11 +778,12 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
              ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), None if first else ptr(gX2),
              rl_slice(li), cut_slice(G * li),
              ptr(ga_parts), E,
-             N, F_, H, lmax, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act, _stream())
+             N, F_, H, cfg.lmax_arg, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act, _stream())
         # the edge-sized W_e^T product leaves 0.7 of its last tile round idle: the two K-heavy atom-sized products
         # (g_x W_s2, g_v W_v2; 60 us as a launch of their own) ride there; W_n1^T needs their output and follows alone
         if first:                                  # the tensor-gate columns of g_eproj were not written: K-prefix
             _, _, ke = _We_first(cfg, lw)
+            _value_first(cfg, lw)                  # (Ws20 / Wv20 exist before the group below names them)
         gemm_group([dict(A=g_eproj, lda=lde, W=_T(lw, "We0" if first else "We"), C=gt_b, ldc=F_, rows=E, nout=F_,
                          K=ke if first else lde, res=gt_in),
                     dict(A=g_x, lda=M * F_, W=_T(lw, "Ws20" if first else "Ws2"), C=g_nproj, ldc=4 * F_, rows=N, nout=F_,
@@ -809,16 +839,4 @@ def pos_gradient(g: Graph, g_vec: torch.Tensor, g_diff: torch.Tensor, sign: floa
     return out
 
 
-def _scoped(impl):
-    def run(cfg, *args, **kwargs):
-        with _act_scope(cfg.act):                   # cfg.act: the GN_ACT_* kind every projection of this call uses
-            return impl(cfg, *args, **kwargs)
-    run.__doc__ = impl.__doc__
-    run.__name__ = impl.__name__.strip("_").replace("_impl", "")
-    return run
-
-
-forward = _scoped(_forward_impl)
-backward = _scoped(_backward_impl)
-gata_layer = _scoped(_gata_layer_impl)
-eqff_layer = _scoped(_eqff_layer_impl)
+forward, backward, gata_layer, eqff_layer = _forward_impl, _backward_impl, _gata_layer_impl, _eqff_layer_impl

@@ -244,7 +244,8 @@ class GATA(_LayerPackCache, nn.Module):
                              composed_update=self.composed_update, gate_kind=self.gate_kind,
                              t_last_act=0 if self.update_info["mlp"] else 3, lin_w=self.update_info["lin_w"],
                              lin_ln=self.update_info["lin_ln"], evec=self.edge_vec_dim, emlp=self.edge_mlp_dim,
-                             act=self.act_kind)
+                             act=self.act_kind, gemm_mode=engine.resolve_mode(getattr(self, "gemm_mode", None)),
+                             sliced=bool(getattr(self, "sliced_kernels", False)))
 
     @torch.no_grad()
     def forward(self, edge_index: Tensor, h: Tensor, X: Tensor, rl_ij: Tensor, t_ij: Tensor, r_ij: Tensor,
@@ -269,17 +270,17 @@ class GATA(_LayerPackCache, nn.Module):
         if E == 0:                                   # no messages, no edge update: only the input norms act (gotennet.py:397-398)
             ho, Xo = engine.gata_input_norms(cfg, lw, h2, X2)
             return ho.clone().reshape(hs) if ho is h2 else ho.reshape(hs), Xo.clone() if Xo is X2 else Xo, t_ij.clone()
-        if n_edges is not None and self.scale_edge:
-            deg = torch.zeros(N, dtype=torch.float32, device=h.device).index_add_(
-                0, edge_index[0], torch.ones(E, dtype=torch.float32, device=h.device))
-            if not bool(torch.equal(n_edges.reshape(-1).to(torch.float32), deg[edge_index[0]])):
-                raise ValueError("GATA.forward: n_edges differs from the out-degree of each edge's source "
-                                 "(gotennet.py:986-989); the accelerated path implements that normalisation only")
         order = None
         if E:
             bits = engine.validate_edges(edge_index, N)
             if bits & 2:
                 raise ValueError(f"edge_index holds indices outside [0, {N})")
+            if n_edges is not None and self.scale_edge:      # (after the range check: the gather below indexes with edge_index)
+                deg = torch.zeros(N, dtype=torch.float32, device=h.device).index_add_(
+                    0, edge_index[0], torch.ones(E, dtype=torch.float32, device=h.device))
+                if not bool(torch.equal(n_edges.reshape(-1).to(torch.float32), deg[edge_index[0]])):
+                    raise ValueError("GATA.forward: n_edges differs from the out-degree of each edge's source "
+                                     "(gotennet.py:986-989); the accelerated path implements that normalisation only")
             if bits & 1:
                 order = torch.sort(edge_index[1], stable=True).indices
                 edge_index, rl, r, t2 = edge_index[:, order].contiguous(), rl[order].contiguous(), r[order].contiguous(), \
@@ -339,7 +340,8 @@ class EQFF(_LayerPackCache, nn.Module):
         N, F_ = h.shape[0], self.n_atom_basis
         D = (self.lmax + 1) ** 2 - 1
         cfg = engine.Config(F=F_, L=1, R=0, H=1, lmax=self.lmax, M=1, cutoff=0.0, eps=float(self.epsilon),
-                            scale_edge=False, sep_dir=False, sep_tensor=False, act=self.act_kind)
+                            scale_edge=False, sep_dir=False, sep_tensor=False, act=self.act_kind,
+                            gemm_mode=engine.resolve_mode(getattr(self, "gemm_mode", None)))
         lw = self._layer_pack(_pack_eqff)
         ho, Xo = engine.eqff_layer(cfg, lw, h.reshape(N, F_).to(torch.float32).contiguous(),
                                    X.to(torch.float32).contiguous())
@@ -405,6 +407,12 @@ class GotenNet(nn.Module):
         #: set True when the caller guarantees ``edge_index[1]`` is non-decreasing (what
         #: radius_graph emits); skips the device->host sortedness check (one sync).
         self.assume_sorted_edges = False
+        #: projection arithmetic of THIS model: None = ``engine.GEMM_MODE`` (the process default), or "f16x2" / "split" /
+        #: "f32" (engine.py).  Carried in ``config()``: two models with different arithmetics may run from two threads.
+        self.gemm_mode: Optional[str] = None
+        #: True: lmax <= 4 runs on the degree-sliced kernel family as well (GN_LMAX_SLICED; tests hold the two families
+        #: against each other)
+        self.sliced_kernels = False
         self._warned_inference_only = False
 
     # ------------------------------------------------------------------ parameters
@@ -472,7 +480,8 @@ class GotenNet(nn.Module):
                              composed_update=g0.composed_update, gate_kind=g0.gate_kind,
                              t_last_act=0 if g0.update_info["mlp"] else 3,
                              lin_w=g0.update_info["lin_w"], lin_ln=g0.update_info["lin_ln"],
-                             evec=g0.edge_vec_dim, emlp=g0.edge_mlp_dim, act=self.act_kind)
+                             evec=g0.edge_vec_dim, emlp=g0.edge_mlp_dim, act=self.act_kind,
+                             gemm_mode=engine.resolve_mode(self.gemm_mode), sliced=bool(self.sliced_kernels))
 
     def packed_weights(self) -> engine.PackedWeights:
         """Concatenate the projections that share an input into single GEMM operands

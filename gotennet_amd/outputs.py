@@ -124,7 +124,8 @@ class Atomwise(nn.Module):
         _, c = self._packed()
         return c["scale"], c["shift"]
 
-    def energy_raw(self, h: torch.Tensor, z32: torch.Tensor, mol_ptr: torch.Tensor, n_mol: int, raw: bool = False):
+    def energy_raw(self, h: torch.Tensor, z32: torch.Tensor, mol_ptr: torch.Tensor, n_mol: int, raw: bool = False,
+                   mode: Optional[str] = None):
         """-> (energy [n_mol,1] (sum or mean over the molecule's atoms), y [N] per-atom contributions, tape).
         ``tape`` (pre-activations of the hidden layers + the aggregation's per-atom weights) goes to ``grad_h_raw``.
         ``raw``: y = the MLP output itself (no standardisation, no atomref) -- what ElectronicSpatialExtentV2 reads."""
@@ -138,11 +139,11 @@ class Atomwise(nn.Module):
             if k + 1 < len(hidden):                  # activated output feeds the next layer; the pre-activation is kept
                 xa = new(N, d.out_features)
                 engine.gemm(x, d.in_features, c["w"][k], c["b"][k], xa, d.out_features, N, d.out_features, d.in_features,
-                            act=(0, d.out_features), pre_out=pre, kind=self.act_kind)
+                            act=(0, d.out_features), pre_out=pre, kind=self.act_kind, mode=mode)
                 x = xa
             else:                                    # last hidden layer: gn_head_energy applies the activation itself
                 engine.gemm(x, d.in_features, c["w"][k], c["b"][k], pre, d.out_features, N, d.out_features, d.in_features,
-                            kind=self.act_kind)
+                            kind=self.act_kind, mode=mode)
             pres.append(pre)
         last_in = pres[-1] if pres else h.contiguous()
         act = self.act_kind if pres else 11          # GN_ACT_NONE: n_layers = 1, y = W h + b
@@ -154,7 +155,7 @@ class Atomwise(nn.Module):
              n_mol, last_in.shape[1], ptr(y), ptr(e), int(mean), ptr(atom_scale), act, engine._stream())
         return e, y, (pres, last_in, atom_scale)
 
-    def grad_h_raw(self, tape, Fd: int) -> torch.Tensor:
+    def grad_h_raw(self, tape, Fd: int, mode: Optional[str] = None) -> torch.Tensor:
         """d(sum over molecules of the aggregated property)/dh [N,F]."""
         layers, c = self._packed()
         pres, last_in, atom_scale = tape
@@ -167,7 +168,7 @@ class Atomwise(nn.Module):
             d = layers[k]
             gi = new(N, d.in_features)
             engine.gemm(g, d.out_features, c["wt"][k], None, gi, d.in_features, N, d.in_features, d.out_features,
-                        dgate=pres[k - 1] if k > 0 else None, kind=self.act_kind)
+                        dgate=pres[k - 1] if k > 0 else None, kind=self.act_kind, mode=mode)
             g = gi
         return g
 

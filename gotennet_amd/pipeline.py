@@ -26,17 +26,28 @@ class EnergyForces:
         #: version counter -- an MD loop or a benchmark on a fixed neighbour list) reuses the CSR / CSC index arrays,
         #: the validation verdict and the stable-sort permutation of the previous call: no sort / scan / fill launch and
         #: no host read on such a step, only the geometry kernel runs on the new ``edge_diff`` / ``edge_vec``.  The cache
-        #: holds a reference to the tensor (its memory cannot be recycled under the key); writes that bypass PyTorch's
+        #: holds a reference to the tensor (its memory cannot be recycled under the key) and the E-sized index / geometry
+        #: buffers of its Graph until the next different edge list or ``clear_cache()``; writes that bypass PyTorch's
         #: version counter (raw pointers, ``.data``) are not seen: pass ``cache_topology=False`` for such callers.
+        #: Inference tensors (made under ``torch.inference_mode()``) have no version counter and are never cached.
         self.cache_topology = cache_topology
         self._topo = None
 
+    def clear_cache(self):
+        """Drop the cached topology (it keeps the last ``edge_index`` tensor and E-sized index / geometry buffers alive)."""
+        self._topo = None
+
     def _graph(self, cfg, pw, N, edge_index, edge_diff, edge_vec, need_csc):
-        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), tuple(edge_index.stride()), N,
-               id(pw), cfg.lmax, cfg.R, cfg.basis, bool(cfg.scale_edge), bool(self.check_edges))
-        hit = self.cache_topology and self._topo is not None and self._topo[0] == key and self._topo[1] is edge_index
+        key = None
+        if self.cache_topology and not edge_index.is_inference():
+            # (inference tensors -- a neighbour list built under torch.inference_mode() -- carry no version counter:
+            #  reading ``_version`` raises, and a write to one cannot be seen, so they are never cached)
+            key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), tuple(edge_index.stride()), N,
+                   id(pw), cfg.lmax, cfg.R, cfg.basis, bool(cfg.scale_edge), bool(self.check_edges))
+        hit = key is not None and self._topo is not None and self._topo[0] == key and self._topo[1] is edge_index
         if hit:
             _, _, g, order = self._topo
+            g.cfg = cfg                              # cutoff / eps may have changed under the same packed weights
             if order is not None:
                 edge_diff, edge_vec = edge_diff[order], edge_vec[order]
             g.set_geometry(edge_diff.contiguous(), edge_vec.contiguous())
@@ -45,7 +56,7 @@ class EnergyForces:
             if self.check_edges:
                 ei, edge_diff, edge_vec, order = engine.sorted_edges(ei, edge_diff, edge_vec, N)
             g = engine.Graph(cfg, pw, N, ei, edge_diff.contiguous(), edge_vec.contiguous())
-            self._topo = (key, edge_index, g, order) if self.cache_topology else None
+            self._topo = (key, edge_index, g, order) if key is not None else None
         if need_csc:
             g.csc()
         return g
@@ -63,10 +74,10 @@ class EnergyForces:
         h, X, tape = engine.forward(cfg, pw, z32, g, save=forces)
         if mol_ptr is None:
             mol_ptr = molecule_ptr(batch, n_mol)
-        e, y, pre1 = self.head.energy_raw(h, z32, mol_ptr, n_mol)
+        e, y, pre1 = self.head.energy_raw(h, z32, mol_ptr, n_mol, mode=cfg.gemm_mode)
         if not forces:
             return e, None
-        gh = self.head.grad_h_raw(pre1, cfg.F)
+        gh = self.head.grad_h_raw(pre1, cfg.F, mode=cfg.gemm_mode)
         g_vec, g_diff = engine.backward(cfg, pw, z32, g, tape, gh, None)
         return e, engine.pos_gradient(g, g_vec, g_diff, sign=-1.0)
 
@@ -118,8 +129,8 @@ class CapturedStep:
         cfg, pw, g = self.cfg, self.pw, self.g
         g.set_positions(self.pos)
         h, X, tape = engine.forward(cfg, pw, self.z32, g, save=True)
-        e, y, pre1 = self.head.energy_raw(h, self.z32, self.mol_ptr, self.n_mol)
-        gh = self.head.grad_h_raw(pre1, cfg.F)
+        e, y, pre1 = self.head.energy_raw(h, self.z32, self.mol_ptr, self.n_mol, mode=cfg.gemm_mode)
+        gh = self.head.grad_h_raw(pre1, cfg.F, mode=cfg.gemm_mode)
         g_vec, g_diff = engine.backward(cfg, pw, self.z32, g, tape, gh, None)
         return e, engine.pos_gradient(g, g_vec, g_diff, sign=-1.0)
 

@@ -16,7 +16,8 @@
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
  *   - return value: 0 on success, otherwise a hipError_t (launch errors) or
  *     GN_ERR_* (argument errors); no C++ exceptions cross the ABI;
- *   - re-entrant, no global mutable state.
+ *   - re-entrant, no global mutable state: no entry point reads the process environment or a mutable static; every
+ *     choice of kernel is a function of the arguments (GN_LMAX_SLICED below) or a build-time constant.
  *
  * Symbols: N atoms, E directed edges in CSR-by-target order (edge e runs
  * src[e] = j  ->  dst = i, rowptr[i] <= e < rowptr[i+1]), F = n_atom_basis,
@@ -37,7 +38,12 @@ extern "C" {
 
 #define GN_OK 0
 #define GN_ERR_BAD_ARG 10001     /* shape/flag combination the kernels do not implement */
-#define GN_ABI_VERSION 6
+#define GN_ABI_VERSION 7
+/* OR-ed into the `lmax` ARGUMENT of gn_message_aggregate, gn_message_backward(_groups), gn_htr_edge and
+ * gn_htr_backward: run this call on the degree-sliced kernel family at lmax <= 4 as well (the family that serves
+ * lmax 5..8).  An explicit per-call request -- the library reads no environment variable and keeps no switch; every
+ * tuning value of the launchers is a build-time constant (csrc/gn_tune.h). */
+#define GN_LMAX_SLICED 0x100
 
 /* `act`: the element-wise activation of the reference's `activation` constructor argument (str2act, layers.py:596-700;
  * shifted_softplus layers.py:40-50).  Wherever an entry point below says SiLU, it means this kind. */

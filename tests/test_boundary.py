@@ -510,3 +510,63 @@ def test_gata_module_edge_cases():
     if cfg["scale_edge"]:
         with pytest.raises(ValueError):
             gata(ei, h, X, rl, tij, ed, torch.full((E, 1), 3.0, device="cuda"))
+
+
+@pytest.mark.gpu
+def test_two_models_two_arithmetics_two_threads():
+    """The projection arithmetic and the activation kind are per-model values carried in ``Config`` (no module-level
+    call state): an exact-fp32 model and a 2xfp16-split model (with different activations) run CONCURRENTLY from two
+    threads, each on its own stream, and every result is bit-identical to the same model run alone."""
+    import threading
+    from tests.test_hip_forces import _head_from_case
+    from gotennet_amd.pipeline import EnergyForces
+    jobs = []
+    for case, mode in (("l2_sep_f32", "f32"), ("opt_act_tanh_l3_gated", "f16x2")):
+        cfg, sd, head_sd, t = load_case(case)
+        net, head = _mirror(cfg, sd), _head_from_case(cfg, head_sd)
+        net.gemm_mode = mode
+        assert net.config().gemm_mode == mode
+        args = [t[k].cuda() for k in ("z", "edge_index", "edge_diff", "edge_vec", "batch")] + [cfg["n_mol"]]
+        ef = EnergyForces(net, head)
+        e0, f0 = ef(*args)
+        torch.cuda.synchronize()
+        assert rel_err(e0.cpu(), t["energy"]) < TOL and rel_err(f0.cpu(), t["forces"]) < TOL
+        jobs.append((ef, args, e0.clone(), f0.clone()))
+    bad, barrier = [], threading.Barrier(2)
+
+    def run(ef, args, e0, f0):
+        stream = torch.cuda.Stream()
+        barrier.wait()
+        with torch.cuda.stream(stream):
+            for _ in range(30):
+                e, f = ef(*args)
+                if not (torch.equal(e, e0) and torch.equal(f, f0)):
+                    bad.append(ef.rep.gemm_mode)
+        stream.synchronize()
+
+    ths = [threading.Thread(target=run, args=j) for j in jobs]
+    [th.start() for th in ths]
+    [th.join() for th in ths]
+    assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_energy_forces_under_inference_mode():
+    """A neighbour list built under torch.inference_mode() has no version counter (reading ``_version`` raises): the
+    topology cache must treat it as a miss, not crash (the round-3 code did)."""
+    from tests.test_hip_forces import _head_from_case
+    from gotennet_amd.graph import distance
+    from gotennet_amd.pipeline import EnergyForces
+    cfg, sd, head_sd, t = load_case("l2_sep_f32")
+    net, head = _mirror(cfg, sd), _head_from_case(cfg, head_sd)
+    ef = EnergyForces(net, head)
+    z, batch = t["z"].cuda(), t["batch"].cuda()
+    e0, f0 = ef(z, t["edge_index"].cuda(), t["edge_diff"].cuda(), t["edge_vec"].cuda(), batch, cfg["n_mol"])
+    with torch.inference_mode():
+        ei, ed, ev = t["edge_index"].cuda(), t["edge_diff"].cuda(), t["edge_vec"].cuda()
+        assert ei.is_inference()
+        for _ in range(2):
+            e, f = ef(z, ei, ed, ev, batch, cfg["n_mol"])
+    assert torch.equal(e, e0) and torch.equal(f, f0)
+    assert ef._topo is None                          # never cached
+    ef.clear_cache()

@@ -2,9 +2,6 @@
 tuned ones at lmax <= 4.  Model-level parity at lmax = 5..8 (forward, energy, forces against the reference goldens
 l5_* .. l8_*) runs with every other fixture in test_hip_parity.py / test_hip_forces.py."""
 import os
-import subprocess
-import sys
-import tempfile
 
 import numpy as np
 import pytest
@@ -42,25 +39,6 @@ def test_harmonics_known_answers_high_degree(lmax):
     assert float(rl[-1].abs().max()) == 0.0
 
 
-_SCRIPT = r"""
-import sys, torch
-sys.path.insert(0, %r)
-from tests.golden_util import load_case
-from tests.test_hip_parity import _net_from_case
-from tests.test_hip_forces import _head_from_case
-from gotennet_amd.pipeline import EnergyForces
-out = {}
-for name in sys.argv[2:]:
-    cfg, sd, head_sd, t = load_case(name)
-    net, head = _net_from_case(cfg, sd), _head_from_case(cfg, head_sd)
-    h, X = net(t["z"].cuda(), t["edge_index"].cuda(), t["edge_diff"].cuda(), t["edge_vec"].cuda())
-    e, f = EnergyForces(net, head)(t["z"].cuda(), t["edge_index"].cuda(), t["edge_diff"].cuda(), t["edge_vec"].cuda(),
-                                   t["batch"].cuda(), cfg["n_mol"])
-    torch.cuda.synchronize()
-    out[name] = [v.cpu() for v in (h, X, e, f)]
-torch.save(out, sys.argv[1])
-""" % ROOT
-
 # every flag family the sliced kernels branch on: sep / no-sep gates, scale_edge, joint HTR, norej, gamma_w gates,
 # TensorLayerNorm, composed edge updates (direct HTR backward)
 _CASES = ["l1_nosep_scale_f32", "l2_sep_f32", "l2_mixed_f64ch", "l3_sep_scale_f32", "l4_sep_f32", "opt_bessel_norej",
@@ -68,26 +46,33 @@ _CASES = ["l1_nosep_scale_f32", "l2_sep_f32", "l2_mixed_f64ch", "l3_sep_scale_f3
           "opt_mlp_linwa_ln_gated", "c2_model_lmax4_1mol_seeded"]
 
 
-def test_degree_sliced_kernels_match_tuned_kernels():
-    """GN_FORCE_HIGHL=1 (read once per process) routes lmax <= 4 through gn_highl.hip: the representation must come out
-    bit-identical where the per-row arithmetic is the same (message stage; HTR differs in the literal-vs-closed
-    rejection form only for the default mode), forces within 1e-5."""
+@pytest.mark.parametrize("name", _CASES)
+def test_degree_sliced_kernels_match_tuned_kernels(name):
+    """``net.sliced_kernels = True`` ORs GN_LMAX_SLICED into the lmax argument of the message / HTR entry points (an
+    explicit per-call flag: the library reads no environment variable) and routes lmax <= 4 through gn_highl.hip: the
+    representation must come out the same as from the tuned kernels (message stage: same per-row arithmetic; HTR
+    differs in the literal-vs-closed rejection form only for the default mode), forces within 1e-5 -- in ONE process,
+    both families side by side."""
+    from tests.test_hip_forces import _head_from_case
+    from tests.test_hip_parity import _net_from_case
+    from gotennet_amd.pipeline import EnergyForces
+    cfg, sd, head_sd, t = load_case(name)
+    net, head = _net_from_case(cfg, sd), _head_from_case(cfg, head_sd)
+    args = [t[k].cuda() for k in ("z", "edge_index", "edge_diff", "edge_vec")]
     outs = {}
-    with tempfile.TemporaryDirectory() as td:
-        for flag in ("0", "1"):
-            path = os.path.join(td, f"hl{flag}.pt")
-            res = subprocess.run([sys.executable, "-c", _SCRIPT, path] + _CASES, env=dict(os.environ, GN_FORCE_HIGHL=flag),
-                                 capture_output=True, text=True, timeout=900, cwd=ROOT)
-            assert res.returncode == 0, res.stderr[-3000:]
-            outs[flag] = torch.load(path)
-    for name in _CASES:
-        _, _, _, t = load_case(name)
-        for what, a, b in zip("hXef", outs["0"][name], outs["1"][name]):
-            assert rel_err(b, a) < 1e-5, (name, what, rel_err(b, a))
-        # and the sliced kernels on their own against the reference
-        h, X, e, f = outs["1"][name]
-        assert rel_err(h, t["h"]) < 1e-4 and rel_err(X, t["X"]) < 1e-4, name
-        assert rel_err(e, t["energy"]) < 1e-4 and rel_err(f, t["forces"]) < 1e-4, name
+    for flag in (False, True):
+        net.sliced_kernels = flag
+        assert net.config().sliced == flag
+        h, X = net(*args)
+        e, f = EnergyForces(net, head)(*args, t["batch"].cuda(), cfg["n_mol"])
+        torch.cuda.synchronize()
+        outs[flag] = [v.cpu() for v in (h, X, e, f)]
+    for what, a, b in zip("hXef", outs[False], outs[True]):
+        assert rel_err(b, a) < 1e-5, (name, what, rel_err(b, a))
+    # and the sliced kernels on their own against the reference
+    h, X, e, f = outs[True]
+    assert rel_err(h, t["h"]) < 1e-4 and rel_err(X, t["X"]) < 1e-4, name
+    assert rel_err(e, t["energy"]) < 1e-4 and rel_err(f, t["forces"]) < 1e-4, name
 
 
 @pytest.mark.parametrize("lmax,sep,F", [(5, True, 128), (6, False, 256), (8, True, 64)])

@@ -185,3 +185,18 @@ def test_bench_line_fits_driver_tail():
     fat["also"] = {f"w{i}": dict(full["also"]["lmax4"], config="x" * 80) for i in range(40)}
     line = bench.compact_line(fat)
     assert len(line) < bench.LINE_BUDGET and "roofline" in json.loads(line) and "cpu_baseline" in json.loads(line)
+
+
+def test_library_reads_no_environment():
+    """include/gotennet_hip.h: "re-entrant, no global mutable state" -- no entry point may read the process environment
+    (round 3 read GN_ATTN_WAVE / GN_GEMM_* / GN_FORCE_HIGHL into function-local statics) and the wrong-result probe
+    paths are gone from the product translation units."""
+    import glob
+    csrc = os.path.join(ROOT, "gotennet_amd", "csrc")
+    for path in glob.glob(os.path.join(csrc, "*")):
+        text = open(path).read()
+        assert "getenv" not in text, path
+        for probe in ("GN_SPLIT_ABL", "GN_SPLIT_NOSTORE", "GN_SPLIT_TRACE"):
+            assert probe not in text, (path, probe)
+    from gotennet_amd import engine
+    assert not hasattr(engine, "ACT") and not hasattr(engine, "_act_scope")
