@@ -58,6 +58,8 @@ class KernelTimer:
         tag = self.tag_of(name, args)
         if self.wanted is not None and tag not in self.wanted:
             return None
+        if name == "gn_message_fused":               # args[0]: byref(gn_fused_desc)
+            return tag + "|first" if not args[0]._obj.X_in else tag
         k = self.X_IN_ARG.get(name)
         return tag + "|first" if (k is not None and args[k] is None) else tag
 
@@ -155,6 +157,8 @@ def compact_line(full):
         elif k == "forward_only":
             also[k] = {"value": v.get("value"), "ms_per_step": v.get("ms_per_step"), "steps": v.get("steps"),
                        "fused_message": v.get("fused_message"),
+                       "fused_ab_ms_per_step": (v.get("fused_message_ab") or {}).get("ms_per_step"),
+                       "fused_kernel_us": (v.get("fused_message_ab") or {}).get("kernel_us"),
                        "cpu_value": (v.get("cpu_baseline") or {}).get("value")}
         elif k in ("single_molecule_latency", "hipgraph_replay_full_batch"):
             also[k] = {kk: v.get(kk) for kk in ("molecules", "eager_ms_per_step", "hipgraph_replay_ms_per_step",
@@ -397,8 +401,10 @@ def graph_latency(a, rep, head, dev, n_mol=1, iters=200):
 
 def forward_only(a, rep, head, dev, steps=20):
     """The path's own API, forward only: representation forward + Atomwise energy, no force backward
-    (`EnergyForces(..., forces=False)`: ping-pong work buffers, nothing saved).  Same workload and model as the headline."""
-    from gotennet_amd import synthetic
+    (`EnergyForces(..., forces=False)`: ping-pong work buffers, nothing saved).  Same workload and model as the headline.
+    Timed twice in one process: with gn_message_fused (edge projection + softmax + message as one kernel, no
+    [E,(1+M)F] stream: what ships for inference) and with the three-kernel sequence (`rep.fuse_message = False`)."""
+    from gotennet_amd import _lib, engine, synthetic
     from gotennet_amd.graph import distance
     from gotennet_amd.outputs import molecule_ptr
     from gotennet_amd.pipeline import EnergyForces
@@ -408,18 +414,46 @@ def forward_only(a, rep, head, dev, steps=20):
     ei, ed, ev = distance(pos, batch, 5.0, 32)
     mol_ptr = molecule_ptr(batch, B)
     ef = EnergyForces(rep, head, check_edges=False)
-    for _ in range(3):
-        e, _ = ef(z, ei, ed, ev, batch, B, mol_ptr=mol_ptr, forces=False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        e, _ = ef(z, ei, ed, ev, batch, B, mol_ptr=mol_ptr, forces=False)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert torch.isfinite(e).all()
-    return {"metric": "molecules/sec (energy only: representation forward + Atomwise head, no forces)",
-            "value": round(B * steps / dt, 1), "unit": "molecules/s", "ms_per_step": round(1e3 * dt / steps, 3),
-            "steps": steps, "config": f"{a.workload} batch={B}, same model as the headline line"}
+
+    def timed():
+        for _ in range(3):
+            e, _ = ef(z, ei, ed, ev, batch, B, mol_ptr=mol_ptr, forces=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e, _ = ef(z, ei, ed, ev, batch, B, mol_ptr=mol_ptr, forces=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(e).all()
+        return dt, e
+
+    old = rep.fuse_message
+    tot = cnt = None
+    try:
+        dt0, e0 = timed()                                # what ships: the default of GotenNet.fuse_message (False)
+        rep.fuse_message = True                          # the opt-in fused kernel, same process
+        fused_on = engine.fused_message_ok(rep.config())
+        if fused_on:
+            dt1, e1 = timed()
+            kt = KernelTimer(wanted={"gn_message_fused"})    # per-launch time of the fused kernel (HIP events, one step)
+            _lib.TIMER = kt
+            ef(z, ei, ed, ev, batch, B, mol_ptr=mol_ptr, forces=False)
+            torch.cuda.synchronize()
+            _lib.TIMER = None
+            tot, cnt = kt.summary(split_first=True)
+    finally:
+        rep.fuse_message = old
+        _lib.TIMER = None
+    out = {"metric": "molecules/sec (energy only: representation forward + Atomwise head, no forces)",
+           "value": round(B * steps / dt0, 1), "unit": "molecules/s", "ms_per_step": round(1e3 * dt0 / steps, 3),
+           "steps": steps, "config": f"{a.workload} batch={B}, same model as the headline line",
+           "fused_message": bool(old)}
+    if fused_on:
+        out["fused_message_ab"] = {"ms_per_step": round(1e3 * dt1 / steps, 3), "value": round(B * steps / dt1, 1),
+                                   "kernel_us": {k: round(1e3 * tot[k] / cnt[k], 1) for k in tot},
+                                   "energy_rel_diff": float((e1 - e0).abs().max() / e0.abs().max()),
+                                   "note": "gn_message_fused (edge projection + softmax + message, no eproj stream), opt-in"}
+    return out
 
 
 #: launches of the GATA message stage (gotennet.py:452-559, 613-640): scores + segment softmax + message + aggregate.

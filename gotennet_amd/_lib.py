@@ -30,6 +30,14 @@ class GemmDesc(C.Structure):
                 ("a_gate", _P), ("ldg", _I), ("A2", _P), ("A3", _P), ("a_seg", _I), ("act_kind", _I)]
 
 
+class FusedDesc(C.Structure):
+    """gn_fused_desc of include/gotennet_hip.h (gn_message_fused)."""
+    _fields_ = [("t", _P), ("W", _P), ("bias", _P), ("q", _P), ("k", _P), ("ldqk", _I), ("x", _P), ("v", _P), ("ldxv", _I),
+                ("X_in", _P), ("h_in", _P), ("h_out", _P), ("X_out", _P), ("rl", _P), ("cut", _P),
+                ("rowptr", _P), ("src", _P), ("outdeg", _P), ("tile_first", _P), ("n_tiles", _P), ("tile_cap", _I),
+                ("attn_ws", _P), ("N", _I), ("F", _I), ("H", _I), ("lmax", _I), ("sep_dir", _I), ("sep_tensor", _I)]
+
+
 SIGNATURES = {
     "gn_abi_version": [C.POINTER(C.c_char_p)],
     "gn_build_csr": [_P, _I, _I, _P, _P, _P, _P],
@@ -45,6 +53,10 @@ SIGNATURES = {
     "gn_gemm": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "gn_attn_softmax": [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P],
     "gn_message_aggregate": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gn_edge_tiles_cap": [_I, _L],
+    "gn_edge_tiles": [_P, _I, _I, _P, _P, _P],
+    "gn_message_fused_supported": [_I, _I, _I, _I, _I, _I],
+    "gn_message_fused": [_P, _I, _P],
     "gn_htr_edge": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "gn_eqff_context": [_P, _P, _F, _I, _I, _I, _P, _P],
     "gn_eqff_update": [_P, _P, _I, _I, _I, _P, _P, _P],
@@ -105,7 +117,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes
-        fn.restype = C.c_long if name in ("gn_split_bf16x3_size", "gn_split_f16x2_size") else C.c_int
+        fn.restype = C.c_long if name in ("gn_split_bf16x3_size", "gn_split_f16x2_size", "gn_edge_tiles_cap") else C.c_int
     if lib.gn_abi_version(None) != ABI_VERSION:
         raise GotenNetHipError("libgotennet_hip.so ABI version mismatch; rebuild")
     _lib = lib

@@ -134,6 +134,8 @@ class Config:
     emlp: int = 0             # emlp_dim: hidden width of the 2-layer gamma_t (0 = F)
     gemm_mode: str = ""       # projection arithmetic of THIS model ("f16x2" | "split" | "f32"; "" = engine.GEMM_MODE, the default)
     sliced: bool = False      # run lmax <= 4 on the degree-sliced kernel family too (GN_LMAX_SLICED in the lmax argument)
+    fuse_message: bool = False  # inference (nothing saved): edge projection + softmax + message as ONE kernel (gn_message_fused,
+                                # no [E,(1+M)F] stream); opt-in: measured 2-10 % slower than the three kernels
 
     @property
     def Fe(self) -> int:
@@ -318,6 +320,7 @@ class Graph:
         self.cut = torch.empty(E, **f32)
         self.perm = self.colptr = self.tgt_by_src = None
         self.edge_diff = self.edge_vec = None
+        self._tiles = None
         if edge_vec is not None:
             self.set_geometry(edge_diff, edge_vec)
 
@@ -337,6 +340,17 @@ class Graph:
         call("gn_edge_vectors", ptr(pos), ptr(self.src), ptr(self.dst), self.E, ptr(self.edge_vec), ptr(self.edge_diff),
              _stream())
         self.set_geometry(self.edge_diff, self.edge_vec)
+
+    def tiles(self):
+        """Edge-row tiles of gn_message_fused (<= 128 consecutive CSR rows cut on target boundaries), built on the device
+        once per topology; the capacity is a host-side bound (no read-back).  -> (tile_first, n_tiles, cap)."""
+        if self._tiles is None:
+            cap = int(_lib.load().gn_edge_tiles_cap(self.N, self.E))
+            tile_first = torch.empty(cap + 1, dtype=torch.int32, device=self.src.device)
+            n_tiles = torch.empty(1, dtype=torch.int32, device=self.src.device)
+            call("gn_edge_tiles", ptr(self.rowptr), self.N, cap, ptr(tile_first), ptr(n_tiles), _stream())
+            self._tiles = (tile_first, n_tiles, cap)
+        return self._tiles
 
     def csc(self):
         """Edges grouped by source (stable): integer index plumbing, no host sync."""
@@ -401,10 +415,11 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
     X = torch.zeros((N, D, F_), **f32)            # gotennet.py:992
     lde = (1 + M) * F_
     nact, g1act = new(N, 4 * F_), new(N, F_)       # activated copies (scratch, shared by all layers)
+    fused = (not save) and trace is None and E > 0 and fused_message_ok(cfg)
     if not save:                                   # inference: ping-pong work buffers, reused by every layer
         h2, X2, t2 = new(N, F_), new(N, D, F_), new(E, F_)
         nproj, xs, vs = new(N, 4 * F_), new(N, M * F_), new(N, M * F_)
-        eproj, attn = new(E, lde), new(E, H)
+        eproj, attn = (None if fused else new(E, lde)), new(E, H)
         EQ, EK, Xp, w = new(N, D, Fe), new(N, D, Fe), new(N, D, F_), new(E, Fe)
         ctx, pre_g1, mm = new(N, 2 * F_), new(N, F_), new(N, 2 * F_)
 
@@ -440,7 +455,7 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
         # pre-activation copy is what the backward needs.
         first = zero_X_in(cfg, li)                  # X is the zero tensor made above: no tensor-gate blocks
         We, be, ne = _We_first(cfg, lw) if first else (lw.We, lw.be, lde)
-        gemm_group([dict(A=t, lda=F_, W=We, bias=be, C=eproj, ldc=lde, rows=E, nout=ne, K=F_),
+        gemm_group([None if fused else dict(A=t, lda=F_, W=We, bias=be, C=eproj, ldc=lde, rows=E, nout=ne, K=F_),
                     dict(A=h, lda=F_, W=lw.Wn1, bias=lw.bn1, C=nact, ldc=4 * F_, rows=N, nout=4 * F_, K=F_,
                          act=(2 * F_, 4 * F_), pre_out=nproj if save else None)])
         nv = _value_first(cfg, lw) if first else M * F_
@@ -448,8 +463,12 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
                          K=F_, a_off=2 * F_),
                     dict(A=nact, lda=4 * F_, W=lw.Wv20 if first else lw.Wv2, bias=lw.bv2, C=vs, ldc=M * F_, rows=N, nout=nv,
                          K=F_, a_off=3 * F_)])
-        # ---- message / softmax / aggregate / residual (452-559, 613-640, 426-427)
-        message_stage(cfg, g, nact, xs, vs, eproj, attn, h, None if first else X, h2, X2)
+        # ---- message / softmax / aggregate / residual (452-559, 613-640, 426-427); inference: with the edge
+        # projection inside (no eproj stream)
+        if fused:
+            message_stage_fused(cfg, g, t, We, be, nact, xs, vs, attn, h, None if first else X, h2, X2)
+        else:
+            message_stage(cfg, g, nact, xs, vs, eproj, attn, h, None if first else X, h2, X2)
         h, h2 = h2, h
         X, X2 = X2, X
         # every product of the updated X (X W_vu^T for EQFF; EQ and the per-degree EK_l for HTR) in one launch
@@ -586,6 +605,32 @@ def message_stage(cfg: Config, g: "Graph", nact, xs, vs, eproj, attn, h, X, h2, 
     call("gn_message_aggregate", ptr(xs), ptr(vs), M * F_, eproj.data_ptr() + 4 * F_, lde,
          ptr(attn), ptr(g.rl), ptr(g.cut), ptr(g.rowptr), ptr(g.src),
          ptr(h), ptr(X), ptr(h2), ptr(X2), g.N, F_, H, cfg.lmax_arg, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
+
+
+def fused_message_ok(cfg: Config) -> bool:
+    """gn_message_fused covers this model (SiLU, lmax <= 4, F a power of two >= 128, a plane arithmetic) and is switched on."""
+    mode = resolve_mode(cfg.gemm_mode)
+    if not cfg.fuse_message or cfg.sliced or mode not in _PLANE_MODES:
+        return False
+    return bool(_lib.load().gn_message_fused_supported(cfg.F, cfg.H, cfg.lmax, cfg.M, cfg.act, 1 if mode == "split" else 2))
+
+
+def message_stage_fused(cfg: Config, g: "Graph", t, We, be, nact, xs, vs, attn_ws, h, X, h2, X2):
+    """Edge projection + scores + segment softmax + message + aggregate + residual as ONE launch (gn_message_fused):
+    the inference form of ``gemm(t, [W_re; W_rs])`` -> ``message_stage`` without eproj.  ``X`` None: first interaction
+    (``We`` / ``be`` are then the prefix without the tensor-gate blocks)."""
+    mode = resolve_mode(cfg.gemm_mode)
+    tile_first, n_tiles, cap = g.tiles()
+    d = _lib.FusedDesc()
+    d.t, d.W, d.bias = ptr(t), ptr(split_weight(We, mode)), ptr(be)
+    d.q, d.k, d.ldqk = ptr(nact), nact.data_ptr() + 4 * cfg.F, 4 * cfg.F
+    d.x, d.v, d.ldxv = ptr(xs), ptr(vs), cfg.M * cfg.F
+    d.X_in, d.h_in, d.h_out, d.X_out = ptr(X), ptr(h), ptr(h2), ptr(X2)
+    d.rl, d.cut, d.rowptr, d.src, d.outdeg = ptr(g.rl), ptr(g.cut), ptr(g.rowptr), ptr(g.src), ptr(g.outdeg)
+    d.tile_first, d.n_tiles, d.tile_cap, d.attn_ws = ptr(tile_first), ptr(n_tiles), cap, ptr(attn_ws)
+    d.N, d.F, d.H, d.lmax, d.sep_dir, d.sep_tensor = g.N, cfg.F, cfg.H, cfg.lmax, int(cfg.sep_dir), int(cfg.sep_tensor)
+    import ctypes
+    call("gn_message_fused", ctypes.byref(d), 1 if mode == "split" else 2, _stream())
 
 
 def _edge_update_composed(cfg: Config, lw: LayerWeights, t, w_raw, t2, E: int, pre_t):

@@ -413,6 +413,10 @@ class GotenNet(nn.Module):
         #: True: lmax <= 4 runs on the degree-sliced kernel family as well (GN_LMAX_SLICED; tests hold the two families
         #: against each other)
         self.sliced_kernels = False
+        #: True: inference calls (nothing saved for a backward) run edge projection + softmax + message as ONE kernel
+        #: (gn_message_fused: no [E, (1+M)F] stream) where the model is covered (engine.fused_message_ok).  Off by default:
+        #: measured 2-10 % slower than the three-kernel sequence on MI355X
+        self.fuse_message = False
         self._warned_inference_only = False
 
     # ------------------------------------------------------------------ parameters
@@ -481,7 +485,8 @@ class GotenNet(nn.Module):
                              t_last_act=0 if g0.update_info["mlp"] else 3,
                              lin_w=g0.update_info["lin_w"], lin_ln=g0.update_info["lin_ln"],
                              evec=g0.edge_vec_dim, emlp=g0.edge_mlp_dim, act=self.act_kind,
-                             gemm_mode=engine.resolve_mode(self.gemm_mode), sliced=bool(self.sliced_kernels))
+                             gemm_mode=engine.resolve_mode(self.gemm_mode), sliced=bool(self.sliced_kernels),
+                             fuse_message=bool(self.fuse_message))
 
     def packed_weights(self) -> engine.PackedWeights:
         """Concatenate the projections that share an input into single GEMM operands
