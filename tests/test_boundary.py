@@ -570,3 +570,38 @@ def test_energy_forces_under_inference_mode():
     assert torch.equal(e, e0) and torch.equal(f, f0)
     assert ef._topo is None                          # never cached
     ef.clear_cache()
+
+
+@pytest.mark.gpu
+def test_energy_forces_replays_static_topology_bit_identically():
+    """EnergyForces(replay=True): after two calls on one topology the step is recorded into one hipGraph and replayed on
+    the call's fresh edge_diff / edge_vec / z -- bit-identical to the eager step for NEW positions, an eager call when the
+    edge list changes, and again a capture on the new list."""
+    from tests.test_hip_forces import _head_from_case
+    from gotennet_amd.graph import distance
+    from gotennet_amd.pipeline import EnergyForces
+    cfg, sd, head_sd, t = load_case("l2_sep_f32")
+    net, head = _mirror(cfg, sd), _head_from_case(cfg, head_sd)
+    z, batch, pos = t["z"].cuda(), t["batch"].cuda(), t["pos"].cuda()
+    eager, rep = EnergyForces(net, head), EnergyForces(net, head, replay=True)
+    ei, ed, ev = distance(pos, batch, cfg["cutoff"], 32)
+    g = torch.Generator().manual_seed(3)
+    for it in range(6):
+        p2 = pos + 1e-3 * torch.randn(pos.shape, generator=g).cuda()       # same neighbour list, new geometry
+        ei2, ed2, ev2 = distance(p2, batch, cfg["cutoff"], 32)
+        assert torch.equal(ei2, ei)
+        e0, f0 = eager(z, ei, ed2, ev2, batch, cfg["n_mol"])
+        e1, f1 = rep(z, ei, ed2, ev2, batch, cfg["n_mol"])
+        assert torch.equal(e0, e1) and torch.equal(f0, f1), it
+        assert (rep._graph_state is not None) == (it >= 2)
+    # another edge list (one edge dropped): eager again, same numbers as the eager object, then a new capture
+    keep = torch.ones(ei.shape[1], dtype=torch.bool, device="cuda")
+    keep[int((ei[0] != ei[1]).nonzero()[0])] = False
+    ei3, ed3, ev3 = ei[:, keep].contiguous(), ed[keep].contiguous(), ev[keep].contiguous()
+    for it in range(4):
+        e0, f0 = eager(z, ei3, ed3, ev3, batch, cfg["n_mol"])
+        e1, f1 = rep(z, ei3, ed3, ev3, batch, cfg["n_mol"])
+        assert torch.equal(e0, e1) and torch.equal(f0, f1)
+    assert rep._graph_state is not None
+    rep.clear_cache()
+    assert rep._graph_state is None and rep._topo is None
