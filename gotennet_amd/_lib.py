@@ -53,6 +53,9 @@ SIGNATURES = {
     "gn_gemm": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "gn_attn_softmax": [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P],
     "gn_message_aggregate": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gn_eqff_fused_supported": [_I, _I, _I],
+    "gn_eqff_fused_forward": [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P],
+    "gn_eqff_fused_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P],
     "gn_edge_tiles_cap": [_I, _L],
     "gn_edge_tiles": [_P, _I, _I, _P, _P, _P],
     "gn_message_fused_supported": [_I, _I, _I, _I, _I, _I],

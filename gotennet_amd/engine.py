@@ -134,6 +134,8 @@ class Config:
     emlp: int = 0             # emlp_dim: hidden width of the 2-layer gamma_t (0 = F)
     gemm_mode: str = ""       # projection arithmetic of THIS model ("f16x2" | "split" | "f32"; "" = engine.GEMM_MODE, the default)
     sliced: bool = False      # run lmax <= 4 on the degree-sliced kernel family too (GN_LMAX_SLICED in the lmax argument)
+    fuse_eqff: bool = False   # the node-local EQFF chain as ONE kernel each way where covered (eqff_fused_ok); opt-in: a wash
+                              # against the launch sequence on MI355X (-0.5 % ... +0.5 % on the step)
     fuse_message: bool = False  # inference (nothing saved): edge projection + softmax + message as ONE kernel (gn_message_fused,
                                 # no [E,(1+M)F] stream); opt-in: measured 2-10 % slower than the three kernels
 
@@ -416,6 +418,7 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
     lde = (1 + M) * F_
     nact, g1act = new(N, 4 * F_), new(N, F_)       # activated copies (scratch, shared by all layers)
     fused = (not save) and trace is None and E > 0 and fused_message_ok(cfg)
+    eq_fused, eq_arith = eqff_fused_ok(cfg), (1 if proj.mode == "split" else 2)
     if not save:                                   # inference: ping-pong work buffers, reused by every layer
         h2, X2, t2 = new(N, F_), new(N, D, F_), new(E, F_)
         nproj, xs, vs = new(N, 4 * F_), new(N, M * F_), new(N, M * F_)
@@ -485,11 +488,18 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
                                        rowmap=(cnt, D, off)))
                     off += cnt
         gemm_group(xprods)
-        # ---- EQFF context (731-735) and HTR edge weights (561-611); then the first gamma_m layer rides in the
-        # launch of the edge-sized gamma_t product
-        call("gn_eqff_context", ptr(h), ptr(Xp), float(cfg.eps), N, F_, D, ptr(ctx), _stream())
-        m0 = dict(A=ctx, lda=2 * F_, W=lw.Wm0, bias=lw.bm0, C=g1act, ldc=F_, rows=N, nout=F_, K=2 * F_, act=(0, F_),
-                  pre_out=pre_g1 if save else None)
+        # ---- EQFF (731-746) and HTR edge weights (561-611).  Where covered the EQFF chain after X_p is ONE kernel
+        # (context, both gamma_m layers, update); else: context kernel, the first gamma_m layer riding in the launch of the
+        # edge-sized gamma_t product, the second layer, update kernel
+        m0 = None
+        if eq_fused:
+            call("gn_eqff_fused_forward", ptr(Xp), ptr(split_weight(lw.Wm0, proj.mode)), ptr(lw.bm0),
+                 ptr(split_weight(lw.Wm1, proj.mode)), ptr(lw.bm1), float(cfg.eps), N, F_, D, ptr(h), ptr(X),
+                 ptr(ctx) if save else None, ptr(pre_g1) if save else None, ptr(mm) if save else None, eq_arith, _stream())
+        else:
+            call("gn_eqff_context", ptr(h), ptr(Xp), float(cfg.eps), N, F_, D, ptr(ctx), _stream())
+            m0 = dict(A=ctx, lda=2 * F_, W=lw.Wm0, bias=lw.bm0, C=g1act, ldc=F_, rows=N, nout=F_, K=2 * F_, act=(0, F_),
+                      pre_out=pre_g1 if save else None)
         if not last:
             call("gn_htr_edge", ptr(EQ), ptr(EK), ptr(g.rl), ptr(g.rowptr), ptr(g.src), N, Fe, cfg.lmax_arg, cfg.htr_mode,
                  ptr(lt.w_raw) if save else None, ptr(w), _stream())
@@ -504,8 +514,9 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
             t, t2 = t2, t
         else:
             gemm_group([m0])
-        gemm(g1act, F_, lw.Wm1, lw.bm1, mm, 2 * F_, N, 2 * F_, F_)
-        call("gn_eqff_update", ptr(mm), ptr(Xp), N, F_, D, ptr(h), ptr(X), _stream())
+        if not eq_fused:
+            gemm(g1act, F_, lw.Wm1, lw.bm1, mm, 2 * F_, N, 2 * F_, F_)
+            call("gn_eqff_update", ptr(mm), ptr(Xp), N, F_, D, ptr(h), ptr(X), _stream())
         if trace is not None:
             trace.append((h.clone(), X.clone(), t.clone()))
     return h, X, tape
@@ -605,6 +616,15 @@ def message_stage(cfg: Config, g: "Graph", nact, xs, vs, eproj, attn, h, X, h2, 
     call("gn_message_aggregate", ptr(xs), ptr(vs), M * F_, eproj.data_ptr() + 4 * F_, lde,
          ptr(attn), ptr(g.rl), ptr(g.cut), ptr(g.rowptr), ptr(g.src),
          ptr(h), ptr(X), ptr(h2), ptr(X2), g.N, F_, H, cfg.lmax_arg, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
+
+
+def eqff_fused_ok(cfg: Config) -> bool:
+    """The EQFF chains run as one kernel each way (gn_eqff_fused_forward / _backward): F in {128, 256}, SiLU, a plane
+    arithmetic; everything else keeps the launch sequence."""
+    mode = resolve_mode(cfg.gemm_mode)
+    if not cfg.fuse_eqff or mode not in _PLANE_MODES:
+        return False
+    return bool(_lib.load().gn_eqff_fused_supported(cfg.F, cfg.act, 1 if mode == "split" else 2))
 
 
 def fused_message_ok(cfg: Config) -> bool:
@@ -730,6 +750,7 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
     new = lambda *shape: torch.empty(shape, **f32)
     colptr, perm = g.csc()
     lde = (1 + M) * F_
+    eq_fused, eq_arith = eqff_fused_ok(cfg), (1 if proj.mode == "split" else 2)
 
     # every contributing kernel writes its own slice; the geometry backward sums them in a fixed order
     L = len(pw.layers)
@@ -755,10 +776,16 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
         lw, lt = pw.layers[li], tape.layers[li]
         last = lw.Wt is None
         first = zero_X_in(cfg, li)
-        # ---- EQFF backward, first half; HTR backward kernels (independent of it)
-        call("gn_eqff_backward_a", ptr(gh), ptr(gX), ptr(lt.mm), ptr(lt.Xp), N, F_, D, ptr(gm), ptr(gXp), _stream())
-        m1 = dict(A=gm, lda=2 * F_, W=_T(lw, "Wm1"), C=g_g1, ldc=F_, rows=N, nout=F_, K=2 * F_,
-                  dgate=lt.pre_g1)                 # * SiLU'(pre) in the epilogue
+        # ---- EQFF backward (one kernel where covered; else its first half here); HTR backward kernels (independent of it)
+        m1 = None
+        if eq_fused:
+            call("gn_eqff_fused_backward", ptr(gh), ptr(gX), ptr(lt.mm), ptr(lt.Xp), ptr(lt.ctx), ptr(lt.pre_g1),
+                 ptr(split_weight(_T(lw, "Wm1"), proj.mode)), ptr(split_weight(_T(lw, "Wm0"), proj.mode)), N, F_, D,
+                 ptr(gXp), ptr(gh1), eq_arith, _stream())
+        else:
+            call("gn_eqff_backward_a", ptr(gh), ptr(gX), ptr(lt.mm), ptr(lt.Xp), N, F_, D, ptr(gm), ptr(gXp), _stream())
+            m1 = dict(A=gm, lda=2 * F_, W=_T(lw, "Wm1"), C=g_g1, ldc=F_, rows=N, nout=F_, K=2 * F_,
+                      dgate=lt.pre_g1)             # * SiLU'(pre) in the epilogue
         if not last:
             if gt is None:
                 raise RuntimeError("internal: missing edge gradient")
@@ -779,8 +806,9 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
             gemm_group([m1])
             gt_in = gt                             # no edge update in this layer: t passes through unchanged
         # ---- EQFF backward, second half
-        gemm(g_g1, F_, _T(lw, "Wm0"), None, g_ctx, 2 * F_, N, 2 * F_, F_)
-        call("gn_eqff_backward_b", ptr(g_ctx), ptr(lt.ctx), ptr(lt.Xp), ptr(gh), N, F_, D, ptr(gXp), ptr(gh1), _stream())
+        if not eq_fused:
+            gemm(g_g1, F_, _T(lw, "Wm0"), None, g_ctx, 2 * F_, N, 2 * F_, F_)
+            call("gn_eqff_backward_b", ptr(g_ctx), ptr(lt.ctx), ptr(lt.Xp), ptr(gh), N, F_, D, ptr(gXp), ptr(gh1), _stream())
         # ---- gX1 = gX + gXp W_vu (+ gEQ W_vq + gEK_l W_vk_l)
         joint = bool(cfg.htr_mode & 1)
         if last:

@@ -230,6 +230,24 @@ int gn_message_aggregate(const float* x, const float* v, int ldxv, const float* 
                          const float* h_in, const float* X_in, float* h_out, float* X_out,
                          int N, int F, int H, int lmax, int sep_dir, int sep_tensor, void* stream);
 
+/* ---- EQFF node chains as one kernel each (gotennet.py:716-748 after X_p = X W_vu^T) ------------------------------ */
+/* Forward: n = sqrt(sum_D X_p^2 + eps); [m1 | m2] = W_1 SiLU(W_0 [h | n] + b_0) + b_1; h += m1; X += m2 * X_p -- the
+ * sequence gn_eqff_context -> gn_gemm(gamma_m.0) -> gn_gemm(gamma_m.1) -> gn_eqff_update as ONE launch (16 atoms per
+ * workgroup, both products on MFMA in the plane arithmetics, W0p / W1p = planes written by gn_split_bf16x3 /
+ * gn_split_f16x2 of gamma_m.0.weight [F, 2F] and gamma_m.1.weight [2F, F]).  ctx_out [N,2F], pre_out [N,F] (the
+ * pre-activation of the hidden layer), mm_out [N,2F]: what the backward needs, or NULL.
+ * Backward: gn_eqff_backward_a -> W_1^T -> W_0^T -> gn_eqff_backward_b as one launch: given g_h, g_X [N,D,F] of the
+ * block's outputs returns g_Xp [N,D,F] (gradient w.r.t. X_p, not yet through W_vu) and g_h1 = g_h + d/dh through gamma_m;
+ * W1Tp / W0Tp = planes of the TRANSPOSED weights ([F, 2F] and [2F, F]).  g_Xp must not alias g_X.
+ * Supported: F in {128, 256}, SiLU, arith 1 (3 x bf16) or 2 (2 x fp16); otherwise callers keep the launch sequence. */
+int gn_eqff_fused_supported(int F, int act, int arith);
+int gn_eqff_fused_forward(const float* Xp, const void* W0p, const float* b0, const void* W1p, const float* b1,
+                          float eps, int N, int F, int D, float* h, float* X,
+                          float* ctx_out, float* pre_out, float* mm_out, int arith, void* stream);
+int gn_eqff_fused_backward(const float* gh, const float* gX, const float* mm, const float* Xp, const float* ctx,
+                           const float* pre_g1, const void* W1Tp, const void* W0Tp, int N, int F, int D,
+                           float* gXp, float* gh1, int arith, void* stream);
+
 /* ---- K5 + K6 fused: the message stage without the [E, (1+M)F] edge-projection stream (inference) ------------- */
 /* The reference materialises t_attn | t_filter = [W_re; W_rs] t_ij + b per edge (gotennet.py:406-407) and consumes it in
  * `message` / `aggregate` (452-559, 613-640).  When nothing is kept for a backward that stream need not exist:

@@ -196,3 +196,54 @@ def test_energy_only_step_uses_fused_kernel_and_matches_force_step():
     torch.cuda.synchronize()
     assert rel_err(e1.cpu(), e0.cpu()) < 5e-6 and rel_err(e2.cpu(), e0.cpu()) < 5e-6
     assert rel_err(e1.cpu(), t["energy"]) < TOL
+
+
+# ------------------------------------------------------------------------------------------ EQFF chains as one kernel
+@pytest.mark.parametrize("mode", ["f16x2", "split"])
+@pytest.mark.parametrize("name", ["c1_qm9_small_seeded", "c2_model_3mol_seeded", "c2_model_lmax4_1mol_seeded"])
+def test_eqff_fused_kernels_match_golden_and_sequence(name, mode):
+    """gn_eqff_fused_forward / _backward (context -> gamma_m.0 -> gamma_m.1 -> update, and the input-gradient chain, one
+    kernel each; reference gotennet.py:716-748) on the full-width fixtures (F = 128 and 256; N = 19 / 63 / 21: not a
+    multiple of the 16-atom tile): (h, X), energies and forces against the reference, and against the launch sequence
+    (`fuse_eqff = False`) within fp32 re-association."""
+    from tests.test_hip_forces import _head_from_case
+    from tests.test_hip_parity import _net_from_case
+    from gotennet_amd import engine
+    from gotennet_amd.pipeline import EnergyForces
+    cfg, sd, head_sd, t = load_case(name)
+    net, head = _net_from_case(cfg, sd), _head_from_case(cfg, head_sd)
+    net.gemm_mode = mode
+    args = [t[k].cuda() for k in ("z", "edge_index", "edge_diff", "edge_vec")]
+    out = {}
+    for fused in (True, False):
+        net.fuse_eqff = fused
+        assert engine.eqff_fused_ok(net.config()) == fused
+        h, X = net(*args)
+        e, f = EnergyForces(net, head)(*args, t["batch"].cuda(), cfg["n_mol"])
+        torch.cuda.synchronize()
+        out[fused] = [v.cpu() for v in (h, X, e, f)]
+    h, X, e, f = out[True]
+    assert rel_err(h, t["h"]) < TOL and rel_err(X, t["X"]) < TOL
+    assert rel_err(e, t["energy"]) < TOL and rel_err(f, t["forces"]) < TOL
+    for a, b in zip(out[True], out[False]):
+        assert rel_err(a, b) < 1e-5
+    net.fuse_eqff = True
+    e2, f2 = EnergyForces(net, head)(*args, t["batch"].cuda(), cfg["n_mol"])
+    assert torch.equal(e2.cpu(), e) and torch.equal(f2.cpu(), f)          # bit-reproducible
+
+
+def test_eqff_fused_falls_back_where_unsupported():
+    import gotennet_amd
+    from gotennet_amd import engine
+    mk = lambda **kw: gotennet_amd.GotenNet(cutoff_fn=gotennet_amd.CosineCutoff(5.0), n_interactions=1, n_rbf=8,
+                                            **{**dict(n_atom_basis=128, lmax=2), **kw})
+    ok = mk()
+    ok.gemm_mode = "f16x2"
+    assert not engine.eqff_fused_ok(ok.config())     # opt-in
+    ok.fuse_eqff = True
+    assert engine.eqff_fused_ok(ok.config())
+    ok.gemm_mode = "f32"
+    assert not engine.eqff_fused_ok(ok.config())
+    for bad in (mk(n_atom_basis=64), mk(n_atom_basis=512), mk(activation="tanh")):
+        bad.gemm_mode, bad.fuse_eqff = "f16x2", True
+        assert not engine.eqff_fused_ok(bad.config())
