@@ -394,12 +394,20 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G34) void message_aggregate_gro
 }
 
 // ------------------------------------------------------------------ K7 HTR edge weights
-// gotennet.py:351-364, 580-609 (sep_htr, rejection on): literal two-rejection form.
+// gotennet.py:351-364, 580-609 (sep_htr, rejection on).  LMAX <= 2: the literal two-rejection form
+//   w_l = sum_m (EQ - (EQ.r) r)_m (EK - (EK.r) r)_m.
+// LMAX == 3 (GN_HTR_CLOSED): the algebraically equal closed form  w_l = EQ.EK - (2 - r.r)(EQ.r)(EK.r)  -- 3 instead of 5
+// float4 FMAs per row and no second pass over the rows (the form gn_options.hip uses for the non-default variants);
+// r.r is not 1 for the reference's degree 3 (and 0 on self-loops), so it is carried.  Rounding differs from the literal
+// form at the 1e-7 level.  Measured (round 4, in the step): lmax 3 (C5) 98.0 -> 90.5 us (126 VGPRs, 4 waves/SIMD instead
+// of 132 / 3); lmax 4 LOSES, 105.9 -> 140.4 us at the same 2 waves/SIMD (the literal form keeps all 24 row loads of an
+// edge in flight; the closed form's schedule does not), so lmax 4 keeps the literal form.
 template <int LMAX>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_EDGE) void htr_edge_kernel(
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
     const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F, float* __restrict__ w) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
+    constexpr bool CLOSED = LMAX == 3 && GN_HTR_CLOSED;
     const int i = xcd_item(blockIdx.x, N);
     if (i < 0) return;
     const int lps = F >> 2, ns = 256 / lps;
@@ -415,22 +423,39 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_EDGE) void htr_edge_kernel(
         int m0 = 0;
 #pragma unroll
         for (int l = 1; l <= LMAX; ++l) {
-            constexpr int dummy = 0; (void)dummy;
             float4 ek[2 * LMAX + 1];
             float r[2 * LMAX + 1];
             float4 pq = zero4(), pk = zero4();
+            if constexpr (CLOSED) {
+                float4 ab = zero4();
+                float rr = 0.f;
 #pragma unroll
-            for (int mm = 0; mm < 2 * l + 1; ++mm) {
-                ek[mm] = ld4(kj + (size_t)(m0 + mm) * F);
-                r[mm] = re[m0 + mm];
-                pq = fma4(r[mm], eq[m0 + mm], pq);
-                pk = fma4(-r[mm], ek[mm], pk);
-            }
+                for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                    ek[mm] = ld4(kj + (size_t)(m0 + mm) * F);
+                    r[mm] = re[m0 + mm];
+                }
 #pragma unroll
-            for (int mm = 0; mm < 2 * l + 1; ++mm) {
-                const float4 a_ = eq[m0 + mm] + pq * (-r[mm]);       // EQ - proj * rl
-                const float4 b_ = ek[mm] + pk * r[mm];               // EK - proj' * (-rl)
-                wsum = fma4(a_, b_, wsum);
+                for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                    rr = fmaf(r[mm], r[mm], rr);
+                    pq = fma4(r[mm], eq[m0 + mm], pq);
+                    pk = fma4(r[mm], ek[mm], pk);
+                    ab = fma4(eq[m0 + mm], ek[mm], ab);
+                }
+                wsum = wsum + (ab + (pq * pk) * (rr - 2.0f));
+            } else {
+#pragma unroll
+                for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                    ek[mm] = ld4(kj + (size_t)(m0 + mm) * F);
+                    r[mm] = re[m0 + mm];
+                    pq = fma4(r[mm], eq[m0 + mm], pq);
+                    pk = fma4(-r[mm], ek[mm], pk);
+                }
+#pragma unroll
+                for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                    const float4 a_ = eq[m0 + mm] + pq * (-r[mm]);       // EQ - proj * rl
+                    const float4 b_ = ek[mm] + pk * r[mm];               // EK - proj' * (-rl)
+                    wsum = fma4(a_, b_, wsum);
+                }
             }
             m0 += 2 * l + 1;
         }

@@ -75,6 +75,9 @@
 #ifndef GN_GEMM_NT_LO
 #define GN_GEMM_NT_LO (-1)     // ... from this column on (-1: the first K columns stay on the normal path)
 #endif
+#ifndef GN_HTR_CLOSED
+#define GN_HTR_CLOSED 1        // htr_edge_kernel at lmax = 3: closed form EQ.EK - (2 - r.r)(EQ.r)(EK.r) instead of two rejections
+#endif
 #ifndef GN_ATTN_WAVE
 #define GN_ATTN_WAVE 1         // 1: one wave per target in gn_attn_softmax where the shape allows; 0: workgroup per target
 #endif
