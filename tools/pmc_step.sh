@@ -20,8 +20,8 @@ t = collections.defaultdict(dict)
 for line in open("gpurun_out/pmc_step_raw.txt"):
     m = re.match(r"^(.*?)\s+(\S+)\s+avg=\s*([\d.]+)", line)
     if not m: continue
-    k = re.sub(r"\(.*", "", m.group(1)).replace("void ", "").replace("gn::", "")[:34]
-    if not re.search(r"msg_bwd|message_aggregate|htr_|attn_", k): continue
+    k = re.sub(r"\(.*", "", m.group(1)).replace("void ", "").replace("gn::", "")[:48]
+    if not re.search(r"msg_bwd|message_aggregate|htr_|attn_|gemm_f16x2", k): continue
     t[k][m.group(2)] = float(m.group(3))
 names = sorted({c for v in t.values() for c in v})
 for k, v in t.items():
