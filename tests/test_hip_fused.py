@@ -53,13 +53,12 @@ def test_edge_tiles_partition_the_targets(kind):
 def _fused_vs_sequence(net, z, ei, ed, ev):
     """(h, X) from the fused kernel and from the three-kernel sequence of the same model."""
     from gotennet_amd import engine
+    net.fuse_message = True                          # opt-in (DESIGN.md 5.0)
     assert engine.fused_message_ok(net.config())
-    net.fuse_message = True
     h1, X1 = net(z, ei, ed, ev)
     net.fuse_message = False
     assert not engine.fused_message_ok(net.config())
     h0, X0 = net(z, ei, ed, ev)
-    net.fuse_message = True
     torch.cuda.synchronize()
     return (h1, X1), (h0, X0)
 
@@ -81,6 +80,7 @@ def test_fused_matches_golden_and_sequence(name, mode):
     e_ref = max(rel_err(t["h"], t["h_f64"]), rel_err(t["X"], t["X_f64"]))
     e_hip = max(rel_err(h1.cpu(), t["h_f64"]), rel_err(X1.cpu(), t["X_f64"]))
     assert e_hip < max(10 * e_ref, 1e-5)
+    net.fuse_message = True
     h2, X2 = net(*args)                              # bit-reproducible (fixed-order reductions, no atomics)
     assert torch.equal(h1, h2) and torch.equal(X1, X2)
 
