@@ -90,7 +90,7 @@ SIGNATURES = {
     "gn_edge_gate_backward": [_P, _P, _I, _P, _L, _P, _P, _P],
     "gn_edge_geometry_backward": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _I, _P, _I, _P, _P, _P, _P],
     "gn_pos_scatter": [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P],
-    "gn_head_energy": [_P, _P, _F, _F, _F, _P, _P, _P, _I, _I, _P, _P, _I, _P, _I, _P],
+    "gn_head_energy": [_P, _P, _F, _F, _F, _F, _P, _P, _P, _I, _I, _P, _P, _I, _P, _I, _P],
     "gn_head_grad": [_P, _P, _F, _P, _I, _I, _P, _I, _P],
     "gn_geb_context": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P],
     "gn_geb_gate": [_P, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P],

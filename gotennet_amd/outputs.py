@@ -151,6 +151,7 @@ class Atomwise(nn.Module):
         mean = self.aggregation_mode == "mean"
         atom_scale = new(N) if mean else None
         call("gn_head_energy", ptr(last_in), ptr(c["w"][-1]), c["b2"], 1.0 if raw else c["scale"], 0.0 if raw else c["shift"],
+             0.0 if raw else c.get("mol_shift", 0.0),
              ptr(self.atomref.weight.detach()) if (self.atomref is not None and not raw) else None, ptr(z32), ptr(mol_ptr),
              n_mol, last_in.shape[1], ptr(y), ptr(e), int(mean), ptr(atom_scale), act, engine._stream())
         return e, y, (pres, last_in, atom_scale)
@@ -171,6 +172,10 @@ class Atomwise(nn.Module):
                         dgate=pres[k - 1] if k > 0 else None, kind=self.act_kind, mode=mode)
             g = gi
         return g
+
+    def _per_atom_property(self, e: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """aggregation_mode=None: the property IS the per-atom contributions."""
+        return y.reshape(-1, 1).clone()
 
     # ---- reference-style call --------------------------------------------------------
     def forward(self, inputs):
@@ -195,13 +200,49 @@ class Atomwise(nn.Module):
         return result
 
 
+class AtomwiseV3(Atomwise):
+    """Reference ``AtomwiseV3`` (outputs.py:96-229) for ``n_out = 1`` with the default ``out_net``: like ``Atomwise`` but the
+    per-atom values are only SCALED (``y_i = MLP(h_i) * stddev [+ atomref]``) and ``mean`` is added AFTER the aggregation
+    (``y = agg(y_i) + mean``; with ``aggregation_mode=None`` per atom), and -- as in the reference -- the arithmetic reads the
+    constructor's ``mean`` / ``stddev`` ATTRIBUTES, not the ``standardize`` buffers it also registers (those only carry
+    the ``state_dict`` keys).  Same kernels: ``gn_head_energy`` with ``shift = 0`` and ``mol_shift = mean``."""
+
+    def __init__(self, n_in: int, n_out: int = 1, aggregation_mode: Optional[str] = "sum", n_layers: int = 2,
+                 n_hidden: Optional[int] = None, activation=shifted_softplus, property: str = "y",
+                 contributions: Optional[str] = None, derivative: Optional[str] = None, negative_dr: bool = True,
+                 create_graph: bool = True, mean=None, stddev=None, atomref=None, outnet=None,
+                 return_vector: Optional[str] = None, standardize: bool = True):
+        mean = 0.0 if mean is None else mean
+        stddev = 1.0 if stddev is None else stddev
+        as_t = lambda v: v if isinstance(v, torch.Tensor) else torch.tensor([float(v)])
+        super().__init__(n_in, n_out, aggregation_mode, n_layers, n_hidden, activation, property, contributions,
+                         derivative, negative_dr, create_graph, as_t(mean), as_t(stddev), atomref, outnet, return_vector,
+                         standardize)
+        self.mean, self.stddev = mean, stddev
+
+    def _packed(self):
+        layers, c = super()._packed()
+        f = lambda v: float(v.reshape(-1)[0]) if isinstance(v, torch.Tensor) else float(v)
+        c = dict(c, scale=f(self.stddev), shift=0.0, mol_shift=f(self.mean))
+        return layers, c
+
+    def energy_raw(self, h, z32, mol_ptr, n_mol, raw: bool = False, mode: Optional[str] = None):
+        if self.aggregation_mode is None and not raw:        # y_n + mean per atom: every atom is its own segment
+            N = h.shape[0]
+            mol_ptr, n_mol = torch.arange(N + 1, dtype=torch.int32, device=h.device), N
+        return super().energy_raw(h, z32, mol_ptr, n_mol, raw=raw, mode=mode)
+
+    def _per_atom_property(self, e, y):
+        return e.reshape(-1, 1)
+
+
 class _AtomwiseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, head, z32, mol_ptr, n_mol):
         e, y, tape = head.energy_raw(h.detach().contiguous(), z32, mol_ptr, n_mol)
         head._last_y = y
         ctx.head, ctx.mol_ptr, ctx.n_mol, ctx.F, ctx.tape = head, mol_ptr, n_mol, h.shape[1], tape
-        return y.reshape(-1, 1).clone() if head.aggregation_mode is None else e
+        return head._per_atom_property(e, y) if head.aggregation_mode is None else e
 
     @staticmethod
     def backward(ctx, ge):

@@ -387,9 +387,11 @@ int gn_pos_scatter(const float* g_vec, const float* g_diff, const float* edge_ve
                    float* out, void* stream);
 
 /* ---- K10 energy head (Atomwise, outputs.py:323-376; SchnetMLP layers.py:225-273, 2 layers, SiLU) ------- */
-/* y_n = scale * (sum_k SiLU(pre1[n,k]) W2[k] + b2) + shift (+ atomref[z_n]); energy[b] = sum_{n in molecule b} y_n.
+/* y_n = scale * (sum_k SiLU(pre1[n,k]) W2[k] + b2) + shift (+ atomref[z_n]); energy[b] = sum_{n in molecule b} y_n + mol_shift.
+ * Atomwise (outputs.py:323-376) standardises per atom: scale = stddev, shift = mean, mol_shift = 0.  AtomwiseV3
+ * (outputs.py:96-229) scales per atom and adds its mean AFTER the aggregation: scale = stddev, shift = 0, mol_shift = mean.
  * pre1 = W1 h + b1 comes from gn_gemm.  mol_ptr [n_mol+1] int32.  head_grad: g_pre1 = scale W2 SiLU'(pre1). */
-int gn_head_energy(const float* pre1, const float* W2, float b2, float scale, float shift,
+int gn_head_energy(const float* pre1, const float* W2, float b2, float scale, float shift, float mol_shift,
                    const float* atomref, const int* z, const int* mol_ptr, int n_mol, int Hd,
                    float* y, float* energy, int mean /* aggregation_mode "mean": energy / atoms of the molecule */,
                    float* atom_scale /* [N] or NULL: d energy / d y_n (1 or 1 / atoms) for gn_head_grad */,

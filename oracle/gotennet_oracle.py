@@ -572,6 +572,31 @@ def atomwise_energy(head: Dict[str, Tensor], h: Tensor, batch: Tensor, n_mol: in
     return out
 
 
+def atomwise_v3(head: Dict[str, Tensor], h: Tensor, batch: Tensor, n_mol: int, mean: float, stddev: float,
+                activation: str = "silu", z: Optional[Tensor] = None, aggregation: Optional[str] = "sum"):
+    """AtomwiseV3.forward (outputs.py:186-229): y_i = MLP(h_i) * stddev [+ atomref[z_i]] (191-196); y = scatter(y_i, batch,
+    reduce) or y_i (198-201); y = y + mean AFTER the aggregation (203).  ``mean`` / ``stddev`` are the constructor's
+    attributes (153-157), not the ``standardize`` buffers.  -> (y, y_i)."""
+    act = activation_of(activation)
+    n = 0
+    while f"out_net.1.out_net.{n}.weight" in head:
+        n += 1
+    yi = h
+    for k in range(n):
+        yi = F.linear(yi, head[f"out_net.1.out_net.{k}.weight"], head[f"out_net.1.out_net.{k}.bias"])
+        if k + 1 < n:
+            yi = act(yi)
+    yi = yi * stddev
+    if "atomref.weight" in head:
+        yi = yi + head["atomref.weight"][z]
+    if aggregation is None:
+        return yi + mean, yi
+    y = torch.zeros((n_mol, yi.shape[1]), dtype=yi.dtype).index_add_(0, batch, yi)
+    if aggregation == "mean":
+        y = y / torch.bincount(batch, minlength=n_mol).clamp(min=1).to(yi.dtype).unsqueeze(1)
+    return y + mean, yi
+
+
 def energy_and_forces(sd, cfg, head, z, pos, batch, n_mol, max_num_neighbors: int = 32,
                       activation: str = "silu", aggregation: str = "sum"):
     """GotenNetWrapper.forward (gotennet.py:1043-1045) + Atomwise with

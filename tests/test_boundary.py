@@ -605,3 +605,58 @@ def test_energy_forces_replays_static_topology_bit_identically():
     assert rep._graph_state is not None
     rep.clear_cache()
     assert rep._graph_state is None and rep._topo is None
+
+
+# --------------------------------------------------------------------------------------------------- AtomwiseV3
+def _head_kat_v3():
+    k = np.load(os.path.join(GOLDEN_DIR, "kat_head_v3.npz"))
+    t = {n: torch.from_numpy(k[n]) for n in k.files if not n.startswith("head/")}
+    hsd = {n[5:]: torch.from_numpy(k[n]) for n in k.files if n.startswith("head/")}
+    return t, hsd
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "none"])
+def test_oracle_atomwise_v3_matches_reference_kat(agg):
+    """The oracle's AtomwiseV3 restatement (scale per atom, mean added after the aggregation; outputs.py:186-229) against
+    the reference's own module, all three aggregation modes."""
+    from oracle import gotennet_oracle as orc
+    t, hsd = _head_kat_v3()
+    y, yi = orc.atomwise_v3(hsd, t["h"], t["batch"], int(t["n_mol"]), float(t["mean"]), float(t["stddev"]), z=t["z"],
+                            aggregation=None if agg == "none" else agg)
+    assert rel_err(y, t[f"energy_{agg}"]) < 1e-6 and rel_err(yi, t[f"contrib_{agg}"]) < 1e-6
+
+
+def test_atomwise_v3_state_dict_keys_match_reference():
+    from gotennet_amd.outputs import AtomwiseV3
+    t, hsd = _head_kat_v3()
+    head = AtomwiseV3(n_in=64, n_hidden=32, activation="silu", mean=1.7, stddev=0.35, atomref=t["atomref"])
+    assert set(head.state_dict().keys()) == set(hsd.keys())
+    head.load_state_dict(hsd, strict=True)
+    with pytest.raises(NotImplementedError):
+        AtomwiseV3(n_in=64, n_out=3)
+
+
+@pytest.mark.gpu
+@pytest.mark.usefixtures("gemm_mode")
+@pytest.mark.parametrize("agg", ["sum", "mean", "none"])
+def test_atomwise_v3_matches_reference_kat(agg):
+    """gotennet_amd.outputs.AtomwiseV3 through the reference-style call (``inputs.z/.batch/.pos/.representation``): property
+    and contributions of the reference's AtomwiseV3, and d(property)/d(representation) against the oracle's autograd."""
+    from gotennet_amd.outputs import AtomwiseV3
+    from oracle import gotennet_oracle as orc
+    t, hsd = _head_kat_v3()
+    aggregation = None if agg == "none" else agg
+    head = AtomwiseV3(n_in=64, n_hidden=32, activation="silu", property="property", contributions="contrib", mean=1.7,
+                      stddev=0.35, atomref=t["atomref"], aggregation_mode=aggregation)
+    head.load_state_dict(hsd, strict=True)
+    head = head.cuda().eval()
+    h = t["h"].cuda().requires_grad_(True)
+    res = head(dict(z=t["z"].cuda(), batch=t["batch"].cuda(), pos=None, representation=h))
+    assert rel_err(res["property"].detach().cpu(), t[f"energy_{agg}"]) < TOL
+    assert rel_err(res["contrib"].detach().cpu(), t[f"contrib_{agg}"]) < TOL
+    (gh,) = torch.autograd.grad(res["property"].sum(), h)
+    h64 = t["h"].double().requires_grad_(True)
+    y64, _ = orc.atomwise_v3({k: v.double() if v.is_floating_point() else v for k, v in hsd.items()}, h64, t["batch"],
+                             int(t["n_mol"]), 1.7, 0.35, z=t["z"], aggregation=aggregation)
+    (g64,) = torch.autograd.grad(y64.sum(), h64)
+    assert rel_err(gh.cpu(), g64) < TOL

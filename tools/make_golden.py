@@ -538,6 +538,21 @@ def head_kat():
         out3["head/" + k] = v.numpy()
     np.savez_compressed(os.path.join(OUT, "kat_head_l3_mean_ssp.npz"), **out3)
     print("kat_head_l3_mean_ssp written:", [tuple(v.shape) for k, v in head3.state_dict().items() if k.endswith("weight")])
+    # AtomwiseV3 (outputs.py:96-229): scale per atom, mean added AFTER the aggregation; "sum", "mean" and None
+    outv = dict(h=h.numpy(), z=z.numpy(), batch=batch.numpy(), n_mol=np.array(n_mol), atomref=atomref.numpy(),
+                mean=np.array(1.7), stddev=np.array(0.35))
+    for tag, agg in (("sum", "sum"), ("mean", "mean"), ("none", None)):
+        hv = ref_out.AtomwiseV3(n_in=F_, n_hidden=Hd, activation=torch.nn.functional.silu, property="property",
+                                contributions="contrib", mean=1.7, stddev=0.35, atomref=atomref, aggregation_mode=agg)
+        randomise(hv, 4300)
+        with torch.no_grad():
+            resv = hv(_D(z=z, batch=batch, representation=h, vector_representation=None))
+        outv[f"energy_{tag}"] = resv["property"].numpy()
+        outv[f"contrib_{tag}"] = resv["contrib"].numpy()
+        for k, v in hv.state_dict().items():
+            outv["head/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "kat_head_v3.npz"), **outv)
+    print("kat_head_v3 written:", sorted(k for k in outv if not k.startswith("head/")))
 
 
 def qm9_heads_kat():
