@@ -145,7 +145,9 @@ def compact_line(full):
                                 "energy_checksum", "launch_mode") if k in full}
     out["roofline"] = _roof_compact(full.get("roofline"))
     if out["roofline"] is not None:
-        out["roofline"]["traffic_source"] = "committed profiles/pmc_traffic.json (rocprofv3 --pmc; FETCH_SIZE x2 + WRITE_SIZE)"
+        live = str((full.get("roofline") or {}).get("traffic_source", "")).startswith("measured in this run")
+        out["roofline"]["traffic_source"] = ("live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE sub-runs of this bench (2 x FETCH + WRITE)"
+                                             if live else "committed profiles/pmc_traffic.json (rocprofv3 --pmc; FETCH_SIZE x2 + WRITE_SIZE)")
     for k in ("roofline_gather_scatter", "roofline_htr_edge", "roofline_message_backward"):
         if k in full:
             out[k] = _roof_compact(full[k])
@@ -214,6 +216,8 @@ def main():
     ap.add_argument("--no-forward-only", action="store_true", help="skip the energy-only (no force backward) side measurement")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (path check)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the short C3 / C5 side measurements")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="take roofline.traffic from the committed PMC passes instead of two rocprofv3 sub-runs of this script")
     ap.add_argument("--replay", action="store_true", help="hipGraph replay of the static-topology step (EnergyForces(replay=True)) instead of eager launches")
     ap.add_argument("--full-json", default=None,
                     help="where the FULL record goes (default: gpurun_out/bench_full.json next to this file, when that "
@@ -308,6 +312,11 @@ def worker(a):
         dist.init_process_group("nccl", device_id=dev)
 
     from gotennet_amd import engine
+    if world == 1 and rank == 0 and not a.no_live_traffic and not a.force_dist:
+        # BEFORE this process touches the GPU's counters itself: the sub-runs profile the same headline workload
+        lt = live_traffic(a)
+        if lt:
+            LIVE_TRAFFIC.update(lt, _key=(a.workload, a.batch, a.lmax))
     res = measure(a, a.workload, a.batch, a.lmax, a.steps, a.warmup, rank, world, dev, dist)
     sides = world == 1                              # side measurements only on the single-GPU line
     side = lat = lat_batch = None
@@ -726,14 +735,95 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
                                                                        "us_per_launch", "algorithmic_bytes_per_launch", "traffic")}
                                          if out[k] else None)
                                      for k in ("roofline_gather_scatter", "roofline_htr_edge", "roofline_message_backward")}
-        out["roofline"]["traffic_source"] = ("committed rocprofv3 --pmc passes of this workload (profiles/pmc_traffic.json, "
-                                             "FETCH_SIZE x2 + WRITE_SIZE per the gfx950 note), not re-measured in this run")
+        live = LIVE_TRAFFIC.get("_key") == (workload, B, lmax)
+        out["roofline"]["traffic_source"] = (
+            "measured in this run: two rocprofv3 --kernel-trace --pmc sub-runs of this script (FETCH_SIZE, WRITE_SIZE; "
+            "2 x FETCH + WRITE KiB per the gfx950 note), per-launch averages" if live else
+            "committed rocprofv3 --pmc passes of this workload (profiles/pmc_traffic.json, FETCH_SIZE x2 + WRITE_SIZE per "
+            "the gfx950 note), not re-measured in this run")
     return {"out": out, "rep": rep, "head": head}
+
+
+#: HBM bytes per launch measured IN THIS RUN (tag -> bytes), filled by live_traffic() before the headline record is built
+LIVE_TRAFFIC = {}
+
+
+def _pmc_counter_table(db_path, counter):
+    """kernel name -> (average counter value per dispatch, dispatches) from a rocprofv3 rocpd database."""
+    import sqlite3
+    from collections import defaultdict
+    cur = sqlite3.connect(db_path).cursor()
+    cols = [d[1] for d in cur.execute("pragma table_info(counters_collection)")]
+    kcol = "kernel_name" if "kernel_name" in cols else "name"
+    acc = defaultdict(lambda: [0.0, 0])
+    for k, cn, v in cur.execute(f"select {kcol}, counter_name, value from counters_collection"):
+        if cn == counter:
+            acc[k][0] += v
+            acc[k][1] += 1
+    return {k: (sm / n, n) for k, (sm, n) in acc.items() if n}
+
+
+def _traffic_entry(f, w):
+    """Per-launch HBM bytes of the kernel families from the FETCH_SIZE / WRITE_SIZE tables of one workload:
+    (2 x FETCH_SIZE + WRITE_SIZE) KiB -- the counters are in KiB and on gfx950 FETCH_SIZE reports half the bytes of wide
+    coalesced reads (MI355X_MICROARCH.md, HBM section; tools/pmc_traffic.py applies the same rule to the committed passes)."""
+    byt = lambda k: int((2 * f[k][0] + w.get(k, (0.0, 0))[0]) * 1024)
+    msg = [k for k in f if "message_aggregate" in k]
+    soft = [k for k in f if "attn_softmax" in k]
+    htr = [k for k in f if "htr_edge" in k]
+    gem = [k for k in f if "gn::gemm_" in k]
+    mb = [k for k in f if "msg_bwd_" in k or "attn_bwd_kernel" in k]
+    if not (msg and soft and gem):
+        return {}
+    layers = f[soft[0]][1]                       # the softmax runs once per interaction: launches = layers x steps
+    out = {"gn_message_aggregate": int(sum(byt(k) * f[k][1] for k in msg) / layers), "gn_attn_softmax": byt(soft[0]),
+           "gn_gemm_family_avg": int(sum(byt(k) * f[k][1] for k in gem) / sum(f[k][1] for k in gem))}
+    if htr:
+        out["gn_htr_edge"] = int(sum(byt(k) * f[k][1] for k in htr) / max(f[k][1] for k in htr))
+    if mb:
+        out["gn_message_backward"] = int(sum(byt(k) * f[k][1] for k in mb) / layers)
+    out["message_stage"] = out["gn_message_aggregate"] + out["gn_attn_softmax"]
+    return out
+
+
+def live_traffic(a):
+    """`roofline.traffic` measured in this run: two rocprofv3 sub-runs of THIS script on the headline workload (separate
+    --pmc passes for FETCH_SIZE and WRITE_SIZE, --kernel-trace only: the combination the guide prescribes), two steps each,
+    read back from the rocpd databases.  Returns {} -- and the record falls back to the committed passes, labelled so --
+    when rocprofv3 is missing, fails or times out."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {}
+    tabs = {}
+    try:
+        with tempfile.TemporaryDirectory(prefix="gn_pmc_", dir="/tmp") as td:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(td, counter)
+                cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "r", "--", sys.executable,
+                       os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", str(a.batch),
+                       "--lmax", str(a.lmax), "--workload", a.workload, "--no-lmax4", "--no-split", "--no-graph",
+                       "--no-workloads", "--no-cpu-baseline", "--no-forward-only", "--no-live-traffic"]
+                env = dict(os.environ, TMPDIR="/tmp")
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=240, check=True)
+                dbs = [os.path.join(r, fn) for r, _, fns in os.walk(out) for fn in fns if fn.endswith("_results.db")]
+                if not dbs:
+                    return {}
+                tabs[counter] = _pmc_counter_table(dbs[0], counter)
+        return _traffic_entry(tabs["FETCH_SIZE"], tabs["WRITE_SIZE"])
+    except Exception as exc:                                   # noqa: BLE001 -- a measurement aid must never fail the bench
+        print(f"# live traffic pass failed ({type(exc).__name__}: {exc}); using the committed PMC passes", file=sys.stderr)
+        return {}
 
 
 def _pmc_traffic(tag, lmax, workload="rmd17_aspirin", batch=128):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), if present for this
     workload, batch and lmax."""
+    if LIVE_TRAFFIC.get("_key") == (workload, batch, lmax) and tag in LIVE_TRAFFIC:
+        return LIVE_TRAFFIC[tag]
     key = f"lmax{lmax}" if (workload == "rmd17_aspirin" and batch == 128) else f"{workload}_b{batch}_lmax{lmax}"
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
