@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("GN_LIB_PATH") or os.path.join(_PKG, "libgotennet_hip.
 GN_ERR_BAD_ARG = 10001
 ABI_VERSION = 7
 LMAX_SLICED = 0x100      # GN_LMAX_SLICED: OR-ed into the lmax argument of the message / HTR entry points
+LMAX_MEAN, LMAX_MAX = 0x200, 0x400      # GN_LMAX_MEAN / GN_LMAX_MAX: the reference's aggr = "mean" / "max" (message entries)
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 

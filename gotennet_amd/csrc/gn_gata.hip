@@ -535,9 +535,11 @@ extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, co
                                     const int* rowptr, const int* src,
                                     const float* h_in, const float* X_in, float* h_out, float* X_out,
                                     int N, int F, int H, int lmax_arg, int sep_dir, int sep_tensor, void* stream) {
-    const int lmax = lmax_arg & 0xff;               // GN_LMAX_SLICED may ride in the argument (gn_use_highl)
-    if ((lmax_arg & ~(0xff | GN_LMAX_SLICED)) || !feature_dim_ok(F) || N < 0 || H <= 0 || lmax < 1 || lmax > 8 ||
-        (ldxv & 3) || (ldt & 3) || X_in == X_out)
+    const int lmax = lmax_arg & 0xff;               // GN_LMAX_SLICED / _MEAN / _MAX may ride in the argument (gn_use_highl)
+    const int aggr = (lmax_arg & GN_LMAX_MEAN) ? 1 : ((lmax_arg & GN_LMAX_MAX) ? 2 : 0);
+    if ((lmax_arg & ~(0xff | GN_LMAX_SLICED | GN_LMAX_MEAN | GN_LMAX_MAX)) ||
+        ((lmax_arg & GN_LMAX_MEAN) && (lmax_arg & GN_LMAX_MAX)) || !feature_dim_ok(F) || N < 0 || H <= 0 || lmax < 1 ||
+        lmax > 8 || (ldxv & 3) || (ldt & 3) || X_in == X_out)
         return GN_ERR_BAD_ARG;
     if (!X_in && gn_use_highl(lmax_arg)) return GN_ERR_BAD_ARG;   // the zero-X_in form: register-tiled kernels only (lmax <= 4)
     const int M = 1 + (sep_dir ? lmax : 1) + (sep_tensor ? lmax : 1);
@@ -545,7 +547,7 @@ extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, co
     if (N == 0) return GN_OK;
     if (gn_use_highl(lmax_arg))                        // degrees 5..8: one launch per degree (gn_highl.hip)
         return gn_highl_message(x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in, h_out, X_out, N, F, H,
-                                lmax, sep_dir, sep_tensor, (hipStream_t)stream);
+                                lmax, sep_dir, sep_tensor, aggr, (hipStream_t)stream);
     const int key = lmax * 4 + (sep_dir ? 2 : 0) + (sep_tensor ? 1 : 0);
     switch (key) {
         case 4: case 5: case 6: case 7: GN_MSG_LAUNCH(1, false, false); break;   // lmax = 1: flags are no-ops

@@ -45,6 +45,7 @@ struct MsgBwdArgs {
     int N, F, H;
     float inv_sqrt_f;
     int act;                                           // GN_ACT_*: t_attn = act(W_re t + b)
+    int mean;                                          // aggr = "mean" (degree-sliced kernels only): messages scaled by 1 / in-degree
 };
 
 // gamma_w (gotennet.py:285-291): 0 identity, 1 nn.Sigmoid ("gated"), 2 nn.Tanh ("gatedt"), 3 nn.SiLU ("act")
@@ -76,7 +77,7 @@ bool gn_use_highl(int lmax_arg);
 int gn_highl_message(const float* x, const float* v, int ldxv, const float* t_filter, int ldt, const float* a,
                      const float* rl, const float* cut, const int* rowptr, const int* src, const float* h_in,
                      const float* X_in, float* h_out, float* X_out, int N, int F, int H, int lmax, int sep_dir,
-                     int sep_tensor, hipStream_t st);
+                     int sep_tensor, int aggr /* 0 add, 1 mean, 2 max */, hipStream_t st);
 int gn_highl_message_backward(const gn::MsgBwdArgs& p, int lmax, int sep_dir, int sep_tensor, hipStream_t st);
 int gn_highl_htr_edge(const float* EQ, const float* EK, const float* rl, const int* rowptr, const int* src,
                       int N, int F, int lmax, int mode, float* w_raw, float* w, hipStream_t st);

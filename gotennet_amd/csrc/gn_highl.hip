@@ -35,7 +35,13 @@ struct HlShape {
 constexpr int HL_MAX_M = 17;                       // 1 + 2 * 8
 
 // ------------------------------------------------------------------ message forward, one degree per launch (L = 0: scalar row)
-template <int L>
+// AGGR: the reference's `aggr` (PyG scatter reduce of the per-edge messages, gotennet.py:638-639): 0 "add" (what every
+// config uses), 1 "mean" = sum / in-degree, 2 "max" = element-wise maximum over the incoming edges; atoms without incoming
+// edges get 0 in all three.  The fixed slot order makes the maximum as reproducible as the sums.
+__device__ __forceinline__ float4 max4(float4 a, float4 b) {
+    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+template <int L, int AGGR>
 __global__ __launch_bounds__(256) void hl_msg_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ v, int ldxv, const float* __restrict__ tf, int ldt,
     const float* __restrict__ a, const float* __restrict__ rl, const float* __restrict__ cut,
@@ -54,10 +60,11 @@ __global__ __launch_bounds__(256) void hl_msg_fwd_kernel(
     const int D = S.D, per_head = (S.M * F) / H;
     const int bd = L == 0 ? 0 : S.dir_block(L), bt = L == 0 ? 0 : S.ten_block(L);
     const int hd = (bd * F + c0) / per_head, ht = (bt * F + c0) / per_head;
+    const float NEG = -INFINITY;
 
     float4 acc[ROWS];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r] = zero4();
+    for (int r = 0; r < ROWS; ++r) acc[r] = AGGR == 2 ? make_float4(NEG, NEG, NEG, NEG) : zero4();
     for (int e = e0 + slot; e < e1; e += ns) {
         const int j = src[e];
         const float ce = cut[e];
@@ -71,24 +78,46 @@ __global__ __launch_bounds__(256) void hl_msg_fwd_kernel(
             return fma4(ar[hb], ld4(vr + b * F), sp);
         };
         if constexpr (L == 0) {
-            acc[0] = acc[0] + gate(0, hd);
+            const float4 c = gate(0, hd);
+            acc[0] = AGGR == 2 ? max4(acc[0], c) : acc[0] + c;
         } else {
             const float* Xj = X_in + (size_t)j * D * F + c0;
             const float* re = rl + (size_t)e * D;
             const float4 gd = gate(bd, hd), gt = gate(bt, ht);
 #pragma unroll
-            for (int mm = 0; mm < ROWS; ++mm)      // gotennet.py:538-558: rl * o_d + X_j * o_t
-                acc[mm] = acc[mm] + fma4(ld4(Xj + (size_t)(M0 + mm) * F), gt, gd * re[M0 + mm]);
+            for (int mm = 0; mm < ROWS; ++mm) {    // gotennet.py:538-558: rl * o_d + X_j * o_t
+                const float4 c = fma4(ld4(Xj + (size_t)(M0 + mm) * F), gt, gd * re[M0 + mm]);
+                acc[mm] = AGGR == 2 ? max4(acc[mm], c) : acc[mm] + c;
+            }
         }
     }
-    reduce_rows<ROWS>(acc, red, slot, c0, F, ns, [&](int row, float4 s) {
+    auto write = [&](int row, float4 s) {
+        if constexpr (AGGR == 1) s = s * (1.0f / (float)(e1 > e0 ? e1 - e0 : 1));
+        if constexpr (AGGR == 2) { if (e1 == e0) s = zero4(); }
         if constexpr (L == 0) {
             st4(h_out + (size_t)i * F + c0, ld4(h_in + (size_t)i * F + c0) + s);
         } else {
             const size_t off = ((size_t)i * D + (M0 + row)) * F + c0;
             st4(X_out + off, ld4(X_in + off) + s);
         }
-    });
+    };
+    if constexpr (AGGR != 2) {
+        reduce_rows<ROWS>(acc, red, slot, c0, F, ns, write);
+    } else {                                         // the same fixed-order pass over the slots, with max for +
+#pragma unroll
+        for (int base = 0; base < ROWS; base += CH) {
+            if (base) __syncthreads();
+#pragma unroll
+            for (int r = 0; r < CH; ++r)
+                if (base + r < ROWS) st4(&red[r * 1024 + slot * F + c0], acc[base + r]);
+            __syncthreads();
+            for (int r = slot; r < CH && base + r < ROWS; r += ns) {
+                float4 s = ld4(red + r * 1024 + c0);
+                for (int k = 1; k < ns; ++k) s = max4(s, ld4(red + r * 1024 + k * F + c0));
+                write(base + r, s);
+            }
+        }
+    }
 }
 
 // gradient of gate block b for edge (i <- j):  go_b = sum over the degrees the block serves of
@@ -117,7 +146,9 @@ __global__ __launch_bounds__(256) void hl_msg_bwd_target_kernel(const MsgBwdArgs
     const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
     const int e0 = p.rowptr[i], e1 = p.rowptr[i + 1];
     const int per_head = (M * F) / H;
-    const float4 gdh = ld4(p.g_h1 + (size_t)i * F + c0);
+    // aggr = "mean": every message of this target carries 1 / in-degree (the residual paths do not)
+    const float inv = p.mean ? 1.0f / (float)(e1 > e0 ? e1 - e0 : 1) : 1.0f;
+    const float4 gdh = ld4(p.g_h1 + (size_t)i * F + c0) * inv;
     const float* gXi = p.g_X1 + (size_t)i * D * F + c0;
 
     for (int e = e0 + slot; e < e1; e += ns) {
@@ -133,7 +164,7 @@ __global__ __launch_bounds__(256) void hl_msg_bwd_target_kernel(const MsgBwdArgs
         float* hrow = hsum + slot * (M * lps);
         float cutp = 0.f;
         for (int b = 0; b < M; ++b) {
-            const float4 go = b == 0 ? gdh : hl_gate_grad(S, b, gXi, Xj, re, F);
+            const float4 go = b == 0 ? gdh : hl_gate_grad(S, b, gXi, Xj, re, F) * inv;
             const float4 tfb = ld4_nt(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
             st4_nt(gtr + b * F, (go * xb) * ce);
             cutp += hsum4(go * tfb * xb);
@@ -142,7 +173,7 @@ __global__ __launch_bounds__(256) void hl_msg_bwd_target_kernel(const MsgBwdArgs
                 const float4 od = fma4(ar[(b * F + c0) / per_head], vb, (tfb * xb) * ce);      // forward direction gate
                 const int m_lo = S.lo(b) * S.lo(b) - 1, m_hi = (S.hi(b) + 1) * (S.hi(b) + 1) - 1;
                 for (int m = m_lo; m < m_hi; ++m) {
-                    const float s = group_sum(hsum4(ld4(gXi + (size_t)m * F) * od), lps);
+                    const float s = group_sum(hsum4(ld4(gXi + (size_t)m * F) * od), lps) * inv;
                     if (lp == 0) p.g_rl[(size_t)e * D + m] = s;
                 }
             }
@@ -211,8 +242,9 @@ __global__ __launch_bounds__(256) void hl_msg_bwd_source_gates_kernel(const MsgB
             const float ce = p.cut[e];
             const float4 tfb = ld4_nt(p.eproj + (size_t)e * p.lde + F + c0 + b * F);
             const float ab = p.a[(size_t)e * H + hb];
-            const float4 go = b == 0 ? ld4(p.g_h1 + (size_t)i * F + c0)
-                                     : hl_gate_grad(S, b, p.g_X1 + (size_t)i * D * F + c0, Xj, p.rl + (size_t)e * D, F);
+            float4 go = b == 0 ? ld4(p.g_h1 + (size_t)i * F + c0)
+                               : hl_gate_grad(S, b, p.g_X1 + (size_t)i * D * F + c0, Xj, p.rl + (size_t)e * D, F);
+            if (p.mean) go = go * (1.0f / (float)(p.rowptr[i + 1] - p.rowptr[i]));      // (edge e exists: in-degree >= 1)
             acc[0] = fma4(go, tfb * ce, acc[0]);
             acc[1] = fma4(ab, go, acc[1]);
         }
@@ -256,8 +288,9 @@ __global__ __launch_bounds__(256) void hl_msg_bwd_source_X_kernel(const MsgBwdAr
         const float4 ot = fma4(p.a[(size_t)e * H + hb], ld4(p.v + (size_t)j * p.ldxv + b * F + c0),
                                (tfb * ld4(p.x + (size_t)j * p.ldxv + b * F + c0)) * p.cut[e]);   // forward tensor gate
         const float* gXi = p.g_X1 + ((size_t)i * D + M0) * F + c0;
+        const float4 otm = p.mean ? ot * (1.0f / (float)(p.rowptr[i + 1] - p.rowptr[i])) : ot;
 #pragma unroll
-        for (int mm = 0; mm < ROWS; ++mm) acc[mm] = fma4(ld4(gXi + (size_t)mm * F), ot, acc[mm]);
+        for (int mm = 0; mm < ROWS; ++mm) acc[mm] = fma4(ld4(gXi + (size_t)mm * F), otm, acc[mm]);
     }
     reduce_rows<ROWS>(acc, red, slot, c0, F, ns, [&](int row, float4 s) {
         const size_t off = ((size_t)j * D + (M0 + row)) * F + c0;
@@ -416,9 +449,22 @@ __global__ __launch_bounds__(256) void hl_htr_bwd_source_kernel(
 }  // namespace gn
 
 // ====================================================================================== launchers
-bool gn_use_highl(int lmax_arg) { return (lmax_arg & 0xff) > 4 || (lmax_arg & GN_LMAX_SLICED) != 0; }
+bool gn_use_highl(int lmax_arg) { return (lmax_arg & 0xff) > 4 || (lmax_arg & (GN_LMAX_SLICED | GN_LMAX_MEAN | GN_LMAX_MAX)) != 0; }
 
 // KERNEL<L> for L = 1..lmax (lmax <= 8), one launch per degree
+#define GN_HL_FWD_DEGREES(AG, ...)                                                                    \
+    do {                                                                                              \
+        hipLaunchKernelGGL((gn::hl_msg_fwd_kernel<0, AG>), grid, block, 0, st, __VA_ARGS__);           \
+        hipLaunchKernelGGL((gn::hl_msg_fwd_kernel<1, AG>), grid, block, 0, st, __VA_ARGS__);           \
+        if (lmax >= 2) hipLaunchKernelGGL((gn::hl_msg_fwd_kernel<2, AG>), grid, block, 0, st, __VA_ARGS__); \
+        if (lmax >= 3) hipLaunchKernelGGL((gn::hl_msg_fwd_kernel<3, AG>), grid, block, 0, st, __VA_ARGS__); \
+        if (lmax >= 4) hipLaunchKernelGGL((gn::hl_msg_fwd_kernel<4, AG>), grid, block, 0, st, __VA_ARGS__); \
+        if (lmax >= 5) hipLaunchKernelGGL((gn::hl_msg_fwd_kernel<5, AG>), grid, block, 0, st, __VA_ARGS__); \
+        if (lmax >= 6) hipLaunchKernelGGL((gn::hl_msg_fwd_kernel<6, AG>), grid, block, 0, st, __VA_ARGS__); \
+        if (lmax >= 7) hipLaunchKernelGGL((gn::hl_msg_fwd_kernel<7, AG>), grid, block, 0, st, __VA_ARGS__); \
+        if (lmax >= 8) hipLaunchKernelGGL((gn::hl_msg_fwd_kernel<8, AG>), grid, block, 0, st, __VA_ARGS__); \
+    } while (0)
+
 #define GN_HL_PER_DEGREE(KERNEL, ...)                                                                 \
     do {                                                                                              \
         hipLaunchKernelGGL(gn::KERNEL<1>, grid, block, 0, st, __VA_ARGS__);                            \
@@ -434,14 +480,16 @@ bool gn_use_highl(int lmax_arg) { return (lmax_arg & 0xff) > 4 || (lmax_arg & GN
 int gn_highl_message(const float* x, const float* v, int ldxv, const float* t_filter, int ldt, const float* a,
                      const float* rl, const float* cut, const int* rowptr, const int* src, const float* h_in,
                      const float* X_in, float* h_out, float* X_out, int N, int F, int H, int lmax, int sep_dir,
-                     int sep_tensor, hipStream_t st) {
+                     int sep_tensor, int aggr, hipStream_t st) {
     if (lmax < 1 || lmax > 8) return GN_ERR_BAD_ARG;
     const gn::HlShape S(lmax, sep_dir, sep_tensor);
     const dim3 grid(gn::xcd_grid(N)), block(256);
-    hipLaunchKernelGGL(gn::hl_msg_fwd_kernel<0>, grid, block, 0, st, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src,
-                       h_in, X_in, h_out, X_out, N, F, H, S);
-    GN_HL_PER_DEGREE(hl_msg_fwd_kernel, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in, h_out, X_out,
-                     N, F, H, S);
+    if (aggr == 1)
+        GN_HL_FWD_DEGREES(1, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in, h_out, X_out, N, F, H, S);
+    else if (aggr == 2)
+        GN_HL_FWD_DEGREES(2, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in, h_out, X_out, N, F, H, S);
+    else
+        GN_HL_FWD_DEGREES(0, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in, h_out, X_out, N, F, H, S);
     GN_LAUNCH_CHECK();
     return GN_OK;
 }

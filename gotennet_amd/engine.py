@@ -69,7 +69,7 @@ def zero_X_in(cfg: "Config", li: int) -> bool:
     """Layer ``li`` of ``forward`` sees the all-zero X that forward itself creates (gotennet.py:992) and the kernels have
     the zero-X_in form (register-tiled SiLU kernels, lmax <= 4): every tensor-gate term of that layer is 0 * gate, so its
     blocks of the edge projection are neither computed nor read, and nothing consumes the gradient w.r.t. X_in."""
-    return ZERO_X_FIRST and li == 0 and cfg.lmax <= 4 and cfg.act == 0 and not cfg.steerable_norm and not cfg.sliced
+    return ZERO_X_FIRST and li == 0 and cfg.lmax <= 4 and cfg.act == 0 and not cfg.steerable_norm and not cfg.sliced and cfg.aggr == 0
 
 
 def _We_first(cfg: "Config", lw) -> Tuple[torch.Tensor, torch.Tensor, int]:
@@ -134,6 +134,7 @@ class Config:
     emlp: int = 0             # emlp_dim: hidden width of the 2-layer gamma_t (0 = F)
     gemm_mode: str = ""       # projection arithmetic of THIS model ("f16x2" | "split" | "f32"; "" = engine.GEMM_MODE, the default)
     sliced: bool = False      # run lmax <= 4 on the degree-sliced kernel family too (GN_LMAX_SLICED in the lmax argument)
+    aggr: int = 0             # the reference's `aggr` (gotennet.py:84,638): 0 "add", 1 "mean", 2 "max" (forward only)
     fuse_eqff: bool = False   # the node-local EQFF chain as ONE kernel each way where covered (eqff_fused_ok); opt-in: a wash
                               # against the launch sequence on MI355X (-0.5 % ... +0.5 % on the step)
     fuse_message: bool = False  # inference (nothing saved): edge projection + softmax + message as ONE kernel (gn_message_fused,
@@ -155,6 +156,11 @@ class Config:
     def lmax_arg(self) -> int:
         """The ``lmax`` argument of the message / HTR entry points: GN_LMAX_SLICED rides in it."""
         return self.lmax | (_lib.LMAX_SLICED if self.sliced else 0)
+
+    @property
+    def lmax_arg_msg(self) -> int:
+        """... of the two MESSAGE entry points, which also carry the aggregation (GN_LMAX_MEAN / GN_LMAX_MAX)."""
+        return self.lmax_arg | {0: 0, 1: _lib.LMAX_MEAN, 2: _lib.LMAX_MAX}[self.aggr]
 
 
 def _stream() -> int:
@@ -615,7 +621,7 @@ def message_stage(cfg: Config, g: "Graph", nact, xs, vs, eproj, attn, h, X, h2, 
          ptr(g.rowptr), ptr(g.src), ptr(g.outdeg), g.N, F_, H, ptr(attn), cfg.act, _stream())
     call("gn_message_aggregate", ptr(xs), ptr(vs), M * F_, eproj.data_ptr() + 4 * F_, lde,
          ptr(attn), ptr(g.rl), ptr(g.cut), ptr(g.rowptr), ptr(g.src),
-         ptr(h), ptr(X), ptr(h2), ptr(X2), g.N, F_, H, cfg.lmax_arg, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
+         ptr(h), ptr(X), ptr(h2), ptr(X2), g.N, F_, H, cfg.lmax_arg_msg, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
 
 
 def eqff_fused_ok(cfg: Config) -> bool:
@@ -630,7 +636,7 @@ def eqff_fused_ok(cfg: Config) -> bool:
 def fused_message_ok(cfg: Config) -> bool:
     """gn_message_fused covers this model (SiLU, lmax <= 4, F a power of two >= 128, a plane arithmetic) and is switched on."""
     mode = resolve_mode(cfg.gemm_mode)
-    if not cfg.fuse_message or cfg.sliced or mode not in _PLANE_MODES:
+    if not cfg.fuse_message or cfg.sliced or cfg.aggr or mode not in _PLANE_MODES:
         return False
     return bool(_lib.load().gn_message_fused_supported(cfg.F, cfg.H, cfg.lmax, cfg.M, cfg.act, 1 if mode == "split" else 2))
 
@@ -748,13 +754,15 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
     gemm, gemm_group = proj.gemm, proj.group
     f32 = dict(dtype=torch.float32, device=z32.device)
     new = lambda *shape: torch.empty(shape, **f32)
+    if cfg.aggr == 2:
+        raise NotImplementedError("aggr='max': the message stage has a forward kernel only (no input-gradient / forces)")
     colptr, perm = g.csc()
     lde = (1 + M) * F_
     eq_fused, eq_arith = eqff_fused_ok(cfg), (1 if proj.mode == "split" else 2)
 
     # every contributing kernel writes its own slice; the geometry backward sums them in a fixed order
     L = len(pw.layers)
-    G = _lib.load().gn_message_backward_groups(cfg.lmax_arg, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act)
+    G = _lib.load().gn_message_backward_groups(cfg.lmax_arg_msg, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act)
     n_rl, n_cut = L + sum(lw.Wt is not None for lw in pw.layers), G * L + 1
     g_rl_parts, g_cut_parts = new(n_rl, E, D), new(n_cut, E)
     ga_parts = new(G, E, H) if G > 1 else None
@@ -851,7 +859,7 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
              ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), None if first else ptr(gX2),
              rl_slice(li), cut_slice(G * li),
              ptr(ga_parts), E,
-             N, F_, H, cfg.lmax_arg, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act, _stream())
+             N, F_, H, cfg.lmax_arg_msg, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act, _stream())
         # the edge-sized W_e^T product leaves 0.7 of its last tile round idle: the two K-heavy atom-sized products
         # (g_x W_s2, g_v W_v2; 60 us as a launch of their own) ride there; W_n1^T needs their output and follows alone
         if first:                                  # the tensor-gate columns of g_eproj were not written: K-prefix

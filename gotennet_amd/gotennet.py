@@ -153,8 +153,9 @@ class GATA(_LayerPackCache, nn.Module):
         info["mlp"], info["mlpa"] = "mlp" in parts, "mlpa" in parts
         info["lin_w"] = 2 if "linwa" in parts else 1 if "linw" in parts else 0
         info["lin_ln"] = 2 if "postln" in parts else 1 if "ln" in parts else 0
-        if aggr != "add":
-            raise NotImplementedError("aggr must be 'add'")
+        if aggr not in ("add", "sum", "mean", "max"):           # PyG aggregations of MessagePassing(aggr=...) GATA.aggregate uses
+            raise NotImplementedError(f"aggr={aggr!r}: 'add', 'mean' or 'max' (gotennet.py:84,638)")
+        self.aggr_kind = {"add": 0, "sum": 0, "mean": 1, "max": 2}[aggr]
         if edge_ln not in ("", None, "layer"):
             raise NotImplementedError(f"edge_ln={edge_ln!r}: only '' and 'layer' are on the accelerated path")
         self.edge_vec_dim = n_atom_basis if evec_dim is None else evec_dim
@@ -245,7 +246,7 @@ class GATA(_LayerPackCache, nn.Module):
                              t_last_act=0 if self.update_info["mlp"] else 3, lin_w=self.update_info["lin_w"],
                              lin_ln=self.update_info["lin_ln"], evec=self.edge_vec_dim, emlp=self.edge_mlp_dim,
                              act=self.act_kind, gemm_mode=engine.resolve_mode(getattr(self, "gemm_mode", None)),
-                             sliced=bool(getattr(self, "sliced_kernels", False)))
+                             sliced=bool(getattr(self, "sliced_kernels", False)), aggr=self.aggr_kind)
 
     @torch.no_grad()
     def forward(self, edge_index: Tensor, h: Tensor, X: Tensor, rl_ij: Tensor, t_ij: Tensor, r_ij: Tensor,
@@ -490,7 +491,7 @@ class GotenNet(nn.Module):
                              lin_w=g0.update_info["lin_w"], lin_ln=g0.update_info["lin_ln"],
                              evec=g0.edge_vec_dim, emlp=g0.edge_mlp_dim, act=self.act_kind,
                              gemm_mode=engine.resolve_mode(self.gemm_mode), sliced=bool(self.sliced_kernels),
-                             fuse_message=bool(self.fuse_message), fuse_eqff=bool(self.fuse_eqff))
+                             fuse_message=bool(self.fuse_message), fuse_eqff=bool(self.fuse_eqff), aggr=g0.aggr_kind)
 
     def packed_weights(self) -> engine.PackedWeights:
         """Concatenate the projections that share an input into single GEMM operands

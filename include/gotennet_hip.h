@@ -44,6 +44,12 @@ extern "C" {
  * lmax 5..8).  An explicit per-call request -- the library reads no environment variable and keeps no switch; every
  * tuning value of the launchers is a build-time constant (csrc/gn_tune.h). */
 #define GN_LMAX_SLICED 0x100
+/* The reference's `aggr` constructor argument (gotennet.py:84,129,638: PyG scatter reduce of the messages), also carried in
+ * the `lmax` argument: default "add"; GN_LMAX_MEAN = "mean" (sum / in-degree, 0 for atoms without incoming edges) in
+ * gn_message_aggregate AND gn_message_backward; GN_LMAX_MAX = "max" (element-wise maximum over the incoming edges, 0 without)
+ * in gn_message_aggregate only (no backward: GN_ERR_BAD_ARG).  Both run on the degree-sliced kernel family at every lmax. */
+#define GN_LMAX_MEAN 0x200
+#define GN_LMAX_MAX 0x400
 
 /* `act`: the element-wise activation of the reference's `activation` constructor argument (str2act, layers.py:596-700;
  * shifted_softplus layers.py:40-50).  Wherever an entry point below says SiLU, it means this kind. */

@@ -61,7 +61,7 @@ def default_config(**kw) -> dict:
         n_atom_basis=128, n_interactions=8, n_rbf=32, cutoff=5.0, max_z=100,
         epsilon=1e-8, num_heads=8, scale_edge=True, lmax=1,
         sep_htr=True, sep_dir=False, sep_tensor=False,
-        radial_basis="expnorm", edge_updates=True, layernorm="", steerable_norm="",
+        radial_basis="expnorm", edge_updates=True, layernorm="", steerable_norm="", aggr="add",
     )
     cfg.update(kw)
     return cfg
@@ -388,9 +388,25 @@ def gata_message_aggregate(sd, cfg, p, edge_index, h, X, rl, t, r, n_edges):
     else:
         dX_X = comps[0].unsqueeze(1) * X_j
     dX = dX_R + dX_X
-    d_h = torch.zeros_like(h).index_add_(0, i, o_s)
-    d_X = torch.zeros_like(X).index_add_(0, i, dX)
+    d_h, d_X = _aggregate(o_s, i, h, cfg.get("aggr", "add")), _aggregate(dX, i, X, cfg.get("aggr", "add"))
     return h + d_h, X + d_X
+
+
+def _aggregate(msg: Tensor, index: Tensor, like: Tensor, aggr: str) -> Tensor:
+    """GATA.aggregate (gotennet.py:638-639): PyG ``scatter(msg, index, dim=0, dim_size=N, reduce=aggr)`` -- "add" (every
+    config), "mean" = sum / in-degree (count clamped to 1), "max" = element-wise maximum over the incoming edges; atoms
+    without incoming edges get 0 in all three (PyG 2.x semantics, the definition of tools/ref_shims._scatter)."""
+    out = torch.zeros_like(like).index_add_(0, index, msg)
+    if aggr in ("add", "sum"):
+        return out
+    if aggr == "mean":
+        cnt = torch.zeros(like.shape[0], dtype=like.dtype).index_add_(0, index, torch.ones(index.numel(), dtype=like.dtype))
+        return out / cnt.clamp(min=1).reshape([-1] + [1] * (like.dim() - 1))
+    if aggr == "max":
+        idx = index.reshape([-1] + [1] * (msg.dim() - 1)).expand_as(msg)
+        mx = torch.full_like(like, float("-inf")).scatter_reduce(0, idx, msg, reduce="amax", include_self=True)
+        return torch.where(torch.isinf(mx), torch.zeros_like(mx), mx)
+    raise ValueError(f"aggr={aggr!r}")
 
 
 def _rejection(rep: Tensor, rl: Tensor) -> Tensor:

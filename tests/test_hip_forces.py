@@ -10,7 +10,8 @@ from tests.test_hip_parity import _net_from_case, _synthetic
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gemm_mode")]
 
 TOL = 1e-4          # north_star: forces within 1e-4 relative (max-norm)
-FORCE_CASES = [n for n in case_names() if "shuffled" not in n]
+# (aggr = "max" has a forward kernel only: its own test below holds the refusal)
+FORCE_CASES = [n for n in case_names() if "shuffled" not in n and "aggr_max" not in n]
 
 
 def _head_from_case(cfg, head_sd):
@@ -338,3 +339,17 @@ def test_forces_asymmetric_graph_neighbor_cap():
     e, f = EnergyForces(net, head)(z.cuda(), ei, w, vec, batch.cuda(), 1)
     assert rel_err(e.cpu(), e_ref) < TOL
     assert rel_err(f.cpu(), f_ref) < TOL
+
+
+def test_aggr_max_is_forward_only():
+    """aggr='max' (gotennet.py:84,638) runs the message stage forward (fixture opt_aggr_max_l3 in test_hip_parity) and refuses
+    the force path before any backward launch."""
+    from gotennet_amd.pipeline import EnergyForces
+    cfg, sd, head_sd, t = load_case("opt_aggr_max_l3")
+    net, head = _net_from_case(cfg, sd), _head_from_case(cfg, head_sd)
+    assert net.config().aggr == 2
+    args = [t[k].cuda() for k in ("z", "edge_index", "edge_diff", "edge_vec", "batch")] + [cfg["n_mol"]]
+    e, _ = EnergyForces(net, head)(*args, forces=False)
+    assert rel_err(e.cpu(), t["energy"]) < 1e-4
+    with pytest.raises(NotImplementedError):
+        EnergyForces(net, head)(*args)

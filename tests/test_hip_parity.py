@@ -20,7 +20,8 @@ def _net_from_case(cfg, sd):
         sep_htr=cfg.get("sep_htr", True), radial_basis=cfg.get("radial_basis", "expnorm"),
         edge_updates=cfg.get("edge_updates", True), layernorm=cfg.get("layernorm", ""),
         steerable_norm=cfg.get("steerable_norm", ""), edge_ln=cfg.get("edge_ln", ""),
-            activation=cfg.get("activation", "silu"), evec_dim=cfg.get("evec_dim"), emlp_dim=cfg.get("emlp_dim"))
+            activation=cfg.get("activation", "silu"), evec_dim=cfg.get("evec_dim"), emlp_dim=cfg.get("emlp_dim"),
+        aggr=cfg.get("aggr", "add"))
     net.load_state_dict(sd, strict=True)
     return net.cuda().eval()
 

@@ -94,8 +94,10 @@ def test_unsupported_flags_raise_before_launch():
         gotennet_amd.GotenNet(cutoff_fn=cut, edge_ln="batch")
     with pytest.raises(NotImplementedError):
         gotennet_amd.GotenNet(cutoff_fn=cut, evec_dim=24, edge_updates="linw")
+    for aggr, kind in (("add", 0), ("mean", 1), ("max", 2)):  # gotennet.py:84,638: the PyG reduce of GATA.aggregate
+        assert gotennet_amd.GotenNet(cutoff_fn=cut, n_atom_basis=32, n_interactions=1, n_rbf=8, aggr=aggr).config().aggr == kind
     with pytest.raises(NotImplementedError):
-        gotennet_amd.GotenNet(cutoff_fn=cut, aggr="mean")
+        gotennet_amd.GotenNet(cutoff_fn=cut, aggr="min")
     with pytest.raises(ValueError):
         gotennet_amd.GotenNet(cutoff_fn=cut, edge_updates="bogus")
     with pytest.raises(ValueError):

@@ -109,6 +109,13 @@ CASES = {
     "l8_sep_tln_f32": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=8, num_heads=8, scale_edge=True,
                             sep_dir=True, sep_tensor=True, max_z=10, steerable_norm="tensor"),
                        dict(mols=[4], box=2.4, seed=44)),
+    # aggr != "add" (gotennet.py:84,638: the PyG reduce of GATA.aggregate); "max" has no HIP backward (forward-only fixture use)
+    "opt_aggr_mean_l2": (dict(n_atom_basis=32, n_interactions=3, n_rbf=8, lmax=2, num_heads=8, scale_edge=False,
+                              sep_dir=True, sep_tensor=True, max_z=10, aggr="mean"), dict(mols=[6, 1, 5], box=3.0, seed=51)),
+    "opt_aggr_mean_l5_nosep": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=5, num_heads=4, scale_edge=True,
+                                    sep_dir=False, sep_tensor=False, max_z=10, aggr="mean"), dict(mols=[5, 3], box=2.6, seed=52)),
+    "opt_aggr_max_l3": (dict(n_atom_basis=32, n_interactions=2, n_rbf=8, lmax=3, num_heads=8, scale_edge=False,
+                             sep_dir=True, sep_tensor=True, max_z=10, aggr="max"), dict(mols=[6, 4], box=2.8, seed=53)),
     "opt_evec16_emlp48": (dict(n_atom_basis=32, n_interactions=3, n_rbf=8, lmax=2, num_heads=8, scale_edge=False,
                                sep_dir=True, sep_tensor=True, max_z=10, activation="silu",
                                edge_updates="mlpa_linwa_postln_gatedt", edge_ln="layer", evec_dim=16, emlp_dim=48),
