@@ -135,8 +135,9 @@ class Config:
     gemm_mode: str = ""       # projection arithmetic of THIS model ("f16x2" | "split" | "f32"; "" = engine.GEMM_MODE, the default)
     sliced: bool = False      # run lmax <= 4 on the degree-sliced kernel family too (GN_LMAX_SLICED in the lmax argument)
     aggr: int = 0             # the reference's `aggr` (gotennet.py:84,638): 0 "add", 1 "mean", 2 "max" (forward only)
-    fuse_eqff: bool = False   # the node-local EQFF chain as ONE kernel each way where covered (eqff_fused_ok); opt-in: a wash
-                              # against the launch sequence on MI355X (-0.5 % ... +0.5 % on the step)
+    fuse_eqff: Optional[bool] = None   # the node-local EQFF chain as ONE kernel each way where covered (eqff_fused_ok).  None =
+                              # auto: on for systems of at most EQFF_FUSED_MAX_ATOMS atoms (launch-bound: -17 % on a one-molecule
+                              # step, -2 % at 32 molecules), off above (a wash at the 128-molecule batch)
     fuse_message: bool = False  # inference (nothing saved): edge projection + softmax + message as ONE kernel (gn_message_fused,
                                 # no [E,(1+M)F] stream); opt-in: measured 2-10 % slower than the three kernels
 
@@ -424,7 +425,7 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
     lde = (1 + M) * F_
     nact, g1act = new(N, 4 * F_), new(N, F_)       # activated copies (scratch, shared by all layers)
     fused = (not save) and trace is None and E > 0 and fused_message_ok(cfg)
-    eq_fused, eq_arith = eqff_fused_ok(cfg), (1 if proj.mode == "split" else 2)
+    eq_fused, eq_arith = eqff_fused_ok(cfg, N), (1 if proj.mode == "split" else 2)
     if not save:                                   # inference: ping-pong work buffers, reused by every layer
         h2, X2, t2 = new(N, F_), new(N, D, F_), new(E, F_)
         nproj, xs, vs = new(N, 4 * F_), new(N, M * F_), new(N, M * F_)
@@ -624,11 +625,16 @@ def message_stage(cfg: Config, g: "Graph", nact, xs, vs, eproj, attn, h, X, h2, 
          ptr(h), ptr(X), ptr(h2), ptr(X2), g.N, F_, H, cfg.lmax_arg_msg, int(cfg.sep_dir), int(cfg.sep_tensor), _stream())
 
 
-def eqff_fused_ok(cfg: Config) -> bool:
+#: ``fuse_eqff = None`` (auto): fused up to this many atoms per call (measured crossover between 672 and 2688 atoms at F = 256)
+EQFF_FUSED_MAX_ATOMS = 1024
+
+
+def eqff_fused_ok(cfg: Config, n_atoms: Optional[int] = None) -> bool:
     """The EQFF chains run as one kernel each way (gn_eqff_fused_forward / _backward): F in {128, 256}, SiLU, a plane
-    arithmetic; everything else keeps the launch sequence."""
+    arithmetic; everything else keeps the launch sequence.  ``cfg.fuse_eqff`` None: decided by the system size."""
     mode = resolve_mode(cfg.gemm_mode)
-    if not cfg.fuse_eqff or mode not in _PLANE_MODES:
+    want = cfg.fuse_eqff if cfg.fuse_eqff is not None else (n_atoms is not None and n_atoms <= EQFF_FUSED_MAX_ATOMS)
+    if not want or mode not in _PLANE_MODES:
         return False
     return bool(_lib.load().gn_eqff_fused_supported(cfg.F, cfg.act, 1 if mode == "split" else 2))
 
@@ -758,7 +764,7 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
         raise NotImplementedError("aggr='max': the message stage has a forward kernel only (no input-gradient / forces)")
     colptr, perm = g.csc()
     lde = (1 + M) * F_
-    eq_fused, eq_arith = eqff_fused_ok(cfg), (1 if proj.mode == "split" else 2)
+    eq_fused, eq_arith = eqff_fused_ok(cfg, N), (1 if proj.mode == "split" else 2)
 
     # every contributing kernel writes its own slice; the geometry backward sums them in a fixed order
     L = len(pw.layers)

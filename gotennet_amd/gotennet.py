@@ -418,10 +418,11 @@ class GotenNet(nn.Module):
         #: (gn_message_fused: no [E, (1+M)F] stream) where the model is covered (engine.fused_message_ok).  Off by default:
         #: measured 2-10 % slower than the three-kernel sequence on MI355X
         self.fuse_message = False
-        #: True: the EQFF chain after X_p (context, gamma_m, update; and its input-gradient) as one kernel each way where
-        #: covered (engine.eqff_fused_ok: F in {128, 256}, SiLU, a plane arithmetic).  Off by default: measured a wash
-        #: against the launch sequence (7.735 vs 7.698 ms at C2 lmax 2, 14.29 vs 14.36 at lmax 4)
-        self.fuse_eqff = False
+        #: the EQFF chain after X_p (context, gamma_m, update; and its input-gradient) as one kernel each way where covered
+        #: (engine.eqff_fused_ok: F in {128, 256}, SiLU, a plane arithmetic).  None = auto: on for calls of at most
+        #: engine.EQFF_FUSED_MAX_ATOMS atoms (a one-molecule step is launch-bound: 2.31 -> 1.91 ms; 32 molecules -2 %), off
+        #: above (the 128-molecule batch: 7.735 vs 7.698 ms); True / False force it
+        self.fuse_eqff = None
         self._warned_inference_only = False
 
     # ------------------------------------------------------------------ parameters
@@ -491,7 +492,7 @@ class GotenNet(nn.Module):
                              lin_w=g0.update_info["lin_w"], lin_ln=g0.update_info["lin_ln"],
                              evec=g0.edge_vec_dim, emlp=g0.edge_mlp_dim, act=self.act_kind,
                              gemm_mode=engine.resolve_mode(self.gemm_mode), sliced=bool(self.sliced_kernels),
-                             fuse_message=bool(self.fuse_message), fuse_eqff=bool(self.fuse_eqff), aggr=g0.aggr_kind)
+                             fuse_message=bool(self.fuse_message), fuse_eqff=self.fuse_eqff, aggr=g0.aggr_kind)
 
     def packed_weights(self) -> engine.PackedWeights:
         """Concatenate the projections that share an input into single GEMM operands

@@ -239,9 +239,13 @@ def test_eqff_fused_falls_back_where_unsupported():
                                             **{**dict(n_atom_basis=128, lmax=2), **kw})
     ok = mk()
     ok.gemm_mode = "f16x2"
-    assert not engine.eqff_fused_ok(ok.config())     # opt-in
+    assert ok.fuse_eqff is None                      # auto: by system size
+    assert engine.eqff_fused_ok(ok.config(), 21) and not engine.eqff_fused_ok(ok.config(), 2688)
+    assert not engine.eqff_fused_ok(ok.config())     # (size unknown: the launch sequence)
+    ok.fuse_eqff = False
+    assert not engine.eqff_fused_ok(ok.config(), 21)
     ok.fuse_eqff = True
-    assert engine.eqff_fused_ok(ok.config())
+    assert engine.eqff_fused_ok(ok.config()) and engine.eqff_fused_ok(ok.config(), 2688)
     ok.gemm_mode = "f32"
     assert not engine.eqff_fused_ok(ok.config())
     for bad in (mk(n_atom_basis=64), mk(n_atom_basis=512), mk(activation="tanh")):
