@@ -603,6 +603,19 @@ def test_energy_forces_replays_static_topology_bit_identically():
         e1, f1 = rep(z, ei3, ed3, ev3, batch, cfg["n_mol"])
         assert torch.equal(e0, e1) and torch.equal(f0, f1)
     assert rep._graph_state is not None
+    # a caller-ordered (shuffled) edge list: the cached stable-sort permutation is applied to every call's edge_diff / edge_vec
+    perm = torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(5)).cuda()
+    ei4 = ei[:, perm].contiguous()
+    for it in range(4):
+        p2 = pos + 1e-3 * torch.randn(pos.shape, generator=g).cuda()
+        _, ed2, ev2 = distance(p2, batch, cfg["cutoff"], 32)
+        ed4, ev4 = ed2[perm].contiguous(), ev2[perm].contiguous()
+        e0, f0 = eager(z, ei4, ed4, ev4, batch, cfg["n_mol"])                     # the same shuffled list, eager
+        e1, f1 = rep(z, ei4, ed4, ev4, batch, cfg["n_mol"])
+        assert torch.equal(e0, e1) and torch.equal(f0, f1), it
+        et, ft = eager(z, ei, ed2, ev2, batch, cfg["n_mol"])                      # target-major list: another order inside a
+        assert rel_err(e1, et) < 1e-5 and rel_err(f1, ft) < 1e-5                  # target's row, fp32 re-association only
+    assert rep._graph_state is not None and rep._graph_state["order"] is not None
     rep.clear_cache()
     assert rep._graph_state is None and rep._topo is None
 
