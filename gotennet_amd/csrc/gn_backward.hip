@@ -223,7 +223,9 @@ __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, float* 
                     for (int m = S::first_row(l); m < S::first_row(l) + 2 * l + 1; ++m)
                         go = S::is_dir(b) ? fma4(re[m], gdX[m], go) : fma4(gdX[m], ld4(Xj + (size_t)m * F), go);
             }
-            const float4 tfb = ld4_nt(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
+            // (t_filter with an ORDINARY load here: the by-source pass re-reads these rows right after this launch, and with
+            //  the non-temporal hint none of them survived in L2 / the Infinity Cache: 303.8 -> 296.3 us per layer, round 4)
+            const float4 tfb = ld4(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
             st4_nt(gtr + b * F, (go * xb) * ce);
             cutp += hsum4(go * tfb * xb);
             pa_h[b] = hsum4(go * vb);
