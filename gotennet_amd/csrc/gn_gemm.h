@@ -110,3 +110,5 @@ __device__ __forceinline__ int phys_row(const GemmArgs& p, int r) {
 // split = 1: 3 x bf16-split MFMA, W = the fragment-major bf16 planes written by gn_split_bf16x3;
 // split = 2: 2 x fp16-split MFMA with block exponents, W = the planes (+ header) written by gn_split_f16x2
 int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split);
+// the K-resident panel kernel for small f16x2 groups (gn_gemm_panel.hip): 1 = launched, 0 = does not apply, < 0 = -hipError_t
+int gn_gemm_panel_launch(const gn::GemmArgs* g, int n, hipStream_t st);

@@ -713,12 +713,15 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     const int BMB = 128, BNB = 128;
     const long cap_big = 512;
 #endif
+    if (split == 2) {
+        const int r = gn_gemm_panel_launch(g, n, st);
+        if (r != 0) return r > 0 ? GN_OK : -r;
+    }
     gn::GroupArgs ga;
-    long big = 0, small = 0;
+    long big = 0;
     bool pro = false;
     for (int i = 0; i < n; ++i) {
         big += (long)((g[i].M + 127) / 128) * ((g[i].N + 127) / 128);
-        small += (long)((g[i].M + 63) / 64) * ((g[i].N + 63) / 64);
         pro = pro || g[i].pro_mode != 0 || g[i].a_gate != nullptr;
     }
     // 128x128 tiles from GN_GEMM_BIG_MIN = 900 tiles up (measured switch-over; a build-time constant of gn_tune.h, swept

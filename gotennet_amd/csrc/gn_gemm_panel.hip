@@ -1,0 +1,252 @@
+// gn_gemm_panel.hip -- the 2 x fp16-split projection for problems too small to hide their own latency.
+//
+// The slab kernel of gn_gemm.hip walks K in 32-deep slabs: fetch -> split -> LDS -> barrier -> 2 k-steps.  With hundreds of
+// tiles per CU two co-resident workgroups hide that chain behind each other; an atom-sized product (N = 2688 rows: 168-840
+// tiles of 64 x 64 for 256 CUs) has ONE tile per CU and pays the chain once per slab: measured 0.9 us per slab, 14-21 us per
+// launch for 0.7 GFLOP (reference call sites gotennet.py:400-405, 432-441, 728, 738 and their input-gradients).
+// Here the whole K extent of a tile's A rows (K = 128 / 256 / 512) is requested at once, split into its two fp16 planes
+// with ONE block exponent per wave and tile, parked in LDS as a [64][K] panel, and the k-steps run back to back off the
+// panel with the weight fragments (fragment-major planes of gn_split_f16x2, L2 -> registers) requested eight k-steps ahead:
+// one HBM round trip, one barrier, then 3 MFMAs per k-step and wave until the epilogue.
+//
+// Same arguments, prologue-free subset: pro_mode = 0 and a_gate = NULL (the launcher keeps the slab kernel for the rest);
+// K-segmented A, row maps, bias / activation range / residual / gate / pre_out epilogues as in gn_gemm.hip.  The block
+// exponent covers all of K (the slab kernel's covers the slabs staged so far): results agree with the slab kernel to the
+// arithmetic's bound (<= 3e-7 of the fp64 product), not bitwise.
+#include "gn_gemm.h"
+#include "gn_tune.h"
+
+namespace gn {
+
+template <int NK, bool ASILU>
+__global__ __launch_bounds__(256) void gemm_f16x2_panel(const GroupArgs ga) {
+    constexpr int K = 32 * NK;                      // depth of every problem of the launch
+    constexpr int KP = K + 8;                       // fp16 per panel row: (K + 8) / 2 dwords = 4 mod 64, so the 16-lane groups
+                                                    // of a ds_read_b128 (16 rows, 16 bytes each) hit 16 distinct 4-bank slots
+    constexpr int BM = 64, BN = 64, CP = BN + 4;
+    constexpr int APL = BM * KP;                    // fp16 per plane
+    constexpr int KC = K / 128;                     // 128-column chunks of a row: one half-wave reads 512 contiguous bytes
+    constexpr int NS = 2 * NK;                      // k-steps of 16
+    constexpr int NB = NS < 8 ? NS : 8;             // weight fragments in flight (k-steps ahead)
+    static_assert(2 * APL * 2 >= BM * CP * 4, "the epilogue tile overlays the panel");
+    __shared__ __attribute__((aligned(16))) _Float16 panel[2 * APL];
+    __shared__ int exps_w;                          // the four waves' block exponents (signed bytes)
+
+    // tile of this workgroup: the concatenated 64 x 64 tile list is cut into 8 contiguous ranges, XCD x (= blockIdx % 8)
+    // takes range x -- neighbouring column tiles share their A rows through one L2
+    int tiles_all = ga.tile_end[0];
+#pragma unroll
+    for (int gi = 1; gi < GN_MAX_GROUP; ++gi)
+        if (gi < ga.n) tiles_all = ga.tile_end[gi];
+    const int xcd = blockIdx.x & 7;
+    const int xq = tiles_all >> 3, xr = tiles_all & 7;
+    const int lo = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+    const int cnt = xq + (xcd < xr ? 1 : 0);
+    if ((int)(blockIdx.x >> 3) >= cnt) return;
+    const int t = lo + (int)(blockIdx.x >> 3);
+    // the problem this tile belongs to, read from the kernarg segment with ONE indexed scalar load (copying all four
+    // descriptors and selecting cost ~500 scalar instructions before the first global load)
+    int gi = 0, first = 0;
+#pragma unroll
+    for (int q = 1; q < GN_MAX_GROUP; ++q)
+        if (q < ga.n && t >= ga.tile_end[q - 1]) {
+            gi = q;
+            first = ga.tile_end[q - 1];
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) GroupArgs* KargPtr;
+    const GemmArgs p = ((KargPtr)__builtin_amdgcn_kernarg_segment_ptr())->g[__builtin_amdgcn_readfirstlane(gi)];
+#else
+    const GemmArgs p = ga.g[gi];                     // host pass of the single-source compile: never executed
+#endif
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int m0 = ((t - first) / tiles_n) * BM, n0 = ((t - first) % tiles_n) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- weight fragments of the first NB k-steps (L2 -> registers; nothing depends on A yet)
+    const uint4* wfrag = reinterpret_cast<const uint4*>(p.W) + 16;        // 256-byte header: the weight tensor's exponent
+    const int ewt = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(p.W));
+    {
+        const int nt_last = (p.N + 31) / 32 - 1;
+        int nt = n0 / 32 + wn;
+        nt = nt < nt_last ? nt : nt_last;            // a column block past N: any valid block (never stored)
+        wfrag += (size_t)nt * NS * 128 + lane;
+    }
+    uint4 bq[NB][2];
+    auto load_b = [&](int g, uint4 (&q)[2]) {
+        q[0] = wfrag[(size_t)(2 * g) * 64];
+        q[1] = wfrag[(size_t)(2 * g + 1) * 64];
+    };
+
+    // ---- the A rows: wave w stages the 8-row blocks w and w + 4 (rows 8w..8w+7 of both 32-row MFMA tiles: accumulator
+    // registers 4w..4w+3 of a tile), two rows per pass, a half-wave per row
+    const int c = lane & 31, lr = lane >> 5;
+    float4 va[8][KC];
+    bool aok[8];
+    size_t ro[8];
+    if (p.row_cnt == 1) {                            // identity row map (wave-uniform branch: no per-row division code)
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int r = m0 + (ps >> 2) * 32 + 8 * wave + (ps & 3) * 2 + lr;
+            aok[ps] = r < p.M;
+            ro[ps] = (size_t)((aok[ps] ? r : 0) * p.row_gstride + p.row_goff) * p.lda;       // a row past M: row 0, zeroed below
+        }
+    } else {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int r = m0 + (ps >> 2) * 32 + 8 * wave + (ps & 3) * 2 + lr;
+            aok[ps] = r < p.M;
+            ro[ps] = (size_t)phys_row(p, aok[ps] ? r : 0) * p.lda;
+        }
+    }
+    const float* Ak[KC];                             // K-segmented A: a 128-column chunk never straddles a segment
+#pragma unroll                                       // (a_seg % 128 == 0: launcher)
+    for (int kc = 0; kc < KC; ++kc) {
+        const int k = kc * 128;
+        const bool s2 = p.a_seg && k >= 2 * p.a_seg, s1 = p.a_seg && k >= p.a_seg;
+        Ak[kc] = (s2 ? p.A3 : (s1 ? p.A2 : p.A)) + (k - (s2 ? 2 * p.a_seg : (s1 ? p.a_seg : 0))) + 4 * c;
+    }
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) va[ps][kc] = ld4(Ak[kc] + ro[ps]);
+#pragma unroll
+    for (int g = 0; g < NB; ++g) load_b(g, bq[g]);
+
+    // ---- block exponent of this wave's 16 rows over all of K, planes -> LDS
+    float m = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            float4& v = va[ps][kc];
+            if (!aok[ps]) v = zero4();
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+    int need = (int)((wave_umax_sgpr(__float_as_uint(m)) >> 23) & 0xffu) - 126 - 15;             // |x| < 2^(need + 15)
+    if (__builtin_expect(need > 112, 0)) {           // an Inf in the block: scale by the finite values, so that only the
+        float mf = 0.f;                              // rows that hold it turn non-finite (as in gn_gemm.hip)
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps)
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const float cv[4] = {va[ps][kc].x, va[ps][kc].y, va[ps][kc].z, va[ps][kc].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mf = fmaxf(mf, fabsf(cv[q]) <= 3.0e38f ? fabsf(cv[q]) : 0.f);
+            }
+        need = (int)((wave_umax_sgpr(__float_as_uint(mf)) >> 23) & 0xffu) - 126 - 15;
+    }
+    need = need < -120 ? -120 : need;
+    const float scale = __uint_as_float((unsigned)(127 - need) << 23);          // 2^-need
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+        const int r = (ps >> 2) * 32 + 8 * wave + (ps & 3) * 2 + lr;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            f16x4 h, l;
+            split4_f16(va[ps][kc], scale, h, l);
+            _Float16* d = panel + r * KP + kc * 128 + 4 * c;
+            *reinterpret_cast<f16x4*>(d) = h;
+            *reinterpret_cast<f16x4*>(d + APL) = l;
+        }
+    }
+    if (lane == 0) reinterpret_cast<signed char*>(&exps_w)[wave] = (signed char)need;
+    __syncthreads();
+    const unsigned e_acc = (unsigned)__builtin_amdgcn_readfirstlane(exps_w);
+
+    // ---- k-steps off the panel: x = hi + lo per operand; lo*hi, hi*lo, hi*hi (lo*lo is below 2^-22 of the product)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const _Float16* Ap = panel + (wm * 32 + (lane & 31)) * KP + (lane >> 5) * 8;
+#pragma unroll
+    for (int g = 0; g < NS; ++g) {
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(Ap + g * 16);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(Ap + APL + g * 16);
+        const f16x8 bh = __builtin_bit_cast(f16x8, bq[g % NB][0]), bl = __builtin_bit_cast(f16x8, bq[g % NB][1]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        if (g + NB < NS) load_b(g + NB, bq[g % NB]);
+    }
+    __syncthreads();                                 // the epilogue tile overlays the panel
+
+    // ---- epilogue through LDS: accumulators -> [64][68] floats -> coalesced float4 rows
+    // (a lane holds column (lane & 31), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of its 32 x 32 tile)
+    float* const sc = reinterpret_cast<float*>(panel);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        sc[row * CP + wn * 32 + (lane & 31)] = ldexpf(acc[r], (int)(signed char)(e_acc >> (8 * (r >> 2))) + ewt);
+    }
+    __syncthreads();
+    constexpr int C4 = BN / 4;                      // 16 column groups: a thread keeps one, rows tid / 16 + 16 it
+    const int cc = (tid % C4) * 4, gn = n0 + cc;
+    if (gn >= p.N) return;
+    const float4 bias4 = p.bias ? ld4(p.bias + gn) : zero4();
+    const bool act = gn >= p.act_lo && gn < p.act_hi;
+    const int kind = ASILU ? (int)GN_ACT_SILU : p.act_kind;
+    size_t off[4];
+    bool ok[4];
+    float4 rv[4], gv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                    // every residual / gate row requested before the first store
+        const int gm = m0 + u * 16 + tid / C4;
+        ok[u] = gm < p.M;
+        off[u] = (size_t)phys_row(p, ok[u] ? gm : 0) * p.ldc + gn;
+        rv[u] = (ok[u] && p.res) ? ld4(p.res + off[u]) : zero4();
+        gv[u] = (ok[u] && p.gate) ? ld4(p.gate + off[u]) : zero4();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+        float4 v = ld4(&sc[(u * 16 + tid / C4) * CP + cc]) + bias4;
+        if (p.pre_out) st4(p.pre_out + off[u], v);
+        if (act) v = act4(v, kind);
+        if (p.gate) v = v * (p.gate_mode ? dact4(gv[u], kind) : gv[u]);
+        if (p.res) v = rv[u] + v;
+        st4(p.C + off[u], v);
+    }
+}
+
+}  // namespace gn
+
+// Launch the panel kernel for a validated group when it applies; returns 0 when the caller must use the slab kernel,
+// 1 after a launch, < 0 on a launch error.  Applies to: no prologue, one depth K in {128, 256, 512} for the whole group,
+// K-segments in whole 128-column chunks, at most GN_GEMM_PANEL_MAX tiles of 64 x 64.
+int gn_gemm_panel_launch(const gn::GemmArgs* g, int n, hipStream_t st) {
+    if (GN_GEMM_PANEL_MAX <= 0) return 0;
+    const int K = g[0].K;
+    if (K != 128 && K != 256 && K != 512) return 0;
+    gn::GroupArgs ga;
+    long end = 0;
+    bool silu = true;
+    for (int i = 0; i < n; ++i) {
+        if (g[i].K != K || g[i].pro_mode != 0 || g[i].a_gate != nullptr || (g[i].a_seg % 128) != 0) return 0;
+        silu = silu && g[i].act_kind == GN_ACT_SILU;
+    }
+    for (int i = 0; i < gn::GN_MAX_GROUP; ++i) {
+        ga.g[i] = g[i < n ? i : n - 1];
+        ga.g[i].nt_store = 0x7fffffff;
+        if (i < n) end += (long)((g[i].M + 63) / 64) * ((g[i].N + 63) / 64);
+        ga.tile_end[i] = (int)end;
+    }
+    ga.n = n;
+    ga.spread = 0;
+    if (end == 0 || end > (long)GN_GEMM_PANEL_MAX) return 0;
+    const unsigned grid = (unsigned)(8L * ((end + 7) / 8));
+#define GN_PANEL_GO(NK_)                                                                                              \
+    do {                                                                                                              \
+        if (silu) hipLaunchKernelGGL((gn::gemm_f16x2_panel<NK_, true>), dim3(grid), dim3(256), 0, st, ga);             \
+        else hipLaunchKernelGGL((gn::gemm_f16x2_panel<NK_, false>), dim3(grid), dim3(256), 0, st, ga);                 \
+    } while (0)
+    if (K == 128) GN_PANEL_GO(4);
+    else if (K == 256) GN_PANEL_GO(8);
+    else GN_PANEL_GO(16);
+#undef GN_PANEL_GO
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return -(int)e;
+    return 1;
+}

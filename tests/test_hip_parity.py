@@ -235,6 +235,58 @@ def test_gemm_group_and_segmented_k():
     assert rel_err(Cc.cpu(), refc) < 1e-5
 
 
+@pytest.mark.parametrize("K", [128, 256, 512])
+def test_gemm_panel_kernel_paths(K):
+    """The K-resident panel kernel (gn_gemm_panel.hip: f16x2 groups of <= 512 tiles with one depth K in {128, 256, 512}
+    and no prologue): ragged M / N, every epilogue, row maps, the K-segmented A operand and a group of equal-K problems,
+    against fp64 products; the same problems through the two other arithmetics (slab kernels) for comparison."""
+    from gotennet_amd import engine
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(K)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)
+    dd = lambda t: t.double().cpu()
+    silu = torch.nn.functional.silu
+    for mode in ("f16x2", "split", "f32"):
+        for (M, N) in [(1, 32), (63, 64), (130, 208), (257, 96), (1000, 384), (2688, 512)]:
+            A, W, b = r(M, K), r(N, K) / 8, r(N)
+            C, P = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+            lo, hi = (N // 16) * 4, (N // 8) * 4
+            engine.gemm(A, K, W, b, C, N, M, N, K, act=(lo, hi), pre_out=P, mode=mode)
+            pre = dd(A) @ dd(W).T + dd(b)
+            ref = pre.clone(); ref[:, lo:hi] = silu(ref[:, lo:hi])
+            assert rel_err(P.cpu(), pre) < 2e-6 and rel_err(C.cpu(), ref) < 2e-6
+            res, gate = r(M, N), r(M, N)
+            engine.gemm(A, K, W, b, C, N, M, N, K, act=(0, N), res=res, gate=gate, mode=mode)
+            assert rel_err(C.cpu(), dd(res) + silu(pre) * dd(gate)) < 2e-6
+            engine.gemm(A, K, W, None, C, N, M, N, K, dgate=gate, mode=mode)          # output * SiLU'(gate)
+            sg = torch.sigmoid(dd(gate))
+            assert rel_err(C.cpu(), (dd(A) @ dd(W).T) * (sg * (1 + dd(gate) * (1 - sg)))) < 2e-6
+        # row map: degree-2 rows (offset 3, count 5) of an [n, D = 8, K] tensor; rows outside stay untouched
+        n, D = 37, 8
+        X, W = r(n, D, K), r(K, K) / 8
+        out = torch.zeros(n, D, K, device=dev)
+        engine.gemm(X, K, W, None, out, K, n * 5, K, K, rowmap=(5, D, 3), mode=mode)
+        ref = torch.zeros(n, D, K, dtype=torch.double); ref[:, 3:] = dd(X)[:, 3:] @ dd(W).T
+        assert rel_err(out.cpu(), ref) < 2e-6 and float(out[:, :3].abs().max()) == 0.0
+        # K-segmented A in whole 128-column chunks + residual, and three equal-K problems in one launch
+        seg = K // 2 if K > 128 else 0
+        probs, refs = [], []
+        for q in range(3):
+            M, N = (300, 200, 77)[q], (64, 160, 256)[q]
+            W, C = r(N, K) / 8, torch.empty(M, N, device=dev)
+            if seg and q == 0:
+                A1, A2, R = r(M, seg), r(M, seg), r(M, N)
+                probs.append(dict(A=A1, A2=A2, a_seg=seg, lda=seg, W=W, C=C, ldc=N, rows=M, nout=N, K=K, res=R))
+                refs.append((C, dd(R) + torch.cat([dd(A1), dd(A2)], 1) @ dd(W).T))
+            else:
+                A = r(M, K)
+                probs.append(dict(A=A, lda=K, W=W, C=C, ldc=N, rows=M, nout=N, K=K))
+                refs.append((C, dd(A) @ dd(W).T))
+        engine.gemm_group(probs, mode=mode)
+        for C, ref in refs:
+            assert rel_err(C.cpu(), ref) < 2e-6
+
+
 @pytest.mark.parametrize("F,H", [(512, 8), (1024, 16), (16, 4)])
 def test_forward_feature_width_extremes(F, H):
     """Slot layout corner cases: F = 512/1024 (a slot spans 2/4 waves), F = 16 (64 slots per workgroup)."""
@@ -305,37 +357,39 @@ def test_fp16_block_exponent_products_on_hostile_operands():
             C, ref = run(A, W), A.double() @ W.double().t()
             assert rel_err(C.double().cpu(), ref.cpu()) < tol, rel_err(C.double().cpu(), ref.cpu())
 
-        W = rn(192, 256) * 0.1
-        for scale in (1e-20, 1e-6, 1.0, 1e6, 1e20):
-            check(rn(700, 256) * scale, W)
-            check(rn(700, 256), W * scale)
-        rows = rn(700, 256) * (10.0 ** torch.randint(-8, 1, (700, 1), device="cuda", generator=g).float())
-        check(rows, W)
-        grow = rn(700, 256)
-        grow[:, :96] *= 1e-9                                      # small slabs first: exponents grow, accumulators rescale
-        check(grow, W)
-        shrink = rn(700, 256)
-        shrink[:, 160:] *= 1e-9
-        check(shrink, W)
-        holes = rn(700, 256)
-        holes[64:200] = 0.0
-        holes[:, 32:64] = 0.0
-        check(holes, W)
-        check(torch.zeros(130, 256, device="cuda"), W, tol=1.0)   # 0 / 0: just must not produce NaN
-        assert float(run(torch.zeros(130, 256, device="cuda"), W).abs().max()) == 0.0
+        for N in (192, 3072):                                     # 33 tiles: the K-resident panel kernel; 528 tiles: the slab kernel
+            W = rn(N, 256) * 0.1
+            tol = 5e-7 if N == 192 else 8e-7                      # the maximum over 16 x more outputs sits higher
+            for scale in (1e-20, 1e-6, 1.0, 1e6, 1e20):
+                check(rn(700, 256) * scale, W, tol)
+                check(rn(700, 256), W * scale, tol)
+            rows = rn(700, 256) * (10.0 ** torch.randint(-8, 1, (700, 1), device="cuda", generator=g).float())
+            check(rows, W, tol)
+            grow = rn(700, 256)
+            grow[:, :96] *= 1e-9                                  # small slabs first: exponents grow, accumulators rescale
+            check(grow, W, tol)
+            shrink = rn(700, 256)
+            shrink[:, 160:] *= 1e-9
+            check(shrink, W, tol)
+            holes = rn(700, 256)
+            holes[64:200] = 0.0
+            holes[:, 32:64] = 0.0
+            check(holes, W, tol)
+            check(torch.zeros(130, 256, device="cuda"), W, tol=1.0)   # 0 / 0: just must not produce NaN
+            assert float(run(torch.zeros(130, 256, device="cuda"), W).abs().max()) == 0.0
+            # non-finite inputs propagate
+            bad = rn(700, 256)
+            bad[7, 5], bad[200, 100] = float("inf"), float("nan")
+            out = run(bad, W)
+            assert not torch.isfinite(out[7]).any() or torch.isnan(out[7]).any()
+            assert torch.isnan(out[200]).all()
+            assert torch.isfinite(out[100]).all()                 # other 8-row blocks are untouched
         # K-segmented A (three tensors along K, gX = gXp W_vu + gEQ W_vq + gEK W_vk): segments 1e6 apart
         A1, A2, A3 = rn(500, 64) * 1e-3, rn(500, 64) * 1e3, rn(500, 64)
         Wc = rn(64, 192) * 0.1
         C = run(A1, Wc, A2=A2, A3=A3, a_seg=64)
         ref = torch.cat([A1, A2, A3], 1).double() @ Wc.double().t()
         assert rel_err(C.double().cpu(), ref.cpu()) < 5e-7
-        # non-finite inputs propagate
-        bad = rn(300, 256)
-        bad[7, 5], bad[200, 100] = float("inf"), float("nan")
-        out = run(bad, W)
-        assert not torch.isfinite(out[7]).any() or torch.isnan(out[7]).any()
-        assert torch.isnan(out[200]).all()
-        assert torch.isfinite(out[100]).all()                     # other 8-row blocks are untouched
     finally:
         engine.GEMM_MODE = old
 
@@ -359,7 +413,8 @@ def test_fp16_block_exponent_per_row_bound():
     g = torch.Generator(device="cuda").manual_seed(11)
     rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
     K = 256
-    for M, N, BM in ((704, 192, 64), (9728, 1536, 128)):       # 64 x 64 tiles; the 128 x 128 tile (912 >= 900 big tiles)
+    # 64-row tiles of the panel kernel (33 tiles) and of the slab kernel (520 tiles > 512); the 128 x 128 tile (912 >= 900)
+    for M, N, BM in ((704, 192, 64), (4160, 512, 64), (9728, 1536, 128)):
         W = rn(N, K) * 0.1
         dec = torch.randint(-10, 1, (M, 1), device="cuda", generator=g).float()
         A = rn(M, K) * (10.0 ** dec)
