@@ -235,10 +235,10 @@ def test_gemm_group_and_segmented_k():
     assert rel_err(Cc.cpu(), refc) < 1e-5
 
 
-@pytest.mark.parametrize("K", [128, 256, 512])
+@pytest.mark.parametrize("K", [128, 256, 512, 768, 1536])
 def test_gemm_panel_kernel_paths(K):
-    """The K-resident panel kernel (gn_gemm_panel.hip: f16x2 groups of <= 512 tiles with one depth K in {128, 256, 512}
-    and no prologue): ragged M / N, every epilogue, row maps, the K-segmented A operand and a group of equal-K problems,
+    """The K-resident panel kernel (gn_gemm_panel.hip: f16x2 groups of <= 512 tiles, no prologue, one depth K in
+    {128, 256, 512} -- one panel per tile -- or depths that are multiples of 256 -- 256-deep chunks): ragged M / N, every epilogue, row maps, the K-segmented A operand and a group of equal-K problems,
     against fp64 products; the same problems through the two other arithmetics (slab kernels) for comparison."""
     from gotennet_amd import engine
     dev = "cuda"
@@ -269,15 +269,17 @@ def test_gemm_panel_kernel_paths(K):
         ref = torch.zeros(n, D, K, dtype=torch.double); ref[:, 3:] = dd(X)[:, 3:] @ dd(W).T
         assert rel_err(out.cpu(), ref) < 2e-6 and float(out[:, :3].abs().max()) == 0.0
         # K-segmented A in whole 128-column chunks + residual, and three equal-K problems in one launch
-        seg = K // 2 if K > 128 else 0
+        nseg = 0 if K == 128 else (2 if K <= 512 else 3)
+        seg = K // nseg if nseg else 0
         probs, refs = [], []
         for q in range(3):
             M, N = (300, 200, 77)[q], (64, 160, 256)[q]
             W, C = r(N, K) / 8, torch.empty(M, N, device=dev)
             if seg and q == 0:
-                A1, A2, R = r(M, seg), r(M, seg), r(M, N)
-                probs.append(dict(A=A1, A2=A2, a_seg=seg, lda=seg, W=W, C=C, ldc=N, rows=M, nout=N, K=K, res=R))
-                refs.append((C, dd(R) + torch.cat([dd(A1), dd(A2)], 1) @ dd(W).T))
+                As, R = [r(M, seg) * 10.0 ** (2 * i) for i in range(nseg)], r(M, N)      # segments 100x apart
+                probs.append(dict(A=As[0], A2=As[1], A3=As[2] if nseg == 3 else None, a_seg=seg, lda=seg, W=W, C=C, ldc=N,
+                                  rows=M, nout=N, K=K, res=R))
+                refs.append((C, dd(R) + torch.cat([dd(a) for a in As], 1) @ dd(W).T))
             else:
                 A = r(M, K)
                 probs.append(dict(A=A, lda=K, W=W, C=C, ldc=N, rows=M, nout=N, K=K))
@@ -285,6 +287,20 @@ def test_gemm_panel_kernel_paths(K):
         engine.gemm_group(probs, mode=mode)
         for C, ref in refs:
             assert rel_err(C.cpu(), ref) < 2e-6
+    if K == 1536:
+        # the one-molecule input-gradient group: depths 1536 / 1280 / 1280 / 512 in one launch (256-deep chunks), and a
+        # product whose chunks differ by 1e9 in both orders (the accumulator rows follow the growing block exponent)
+        Ms, Ns, Ks = (429, 21, 21, 21), (256, 256, 256, 256), (1536, 1280, 1280, 512)
+        As = [r(m, k) for m, k in zip(Ms, Ks)]
+        As[0][:, :512] *= 1e-9
+        As[1][:, 768:] *= 1e-9
+        Ws = [r(n, k) / 8 for n, k in zip(Ns, Ks)]
+        Rs = [r(m, n) for m, n in zip(Ms, Ns)]
+        Cs = [torch.empty(m, n, device=dev) for m, n in zip(Ms, Ns)]
+        engine.gemm_group([dict(A=a, lda=k, W=w, C=c, ldc=n, rows=m, nout=n, K=k, res=rr)
+                           for a, w, c, rr, m, n, k in zip(As, Ws, Cs, Rs, Ms, Ns, Ks)], mode="f16x2")
+        for a, w, c, rr in zip(As, Ws, Cs, Rs):
+            assert rel_err(c.cpu(), dd(rr) + dd(a) @ dd(w).T) < 2e-6
 
 
 @pytest.mark.parametrize("F,H", [(512, 8), (1024, 16), (16, 4)])
