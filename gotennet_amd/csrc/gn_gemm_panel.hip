@@ -1,14 +1,16 @@
 // gn_gemm_panel.hip -- the 2 x fp16-split projection for problems too small to hide their own latency.
 //
 // The slab kernel of gn_gemm.hip walks K in 32-deep slabs: fetch -> split -> LDS -> barrier -> 2 k-steps.  With hundreds of
-// tiles per CU two co-resident workgroups hide that chain behind each other; an atom-sized product (N = 2688 rows: 168-840
-// tiles of 64 x 64 for 256 CUs) has ONE tile per CU and pays the chain once per slab: measured 0.9 us per slab, 14-21 us per
-// launch for 0.7 GFLOP (reference call sites gotennet.py:400-405, 432-441, 728, 738 and their input-gradients).
-// Here the whole K extent of a tile's A rows (K = 128 / 256 / 512) is requested at once, split into its two fp16 planes
-// with ONE block exponent per wave and tile, parked in LDS as a [64][K] panel, and the k-steps run back to back off the
-// panel with the weight fragments (fragment-major planes of gn_split_f16x2, L2 -> registers) requested eight k-steps ahead:
-// one HBM round trip, one barrier, then 3 MFMAs per k-step and wave until the epilogue.
-//
+// tiles per CU two to four co-resident workgroups hide that chain behind each other; an atom-sized product (N = 2688 rows)
+// has ONE tile per CU and pays the chain once per slab: measured 0.9 us per slab, 14-21 us per launch for 0.7 GFLOP
+// (reference call sites gotennet.py:400-405, 432-441, 728, 738 and their input-gradients).
+// Here a workgroup owns a 32 x 128 tile (four waves side by side, one 32 x 32 MFMA tile each): the whole K extent of its 32
+// A rows (K = 128 / 256 / 512) is requested at once, split into the two fp16 planes with ONE block exponent per wave (its
+// eight rows) and tile, parked in LDS as a [32][K] panel, and the k-steps run back to back off the panel with the weight
+// fragments (fragment-major planes of gn_split_f16x2, L2 -> registers) requested eight k-steps ahead: one HBM round trip,
+// one barrier, then 3 MFMAs per k-step and wave until the epilogue.  (A 64 x 64 tile with 2 x 2 waves was built first and is
+// slower at every size: twice the rows to request, split and park per workgroup for the same MFMA work per wave --
+// [2688 x 512 x 256] 9.1 vs 7.9 us, [2688 x 256 x 512] 10.3 vs 8.6, the one-molecule [429 x 256 x 1536] 22.2 vs 18.5.)
 // Deeper products (K a multiple of 256, e.g. the K = 1536 input-gradient of the edge projection in a one-molecule call)
 // walk 256-deep chunks of the same panel: the next chunk's rows are in flight under the current chunk's k-steps, the block
 // exponent only grows and the accumulator rows follow it (exact: powers of two), as in the slab kernel.
@@ -27,7 +29,8 @@ __global__ __launch_bounds__(256) void gemm_f16x2_panel(const GroupArgs ga) {
     constexpr int K = 32 * NK;                      // depth of a panel: all of K, or (MULTI) one chunk of a K that is a multiple of it
     constexpr int KP = K + 8;                       // fp16 per panel row: (K + 8) / 2 dwords = 4 mod 64, so the 16-lane groups
                                                     // of a ds_read_b128 (16 rows, 16 bytes each) hit 16 distinct 4-bank slots
-    constexpr int BM = 64, BN = 64, CP = BN + 4;
+    constexpr int BM = 32, BN = 128, CP = BN + 4;
+    constexpr int NPS = 4;                          // staging passes of a wave: two rows each (its 8-row block)
     constexpr int APL = BM * KP;                    // fp16 per plane
     constexpr int KC = K / 128;                     // 128-column chunks of a row: one half-wave reads 512 contiguous bytes
     constexpr int NS = 2 * NK;                      // k-steps of 16
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void gemm_f16x2_panel(const GroupArgs ga) {
     const int m0 = ((t - first) / tiles_n) * BM, n0 = ((t - first) % tiles_n) * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wn = wave;                            // four waves side by side
 
     // MULTI: K is a run-time multiple of the chunk depth; the panel is refilled per chunk, the accumulators carry on
     const int nch = MULTI ? p.K / K : 1;
@@ -92,23 +95,23 @@ __global__ __launch_bounds__(256) void gemm_f16x2_panel(const GroupArgs ga) {
         q[1] = wfrag[(size_t)(2 * g + 1) * 64];
     };
 
-    // ---- the A rows: wave w stages the 8-row blocks w and w + 4 (rows 8w..8w+7 of both 32-row MFMA tiles: accumulator
-    // registers 4w..4w+3 of a tile), two rows per pass, a half-wave per row
+    // ---- the A rows: wave w stages rows 8w..8w+7 (accumulator registers 4w..4w+3 of every wave's MFMA tile), two rows
+    // per pass, a half-wave per row
     const int c = lane & 31, lr = lane >> 5;
-    float4 va[8][KC];
-    bool aok[8];
-    size_t ro[8];
+    float4 va[NPS][KC];
+    bool aok[NPS];
+    size_t ro[NPS];
     if (p.row_cnt == 1) {                            // identity row map (wave-uniform branch: no per-row division code)
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-            const int r = m0 + (ps >> 2) * 32 + 8 * wave + (ps & 3) * 2 + lr;
+        for (int ps = 0; ps < NPS; ++ps) {
+            const int r = m0 + 8 * wave + ps * 2 + lr;
             aok[ps] = r < p.M;
             ro[ps] = (size_t)((aok[ps] ? r : 0) * p.row_gstride + p.row_goff) * p.lda;       // a row past M: row 0, zeroed below
         }
     } else {
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-            const int r = m0 + (ps >> 2) * 32 + 8 * wave + (ps & 3) * 2 + lr;
+        for (int ps = 0; ps < NPS; ++ps) {
+            const int r = m0 + 8 * wave + ps * 2 + lr;
             aok[ps] = r < p.M;
             ro[ps] = (size_t)phys_row(p, aok[ps] ? r : 0) * p.lda;
         }
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void gemm_f16x2_panel(const GroupArgs ga) {
             const unsigned long long a0 = (unsigned long long)seg_ptr[0], a1 = (unsigned long long)seg_ptr[1], a2 = (unsigned long long)seg_ptr[2];
             const float* Ak = reinterpret_cast<const float*>(s2 ? a2 : (s1 ? a1 : a0)) + (k - (s2 ? 2 * a_seg : (s1 ? a_seg : 0))) + 4 * c;
 #pragma unroll
-            for (int ps = 0; ps < 8; ++ps) va[ps][kc] = ld4(Ak + ro[ps]);
+            for (int ps = 0; ps < NPS; ++ps) va[ps][kc] = ld4(Ak + ro[ps]);
         }
     };
     fetch_chunk(0);
@@ -134,13 +137,13 @@ __global__ __launch_bounds__(256) void gemm_f16x2_panel(const GroupArgs ga) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     int e_run = -120;                                // staging side: this wave's block exponent (only grows over the chunks)
     unsigned e_acc = 0x88888888u;                    // MFMA side: the exponents (bytes) the accumulator rows are held in
-    const _Float16* Ap = panel + (wm * 32 + (lane & 31)) * KP + (lane >> 5) * 8;
+    const _Float16* Ap = panel + (lane & 31) * KP + (lane >> 5) * 8;
 
     for (int ch = 0; ch < nch; ++ch) {
         // ---- block exponent of this wave's 16 rows over the chunk, planes -> LDS
         float m = 0.f;
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps)
+        for (int ps = 0; ps < NPS; ++ps)
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
                 float4& v = va[ps][kc];
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void gemm_f16x2_panel(const GroupArgs ga) {
         if (__builtin_expect(need > 112, 0)) {       // an Inf in the block: scale by the finite values, so that only the
             float mf = 0.f;                          // rows that hold it turn non-finite (as in gn_gemm.hip)
 #pragma unroll
-            for (int ps = 0; ps < 8; ++ps)
+            for (int ps = 0; ps < NPS; ++ps)
 #pragma unroll
                 for (int kc = 0; kc < KC; ++kc) {
                     const float cv[4] = {va[ps][kc].x, va[ps][kc].y, va[ps][kc].z, va[ps][kc].w};
@@ -164,8 +167,8 @@ __global__ __launch_bounds__(256) void gemm_f16x2_panel(const GroupArgs ga) {
         e_run = need > e_run ? need : e_run;
         const float scale = __uint_as_float((unsigned)(127 - e_run) << 23);     // 2^-e_run
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-            const int r = (ps >> 2) * 32 + 8 * wave + (ps & 3) * 2 + lr;
+        for (int ps = 0; ps < NPS; ++ps) {
+            const int r = 8 * wave + ps * 2 + lr;
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
                 f16x4 h, l;
@@ -178,7 +181,8 @@ __global__ __launch_bounds__(256) void gemm_f16x2_panel(const GroupArgs ga) {
         if (lane == 0) reinterpret_cast<signed char*>(&exps_w)[wave] = (signed char)e_run;
         __syncthreads();
         // the next chunk's rows go in flight now: they are older than every weight fragment requested below, so no
-        // fragment wait of THIS chunk's k-steps (ring of a whole chunk when MULTI) ever queues behind them
+        // fragment wait of THIS chunk's k-steps (ring of a whole chunk when MULTI) ever queues behind them.  (Two chunks
+        // ahead in a second register set: slower at every size -- 254 VGPRs, [429 x 256 x 1536] 18.5 -> 19.4 us.)
         if (MULTI && ch + 1 < nch) fetch_chunk(ch + 1);
         const unsigned en = (unsigned)__builtin_amdgcn_readfirstlane(exps_w);
         if (MULTI && __builtin_expect(en != e_acc && ch > 0, 0)) {               // the block exponents grew: bring the
@@ -213,11 +217,11 @@ __global__ __launch_bounds__(256) void gemm_f16x2_panel(const GroupArgs ga) {
     float* const sc = reinterpret_cast<float*>(panel);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         sc[row * CP + wn * 32 + (lane & 31)] = ldexpf(acc[r], (int)(signed char)(e_acc >> (8 * (r >> 2))) + ewt);
     }
     __syncthreads();
-    constexpr int C4 = BN / 4;                      // 16 column groups: a thread keeps one, rows tid / 16 + 16 it
+    constexpr int C4 = BN / 4, RP = 256 / C4;       // column groups (a thread keeps one) and rows per pass: four passes either way
     const int cc = (tid % C4) * 4, gn = n0 + cc;
     if (gn >= p.N) return;
     const float4 bias4 = p.bias ? ld4(p.bias + gn) : zero4();
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256) void gemm_f16x2_panel(const GroupArgs ga) {
     float4 rv[4], gv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {                    // every residual / gate row requested before the first store
-        const int gm = m0 + u * 16 + tid / C4;
+        const int gm = m0 + u * RP + tid / C4;
         ok[u] = gm < p.M;
         off[u] = (size_t)phys_row(p, ok[u] ? gm : 0) * p.ldc + gn;
         rv[u] = (ok[u] && p.res) ? ld4(p.res + off[u]) : zero4();
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(256) void gemm_f16x2_panel(const GroupArgs ga) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         if (!ok[u]) continue;
-        float4 v = ld4(&sc[(u * 16 + tid / C4) * CP + cc]) + bias4;
+        float4 v = ld4(&sc[(u * RP + tid / C4) * CP + cc]) + bias4;
         if (p.pre_out) st4(p.pre_out + off[u], v);
         if (act) v = act4(v, kind);
         if (p.gate) v = v * (p.gate_mode ? dact4(gv[u], kind) : gv[u]);
@@ -250,15 +254,13 @@ __global__ __launch_bounds__(256) void gemm_f16x2_panel(const GroupArgs ga) {
 
 // Launch the panel kernel for a validated group when it applies; returns 0 when the caller must use the slab kernel,
 // 1 after a launch, < 0 on a launch error.  Applies to: no prologue, K-segments in whole 128-column pieces, at most
-// GN_GEMM_PANEL_MAX tiles of 64 x 64, and either ONE depth K in {128, 256, 512} for the whole group (one panel per tile)
-// or depths that are all multiples of 256 (K = 768 ... 1536 and mixed groups: 256-deep chunks, the next chunk's rows in
-// flight under the current chunk's k-steps -- what a one-molecule call's K-heavy input-gradient products need: 48 slab
-// chains in a row are 60 us for 28 tiles).
+// GN_GEMM_PANEL_MAX tiles of 32 x 128, and either ONE depth K in {128, 256, 512} for the whole group (one panel per tile)
+// or depths that are all multiples of 256 (K = 768 ... 1536 and mixed groups: 256-deep chunks -- what a one-molecule
+// call's K-heavy input-gradient products need: 48 slab chains in a row are 27 us for 28 tiles).
 int gn_gemm_panel_launch(const gn::GemmArgs* g, int n, hipStream_t st) {
     if (GN_GEMM_PANEL_MAX <= 0) return 0;
     const int K = g[0].K;
     gn::GroupArgs ga;
-    long end = 0;
     bool silu = true, same = true, m256 = true;
     for (int i = 0; i < n; ++i) {
         if (g[i].pro_mode != 0 || g[i].a_gate != nullptr || (g[i].a_seg % 128) != 0) return 0;
@@ -268,10 +270,11 @@ int gn_gemm_panel_launch(const gn::GemmArgs* g, int n, hipStream_t st) {
     }
     const bool single = same && (K == 128 || K == 256 || K == 512);
     if (!single && !m256) return 0;
+    long end = 0;
     for (int i = 0; i < gn::GN_MAX_GROUP; ++i) {
         ga.g[i] = g[i < n ? i : n - 1];
         ga.g[i].nt_store = 0x7fffffff;
-        if (i < n) end += (long)((g[i].M + 63) / 64) * ((g[i].N + 63) / 64);
+        if (i < n) end += (long)((g[i].M + 31) / 32) * ((g[i].N + 127) / 128);
         ga.tile_end[i] = (int)end;
     }
     ga.n = n;

@@ -76,10 +76,12 @@
 #define GN_GEMM_NT_LO (-1)     // ... from this column on (-1: the first K columns stay on the normal path)
 #endif
 #ifndef GN_GEMM_PANEL_MAX
-#define GN_GEMM_PANEL_MAX 512    // f16x2 groups of at most this many 64 x 64 tiles (one depth K in {128, 256, 512}, no prologue) run the
-#endif                          // K-resident panel kernel (gn_gemm_panel.hip); 0: never.  Measured inside the C2 step: [2688 x 256 x 256]
-                                // 14.1 -> 12.0 us, [2688 x 512 x 256] 15.1 -> 13.4, [2688 x 256 x 512] 22.1 -> 20.2; from ~1000 tiles
-                                // up the slab kernel's co-resident workgroups win (two [2688 x 1280 x 256]: 29.1 vs 34.1 us)
+#define GN_GEMM_PANEL_MAX 2048   // f16x2 groups of at most this many 32 x 128 tiles (no prologue; one depth K in {128, 256, 512} or depths
+#endif                          // that are multiples of 256) run the K-resident panel kernel (gn_gemm_panel.hip); 0: never.  Inside the C2
+                                // step: [2688 x 256 x 256] 14.1 -> 12 us, [2688 x 512 x 256] 15.1 -> 13.4, two [2688 x 1280 x 256] 29.1 ->
+                                // 26.6, [8064 + 13440 x 256 x 768] 62 -> 57.9; at 3400-4000 tiles the slab kernel's co-resident workgroups
+                                // win (the gated edge product 67 vs 78.7 us, the four-problem X group 47.4 vs 51.7, the K = 1536
+                                // input-gradient group 184 vs 243.6)
 #ifndef GN_HTR_CLOSED
 #define GN_HTR_CLOSED 1        // htr_edge_kernel at lmax = 3: closed form EQ.EK - (2 - r.r)(EQ.r)(EK.r) instead of two rejections
 #endif

@@ -59,7 +59,7 @@ def shape(M, N, K, it=50, epi=False):
 
 for s in ((2688, 512, 256), (2688, 256, 512), (2688, 256, 256), (2688, 1280, 256), (2688, 768, 256), (21504, 256, 256),
           (21, 512, 256), (441, 1536, 256), (2688, 256, 128), (54368, 256, 256), (429, 256, 1536), (168, 256, 768),
-          (2688, 256, 1536), (2688, 256, 768)):
+          (2688, 256, 1536), (2688, 256, 768), (21504, 256, 768), (5376, 1280, 256)):
     shape(*s)
 shape(2688, 256, 256, epi=True)
 shape(54368, 256, 256, epi=True)
