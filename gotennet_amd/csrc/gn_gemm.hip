@@ -729,6 +729,9 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     // 4-20 % faster as 3400 64x64 tiles, the [E x 1536 x 256] product (5100 tiles) and the four-problem X group (1008)
     // want the big tile
     const bool use_big = big >= (long)GN_GEMM_BIG_MIN;
+    // the f16x2 small tile is 32 x 128 (waves 1 x 4: a row is split once per 128 columns) unless a problem is narrower than a tile
+    bool wide = GN_F16_SMALL_WIDE && split == 2;
+    for (int i = 0; i < n; ++i) wide = wide && g[i].N >= 128;
     long end = 0;
     // outputs of 100 MB and more (the [E, (1+M)F] edge projection) are stored non-temporally: they are consumed by
     // later kernels from HBM anyway and would only evict the node tables (K6 +5 %); GN_GEMM_NT_MB (gn_tune.h)
@@ -742,7 +745,8 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
         const int nt_lo = GN_GEMM_NT_LO >= 0 ? GN_GEMM_NT_LO : ga.g[i].K;
         ga.g[i].nt_store = (double)ga.g[i].M * ga.g[i].N * 4.0 >= nt_min ? (ga.g[i].N > nt_lo ? nt_lo : 0) : 0x7fffffff;
         if (i < n) end += use_big ? (long)((g[i].M + BMB - 1) / BMB) * ((g[i].N + BNB - 1) / BNB)
-                                  : (long)((g[i].M + 63) / 64) * ((g[i].N + 63) / 64);
+                                  : (wide ? (long)((g[i].M + 31) / 32) * ((g[i].N + 127) / 128)
+                                                                     : (long)((g[i].M + 63) / 64) * ((g[i].N + 63) / 64));
         ga.tile_end[i] = (int)end;
     }
     ga.n = n;
@@ -756,7 +760,7 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     if (end == 0) return GN_OK;
     // persistent launch: at most 2 (big tiles) / 4 (small tiles) workgroups per CU walk the tile list (+2 %)
     long grid = 8L * ((end + 7) / 8);
-    const long cap = use_big ? cap_big : 1024;
+    const long cap = use_big ? cap_big : (wide ? (long)GN_F16_SMALL_CAP : 1024);
     if (grid > cap) grid = cap;
     bool silu = true;
     for (int i = 0; i < n; ++i) silu = silu && g[i].act_kind == GN_ACT_SILU;
@@ -784,6 +788,7 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
 #endif
     if (split == 2) {
         if (use_big) { if (pro) GN_GEMM_GO_H(4, 1, 1, 4, true); else GN_GEMM_GO_H(4, 1, 1, 4, false); }
+        else if (wide) { if (pro) GN_GEMM_GO_H(1, 1, 1, 4, true); else GN_GEMM_GO_H(1, 1, 1, 4, false); }
         else { if (pro) GN_GEMM_GO_H(1, 1, 2, 2, true); else GN_GEMM_GO_H(1, 1, 2, 2, false); }
     } else if (split) {
         if (use_big) { if (pro) GN_SPLIT_BIG(true); else GN_SPLIT_BIG(false); }

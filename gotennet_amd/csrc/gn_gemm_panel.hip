@@ -264,6 +264,7 @@ int gn_gemm_panel_launch(const gn::GemmArgs* g, int n, hipStream_t st) {
     bool silu = true, same = true, m256 = true;
     for (int i = 0; i < n; ++i) {
         if (g[i].pro_mode != 0 || g[i].a_gate != nullptr || (g[i].a_seg % 128) != 0) return 0;
+        if (g[i].N < 128 && g[i].M > 4096) return 0;    // a long narrow product ([E x 32 x 512]: 33 us on 64 x 64 slab tiles, 52 us here: three of four waves idle)
         same = same && g[i].K == K;
         m256 = m256 && (g[i].K % 256) == 0;
         silu = silu && g[i].act_kind == GN_ACT_SILU;

@@ -82,6 +82,14 @@
                                 // 26.6, [8064 + 13440 x 256 x 768] 62 -> 57.9; at 3400-4000 tiles the slab kernel's co-resident workgroups
                                 // win (the gated edge product 67 vs 78.7 us, the four-problem X group 47.4 vs 51.7, the K = 1536
                                 // input-gradient group 184 vs 243.6)
+#ifndef GN_F16_SMALL_WIDE
+#define GN_F16_SMALL_WIDE 1      // the small tile of the f16x2 slab kernel: 1 = 32 x 128 (waves 1 x 4) when every N >= 128, 0 = always 64 x 64
+                                // (waves 2 x 2).  Stand-alone [54368 x 256 x 256] 50.6 -> 47.2 us, with the gated epilogue 58.5 -> 53.9; in the
+                                // step (HBM-bound: res, gate, pre_out) 67 -> 66 us
+#endif
+#ifndef GN_F16_SMALL_CAP
+#define GN_F16_SMALL_CAP 1024     // persistent workgroups of that kernel
+#endif
 #ifndef GN_HTR_CLOSED
 #define GN_HTR_CLOSED 1        // htr_edge_kernel at lmax = 3: closed form EQ.EK - (2 - r.r)(EQ.r)(EK.r) instead of two rejections
 #endif
