@@ -627,7 +627,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
         # split modes: the kernel EXECUTES several 16-bit MFMA flops per algorithmic fp32 flop (six bf16 terms, or three
         # fp16 terms with block exponents), so it is priced against the dense 16-bit matrix peak:
         # achieved = terms x algorithmic flops / time
-        terms, kname, what = ((3, "gn::gemm_f16x2_mfma", "3 fp16 MFMAs on 2 scaled fp16 planes") if _engine_mode() == "f16x2"
+        terms, kname, what = ((3, "gn::gemm_f16x2_mfma + gn::gemm_f16x2_panel", "3 fp16 MFMAs on 2 scaled fp16 planes") if _engine_mode() == "f16x2"
                               else (6, "gn::gemm_bf16x3_mfma", "6 bf16 MFMAs on 3 bf16 planes"))
         return dict(kernel=f"{kname} (all projection launches; every fp32 product as {what}, fp32 accumulate)",
                     bound="mfma", achieved=round(terms * ach, 1), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
