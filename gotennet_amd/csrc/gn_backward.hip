@@ -907,7 +907,7 @@ __host__ __device__ inline Dual3 operator*(Dual3 a, float s) { return s * a; }
 
 // per edge: g_phi [R], g_cut, g_rl [D]  ->  g_vec [3] (through the unit vector) and g_diff (through the distance)
 template <int LMAX>
-__global__ void edge_geometry_bwd_kernel(
+__global__ __launch_bounds__(128) void edge_geometry_bwd_kernel(
     const float* __restrict__ vec, const float* __restrict__ dist, const int* __restrict__ src, const int* __restrict__ dst,
     int E, int R, int basis, const float* __restrict__ means, const float* __restrict__ betas, float cutoff, float alpha,
     const float* __restrict__ g_rl, int n_rl, const float* __restrict__ g_cut, int n_cut,
@@ -941,15 +941,29 @@ __global__ void edge_geometry_bwd_kernel(
         float s = 0.f;
         if (basis == 0) {
             const float u = expf(alpha * (-d));
-            for (int r = 0; r < R; ++r) {
+            // d/dd [ c G ] = dc G + c G (-2 beta w) (-alpha u)
+            auto term = [&](int r, float gp) {
                 const float w = u - means[r];
                 const float G = expf(-betas[r] * (w * w));
-                // d/dd [ c G ] = dc G + c G (-2 beta w) (-alpha u)
-                s += g_phi[(size_t)e * R + r] * G * (dc + c * (2.0f * betas[r] * w * alpha * u));
+                s += gp * G * (dc + c * (2.0f * betas[r] * w * alpha * u));
+            };
+            if ((R & 3) == 0) {                      // a lane's own row in 16-byte pieces (a quarter of the divergent loads)
+                for (int r = 0; r < R; r += 4) {
+                    const float4 gp = ld4(g_phi + (size_t)e * R + r);
+                    term(r, gp.x); term(r + 1, gp.y); term(r + 2, gp.z); term(r + 3, gp.w);
+                }
+            } else {
+                for (int r = 0; r < R; ++r) term(r, g_phi[(size_t)e * R + r]);
             }
         }
-        float gc = 0.f;                              // fixed-order sum of the per-kernel slices
-        for (int q = 0; q < n_cut; ++q) gc += g_cut[(size_t)q * E + e];
+        float gc = 0.f;                              // fixed-order sum of the per-kernel slices (four loads in flight)
+        int q = 0;
+        for (; q + 4 <= n_cut; q += 4) {
+            const float c0 = g_cut[(size_t)q * E + e], c1 = g_cut[(size_t)(q + 1) * E + e];
+            const float c2 = g_cut[(size_t)(q + 2) * E + e], c3 = g_cut[(size_t)(q + 3) * E + e];
+            gc += c0; gc += c1; gc += c2; gc += c3;
+        }
+        for (; q < n_cut; ++q) gc += g_cut[(size_t)q * E + e];
         gd += s + gc * dc;
     }
     g_diff[e] = gd;
@@ -958,12 +972,30 @@ __global__ void edge_geometry_bwd_kernel(
     const float ux = x / n, uy = y / n, uz = z / n;
     Dual3 o[D];
     real_harmonics<LMAX, Dual3>(Dual3{ux, {1.f, 0.f, 0.f}}, Dual3{uy, {0.f, 1.f, 0.f}}, Dual3{uz, {0.f, 0.f, 1.f}}, o);
+    // fixed-order sum of the per-kernel slices, a slice's D values of this edge per trip (they are contiguous: D = 8 is two
+    // 16-byte loads).  With the slice loop innermost every one of the n_rl * D loads was its own dependent round trip:
+    // 30 us at C2 and 21 us for ONE molecule.
+    float gsum[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) gsum[m] = 0.f;
+#pragma unroll 2
+    for (int q = 0; q < n_rl; ++q) {
+        const float* row = g_rl + ((size_t)q * E + e) * D;
+        if constexpr (D % 4 == 0) {
+#pragma unroll
+            for (int m = 0; m < D; m += 4) {
+                const float4 v = ld4(row + m);
+                gsum[m] += v.x; gsum[m + 1] += v.y; gsum[m + 2] += v.z; gsum[m + 3] += v.w;
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < D; ++m) gsum[m] += row[m];
+        }
+    }
     float gu0 = 0.f, gu1 = 0.f, gu2 = 0.f;
 #pragma unroll
     for (int m = 0; m < D; ++m) {
-        float g = 0.f;
-        for (int q = 0; q < n_rl; ++q) g += g_rl[((size_t)q * E + e) * D + m];
-        gu0 += g * o[m].d[0]; gu1 += g * o[m].d[1]; gu2 += g * o[m].d[2];
+        gu0 += gsum[m] * o[m].d[0]; gu1 += gsum[m] * o[m].d[1]; gu2 += gsum[m] * o[m].d[2];
     }
     const float dotp = gu0 * ux + gu1 * uy + gu2 * uz;      // u = v / |v|:  g_v = (g_u - (g_u . u) u) / |v|
     g_vec[3 * e] = (gu0 - dotp * ux) / n;
@@ -972,24 +1004,35 @@ __global__ void edge_geometry_bwd_kernel(
 }
 
 // g_pos[n] = sum_{e: src = n} gv[e] - sum_{e: dst = n} gv[e],  gv = g_vec + g_diff * vec / |vec|
-__global__ void pos_scatter_kernel(const float* __restrict__ g_vec, const float* __restrict__ g_diff,
-                                   const float* __restrict__ vec,
-                                   const int* __restrict__ rowptr, const int* __restrict__ colptr,
-                                   const int* __restrict__ perm, int N, float sign, float* __restrict__ g_pos) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 3 * N) return;
-    const int n = idx / 3, k = idx % 3;
-    auto gv = [&](int e) {
+// One wave per atom: the lanes stride over its outgoing (CSC) and incoming (CSR) edges, then a fixed-order wave sum per
+// component (a thread per (atom, component) walked ~40 edges one dependent round trip at a time: 28 us at C2, 20 us for ONE
+// molecule).
+__global__ __launch_bounds__(256) void pos_scatter_kernel(const float* __restrict__ g_vec, const float* __restrict__ g_diff,
+                                                          const float* __restrict__ vec,
+                                                          const int* __restrict__ rowptr, const int* __restrict__ colptr,
+                                                          const int* __restrict__ perm, int N, float sign, float* __restrict__ g_pos) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    auto add = [&](int e, float w) {
         const float x = vec[3 * e], y = vec[3 * e + 1], z = vec[3 * e + 2];
         const float gd = g_diff[e];
-        float r = g_vec[3 * e + k];
-        if (gd != 0.f) r += gd * vec[3 * e + k] / sqrtf(x * x + y * y + z * z);
-        return r;
+        float rx = g_vec[3 * e], ry = g_vec[3 * e + 1], rz = g_vec[3 * e + 2];
+        if (gd != 0.f) {
+            const float q = gd / sqrtf(x * x + y * y + z * z);
+            rx += q * x; ry += q * y; rz += q * z;
+        }
+        sx += w * rx; sy += w * ry; sz += w * rz;
     };
-    float s = 0.f;
-    for (int pp = colptr[n]; pp < colptr[n + 1]; ++pp) s += gv(perm[pp]);
-    for (int e = rowptr[n]; e < rowptr[n + 1]; ++e) s -= gv(e);
-    g_pos[idx] = sign * s;
+    const int p0 = colptr[n], p1 = colptr[n + 1], e0 = rowptr[n], e1 = rowptr[n + 1];
+    for (int pp = p0 + lane; pp < p1; pp += 64) add(perm[pp], 1.0f);
+    for (int e = e0 + lane; e < e1; e += 64) add(e, -1.0f);
+    sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+    if (lane == 0) {
+        g_pos[3 * n] = sign * sx;
+        g_pos[3 * n + 1] = sign * sy;
+        g_pos[3 * n + 2] = sign * sz;
+    }
 }
 
 // =========================================================================== energy head (Atomwise)
@@ -1257,7 +1300,7 @@ extern "C" int gn_pos_scatter(const float* g_vec, const float* g_diff, const flo
                               float* out, void* stream) {
     if (N < 0) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
-    hipLaunchKernelGGL(gn::pos_scatter_kernel, dim3((3 * N + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(gn::pos_scatter_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        g_vec, g_diff, edge_vec, rowptr, colptr, perm, N, sign, out);
     GN_LAUNCH_CHECK();
     return GN_OK;
