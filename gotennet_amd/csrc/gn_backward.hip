@@ -1038,14 +1038,14 @@ __global__ __launch_bounds__(256) void pos_scatter_kernel(const float* __restric
 // =========================================================================== energy head (Atomwise)
 // y_n = scale * (sum_k SiLU(pre1[n,k]) W2[k] + b2) + shift (+ atomref[z_n]);  E_mol = agg_{n in mol} y_n + mol_shift
 // (mol_shift: AtomwiseV3 adds its mean AFTER the aggregation, outputs.py:212; Atomwise standardises per atom: 0)
-__global__ __launch_bounds__(256) void head_energy_kernel(
+__global__ __launch_bounds__(1024) void head_energy_kernel(
     const float* __restrict__ pre1, const float* __restrict__ W2, float b2, float scale, float shift, float mol_shift,
     const float* __restrict__ atomref, const int* __restrict__ z, const int* __restrict__ mol_ptr,
     int Hd, float* __restrict__ y, float* __restrict__ energy, int mean, float* __restrict__ atom_scale, int act) {
     const int b = blockIdx.x;
     const int n0 = mol_ptr[b], n1 = mol_ptr[b + 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int n = n0 + wave; n < n1; n += 4) {
+    for (int n = n0 + wave; n < n1; n += 16) {       // 16 waves: a 21-atom molecule is two dependent trips instead of six
         float s = 0.f;
         for (int k = lane; k < Hd; k += 64) s += act1(pre1[(size_t)n * Hd + k], act) * W2[k];
         s = wave_sum(s);
@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(256) void head_energy_kernel(
         if (lane == 0) energy[b] = ((mean && n1 > n0) ? s / (float)(n1 - n0) : s) + mol_shift;   // aggregation_mode "mean" / "sum"
     }
     if (atom_scale)                                  // d(aggregate) / d(y_n): what gn_head_grad multiplies by
-        for (int n = n0 + (int)threadIdx.x; n < n1; n += 256) atom_scale[n] = mean ? 1.0f / (float)(n1 - n0) : 1.0f;
+        for (int n = n0 + (int)threadIdx.x; n < n1; n += 1024) atom_scale[n] = mean ? 1.0f / (float)(n1 - n0) : 1.0f;
 }
 
 __global__ void head_grad_kernel(const float* __restrict__ pre1, const float* __restrict__ W2, float scale,
@@ -1311,7 +1311,7 @@ extern "C" int gn_head_energy(const float* pre1, const float* W2, float b2, floa
                               float* y, float* energy, int mean, float* atom_scale, int act, void* stream) {
     if (n_mol < 0 || Hd <= 0 || act < 0 || act >= GN_ACT_COUNT) return GN_ERR_BAD_ARG;
     if (n_mol == 0) return GN_OK;
-    hipLaunchKernelGGL(gn::head_energy_kernel, dim3(n_mol), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(gn::head_energy_kernel, dim3(n_mol), dim3(1024), 0, (hipStream_t)stream,
                        pre1, W2, b2, scale, shift, mol_shift, atomref, z, mol_ptr, Hd, y, energy, mean, atom_scale, act);
     GN_LAUNCH_CHECK();
     return GN_OK;
