@@ -11,6 +11,9 @@
 // tile; each wave a (32 TM) x (32 TN) patch of 32x32 MFMA tiles.  TM = TN = 2 for
 // the edge-sized products, TM = TN = 1 when the problem has too few 128x128 tiles to
 // fill 256 CUs (atom-sized products: a wave's chain of 64-cycle MFMAs is the latency).
+// (The plane arithmetics below use 1 x 4 waves instead: 128 x 128 big tiles, and in the f16x2
+// arithmetic 32 x 128 small tiles when every N >= 128; small f16x2 groups leave this file
+// altogether for the K-resident panel kernel of gn_gemm_panel.hip.)
 // K in slabs of 32.  A and W slabs are staged through LDS as [rows][36] floats: the
 // 36-float pitch keeps ds_read_b128 conflict-free for its 16-lane service groups
 // (r*36 mod 64 hits 16 distinct 4-bank slots) and keeps 16-byte alignment.  Within a
