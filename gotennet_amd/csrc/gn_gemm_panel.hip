@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void gemm_f16x2_panel(const GroupArgs ga) {
     __shared__ __attribute__((aligned(16))) _Float16 panel[2 * APL];
     __shared__ int exps_w;                          // the four waves' block exponents (signed bytes)
 
-    // tile of this workgroup: the concatenated 64 x 64 tile list is cut into 8 contiguous ranges, XCD x (= blockIdx % 8)
+    // tile of this workgroup: the concatenated 32 x 128 tile list is cut into 8 contiguous ranges, XCD x (= blockIdx % 8)
     // takes range x -- neighbouring column tiles share their A rows through one L2
     int tiles_all = ga.tile_end[0];
 #pragma unroll
