@@ -164,7 +164,14 @@ class Config:
         return self.lmax_arg | {0: 0, 1: _lib.LMAX_MEAN, 2: _lib.LMAX_MAX}[self.aggr]
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """The current stream's handle.  (``torch.cuda.current_stream().cuda_stream`` builds a Stream object per call: 4 us, a
+    hundred times per step -- a fifth of the host time of a one-molecule eager step.)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -241,7 +248,7 @@ def gemm_group(problems, mode=None, kind=None):
         chunk = problems[i0:i0 + 4]
         arr = (_lib.GemmDesc * len(chunk))()
         for d, q in zip(arr, chunk):
-            g = lambda k, dflt=None: q.get(k, dflt)
+            g = q.get                                # (a lambda around it was 39 Python calls per problem, 41 groups per step)
             act, rowmap, pro = g("act", (0, 0)), g("rowmap", (1, 1, 0)), g("pro", (0, 0, 0))
             dgate = g("dgate")
             d.A = q["A"].data_ptr() + 4 * g("a_off", 0); d.lda = q["lda"]
