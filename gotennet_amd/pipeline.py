@@ -44,11 +44,12 @@ class EnergyForces:
         #: Inference tensors (made under ``torch.inference_mode()``) have no version counter and are never cached.
         self.cache_topology = cache_topology
         self._topo = None
+        self._mol_ptr = None                         # (key, batch tensor, offsets) of the last call without mol_ptr
 
     def clear_cache(self):
         """Drop the cached topology (it keeps the last ``edge_index`` tensor and E-sized index / geometry buffers alive)
         and the recorded hipGraph with its memory pool."""
-        self._topo = None
+        self._topo = self._mol_ptr = None
         self._hits, self._graph_state = 0, None
 
     def _graph(self, cfg, pw, N, edge_index, edge_diff, edge_vec, need_csc):
@@ -87,7 +88,13 @@ class EnergyForces:
         cfg, pw = rep.config(), rep.packed_weights()
         N = z.shape[0]
         if mol_ptr is None:
-            mol_ptr = molecule_ptr(batch, n_mol)
+            # (bincount + cumsum + two fills per call otherwise: kept per batch tensor, like the topology)
+            mkey = None if (batch.is_inference() or not self.cache_topology) else (batch.data_ptr(), batch._version, tuple(batch.shape), n_mol)
+            if mkey is not None and self._mol_ptr is not None and self._mol_ptr[0] == mkey and self._mol_ptr[1] is batch:
+                mol_ptr = self._mol_ptr[2]
+            else:
+                mol_ptr = molecule_ptr(batch, n_mol)
+                self._mol_ptr = (mkey, batch, mol_ptr) if mkey is not None else None
         gs = self._graph_state
         if self.replay and gs is not None and forces and self._replay_ok(gs, cfg, pw, N, edge_index, n_mol):
             return self._replay(gs, z, edge_diff, edge_vec, mol_ptr)
