@@ -421,6 +421,33 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_EDGE) void htr_edge_kernel(
         const float* re = rl + (size_t)e * D;
         float4 wsum = zero4();
         int m0 = 0;
+#if GN_HTR_CLOSED_ALL
+        if constexpr (LMAX >= GN_HTR_CLOSED_ALL) {
+            // every row of the edge requested before the first use (the literal form gets that from the compiler, the
+            // closed form degree by degree does not), then  w_l = EQ.EK - (2 - r.r)(EQ.r)(EK.r)
+            float4 eka[D];
+            float ra[D];
+#pragma unroll
+            for (int m = 0; m < D; ++m) { eka[m] = ld4(kj + (size_t)m * F); ra[m] = re[m]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int l = 1; l <= LMAX; ++l) {
+                float4 pq = zero4(), pk = zero4(), ab = zero4();
+                float rr = 0.f;
+#pragma unroll
+                for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                    const int m = l * l - 1 + mm;
+                    rr = fmaf(ra[m], ra[m], rr);
+                    pq = fma4(ra[m], eq[m], pq);
+                    pk = fma4(ra[m], eka[m], pk);
+                    ab = fma4(eq[m], eka[m], ab);
+                }
+                wsum = wsum + (ab + (pq * pk) * (rr - 2.0f));
+            }
+            st4_nt(w + (size_t)e * F + c0, wsum);
+            continue;
+        }
+#endif
 #pragma unroll
         for (int l = 1; l <= LMAX; ++l) {
             float4 ek[2 * LMAX + 1];

@@ -93,6 +93,10 @@
 #ifndef GN_HTR_CLOSED
 #define GN_HTR_CLOSED 1        // htr_edge_kernel at lmax = 3: closed form EQ.EK - (2 - r.r)(EQ.r)(EK.r) instead of two rejections
 #endif
+#ifndef GN_HTR_CLOSED_ALL
+#define GN_HTR_CLOSED_ALL 4    // ... and from this lmax up the closed form with EVERY row of the edge requested before the first use: lmax 4
+#endif                         // 108.4 -> 90 us per call (degree by degree the closed form lost there, 140 us: the compiler serialised the
+                               // row loads); lmax 3 is 90.4 us degree by degree, 92.4 us in this form (0: never)
 #ifndef GN_ATTN_WAVE
 #define GN_ATTN_WAVE 1         // 1: one wave per target in gn_attn_softmax where the shape allows; 0: workgroup per target
 #endif
