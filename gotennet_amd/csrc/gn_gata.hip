@@ -400,8 +400,9 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G34) void message_aggregate_gro
 // float4 FMAs per row and no second pass over the rows (the form gn_options.hip uses for the non-default variants);
 // r.r is not 1 for the reference's degree 3 (and 0 on self-loops), so it is carried.  Rounding differs from the literal
 // form at the 1e-7 level.  Measured (round 4, in the step): lmax 3 (C5) 98.0 -> 90.5 us (126 VGPRs, 4 waves/SIMD instead
-// of 132 / 3); lmax 4 LOSES, 105.9 -> 140.4 us at the same 2 waves/SIMD (the literal form keeps all 24 row loads of an
-// edge in flight; the closed form's schedule does not), so lmax 4 keeps the literal form.
+// of 132 / 3); at lmax 4 the same code LOSES, 105.9 -> 140.4 us at the same 2 waves/SIMD (the literal form keeps all 24 row
+// loads of an edge in flight; the closed form's schedule does not).  LMAX >= GN_HTR_CLOSED_ALL (= 4): the closed form with
+// every row of the edge requested before the first use (a sched_barrier keeps the loads together): 108.4 -> 90 us.
 template <int LMAX>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_EDGE) void htr_edge_kernel(
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
