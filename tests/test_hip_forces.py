@@ -341,6 +341,40 @@ def test_forces_asymmetric_graph_neighbor_cap():
     assert rel_err(f.cpu(), f_ref) < TOL
 
 
+def test_forces_high_degree_cluster():
+    """Every atom of a 120-atom cluster inside the cutoff of every other one: 121 incoming and 121 outgoing edges per atom
+    (more than a wave of lanes in the position scatter, more than one pass of the per-target slots everywhere, 968 head
+    scores per target in the softmax backward).  Energy and forces vs the oracle's fp64 autograd."""
+    import gotennet_amd
+    from gotennet_amd.graph import distance
+    from gotennet_amd.outputs import Atomwise
+    from gotennet_amd.pipeline import EnergyForces
+    from oracle import gotennet_oracle as orc
+    torch.manual_seed(21)
+    F, L, lmax, cap, n = 64, 2, 2, 128, 120
+    net = gotennet_amd.GotenNet(n_atom_basis=F, n_interactions=L, n_rbf=16, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
+                                num_heads=8, scale_edge=True, lmax=lmax, sep_dir=True, sep_tensor=True)
+    head = Atomwise(n_in=F, n_hidden=32, derivative="forces", activation="silu")
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    hsd = {k: v.clone() for k, v in head.state_dict().items()}
+    cfg = orc.default_config(n_atom_basis=F, n_interactions=L, n_rbf=16, num_heads=8, scale_edge=True, lmax=lmax,
+                             sep_dir=True, sep_tensor=True)
+    g = torch.Generator().manual_seed(6)
+    pos = torch.rand((n, 3), generator=g) * 2.5                  # the cube's diagonal is 4.33 < 5
+    batch = torch.zeros(n, dtype=torch.long)
+    z = torch.randint(1, 9, (n,), generator=g)
+    e_ref, f_ref, _ = orc.energy_and_forces({k: v.double() for k, v in sd.items()}, cfg,
+                                            {k: v.double() for k, v in hsd.items()}, z, pos.double(), batch, 1,
+                                            max_num_neighbors=cap)
+    net, head = net.cuda().eval(), head.cuda().eval()
+    ei, w, vec = distance(pos.cuda(), batch.cuda(), 5.0, cap)
+    assert ei.shape[1] == n * n                                   # complete graph incl. self-loops
+    e, f = EnergyForces(net, head)(z.cuda(), ei, w, vec, batch.cuda(), 1)
+    assert rel_err(e.cpu(), e_ref) < TOL
+    assert rel_err(f.cpu(), f_ref) < TOL
+    assert float(f.sum(0).abs().max()) < 1e-3 * float(f.abs().max())
+
+
 def test_aggr_max_is_forward_only():
     """aggr='max' (gotennet.py:84,638) runs the message stage forward (fixture opt_aggr_max_l3 in test_hip_parity) and refuses
     the force path before any backward launch."""
