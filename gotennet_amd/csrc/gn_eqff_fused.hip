@@ -108,10 +108,11 @@ __device__ __forceinline__ void chain_product(const unsigned short* P, int K, co
         off[j] = (size_t)nt * ks2 * (NP * 64) + lane;
     }
     const unsigned short* Ap = P + (lane & (EQ_ATOMS - 1)) * pitch + (lane >> 5) * 8;
-    // CH k-steps of weight fragments in flight at once: with one step of look-ahead every k-step waited a full L2 round
-    // trip for 6 MFMAs of work (14 us for the 32 steps of product 1)
-    constexpr int CH = NP == 2 ? (NTW <= 2 ? 8 : 4) : (NTW <= 2 ? 4 : 2);
-    uint4 bq[CH][NTW][NP];
+    // CH k-steps of weight fragments per register set, TWO sets: while one set is multiplied the other is in flight.  (With
+    // one step of look-ahead every k-step waited a full L2 round trip for 6 MFMAs of work, 14 us for the 32 steps of
+    // product 1; one set of 2 CH steps, loaded and then multiplied, still paid that round trip once per set.)
+    constexpr int CH = NP == 2 ? (NTW <= 2 ? 4 : 2) : (NTW <= 2 ? 2 : 1);
+    uint4 bq0[CH][NTW][NP], bq1[CH][NTW][NP];
     auto load_b = [&](int g, uint4 (&q)[NTW][NP]) {
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
@@ -143,12 +144,22 @@ __device__ __forceinline__ void chain_product(const unsigned short* P, int K, co
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]], __builtin_bit_cast(bf16x8, bw[j][TB[t]]), acc[j], 0, 0, 0);
         }
     };
-    for (int g0 = 0; g0 < nk; g0 += CH) {            // nk = K / 16 is a multiple of 8 (K % 128 == 0)
 #pragma unroll
-        for (int c = 0; c < CH; ++c) load_b(g0 + c, bq[c]);
-        __builtin_amdgcn_sched_barrier(0);           // all CH steps' loads first: left alone the scheduler interleaves them
-#pragma unroll                                       // with the MFMAs three at a time and every group waits on L2
-        for (int c = 0; c < CH; ++c) kstep(g0 + c, bq[c]);
+    for (int c = 0; c < CH; ++c) load_b(c, bq0[c]);
+    for (int g0 = 0; g0 < nk; g0 += 2 * CH) {        // nk = K / 16 is a multiple of 8 (K % 128 == 0), 2 CH divides 8
+#pragma unroll
+        for (int c = 0; c < CH; ++c) load_b(g0 + CH + c, bq1[c]);
+        __builtin_amdgcn_sched_barrier(0);           // a set's loads together: left alone the scheduler interleaves them with
+#pragma unroll                                       // the MFMAs three at a time and every group waits on L2
+        for (int c = 0; c < CH; ++c) kstep(g0 + c, bq0[c]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g0 + 2 * CH < nk) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) load_b(g0 + 2 * CH + c, bq0[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) kstep(g0 + CH + c, bq1[c]);
         __builtin_amdgcn_sched_barrier(0);
     }
     // rows 0..EQ_ATOMS-1 of the 32 x 32 tile: lane (l >> 5) holds rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)
