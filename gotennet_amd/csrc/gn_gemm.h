@@ -106,9 +106,27 @@ __device__ __forceinline__ int phys_row(const GemmArgs& p, int r) {
 
 }  // namespace gn
 
+namespace gn {
+// ---- column-loop kernel (gn_gemm_colpipe.hip) -----------------------------------------------------------------------
+// Work decomposition: a UNIT is (row panel of 64, column pass of 128) of a problem, units are numbered panel-major.
+// Workgroup w of G takes the units [w T / G, (w + 1) T / G) (T = all units of the group): every workgroup gets the same MFMA
+// work to within one unit, and consecutive units of a workgroup are consecutive column passes of the same row panel.
+struct ClArgs {
+    GemmArgs g[GN_MAX_GROUP];
+    long wend[GN_MAX_GROUP];        // running unit count: problem i owns the units [wend[i-1], wend[i])
+    int n;
+};
+constexpr int CL_KC = 256;          // panel depth (one K chunk)
+// workgroup barrier for LDS hand-over that does NOT drain the vector-memory counter (a __syncthreads() waits for every
+// outstanding global store and load of the wave)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+}  // namespace gn
+
 // launcher for a group of n <= GN_MAX_GROUP problems (gn_gemm.hip).  split = 0: exact fp32 MFMA, W = fp32 [N][K];
 // split = 1: 3 x bf16-split MFMA, W = the fragment-major bf16 planes written by gn_split_bf16x3;
 // split = 2: 2 x fp16-split MFMA with block exponents, W = the planes (+ header) written by gn_split_f16x2
 int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split);
 // the K-resident panel kernel for small f16x2 groups (gn_gemm_panel.hip): 1 = launched, 0 = does not apply, < 0 = -hipError_t
 int gn_gemm_panel_launch(const gn::GemmArgs* g, int n, hipStream_t st);
+// the column-loop kernel for large K = 256 f16x2 groups (gn_gemm_colpipe.hip; g[i].nt_store set by the caller): same return convention
+int gn_gemm_colpipe_launch(const gn::GemmArgs* g, int n, hipStream_t st);

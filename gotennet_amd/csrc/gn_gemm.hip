@@ -753,6 +753,10 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
         ga.tile_end[i] = (int)end;
     }
     ga.n = n;
+    if (split == 2) {                                // large prologue-free K = 256 groups with a wide product: the column-loop kernel
+        const int r = gn_gemm_colpipe_launch(ga.g, n, st);
+        if (r != 0) return r > 0 ? GN_OK : -r;
+    }
     // per-problem XCD ranges when the problems are unlike (different tile lengths K, or a small problem riding with
     // a large one: its tiles would otherwise all sit at the end of the last XCD's range)
     ga.spread = 0;

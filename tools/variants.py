@@ -12,7 +12,11 @@ from gotennet_amd.build import PKG, build_library  # noqa: E402
 out_dir = os.path.join(PKG, "variants")
 os.makedirs(out_dir, exist_ok=True)
 jobs = []
+only = None
 for arg in sys.argv[1:]:
+    if arg.startswith("--only="):        # translation units the flags apply to (the rest comes from the default build's object cache)
+        only = arg[7:].split(",")
+        continue
     name, flags = arg.split("=", 1)
     jobs.append((name, flags.split()))
 
@@ -20,7 +24,7 @@ for arg in sys.argv[1:]:
 def one(job):
     name, flags = job
     path = os.path.join(out_dir, f"lib_{name}.so")
-    build_library(force=True, extra_flags=flags, out=path)
+    build_library(force=True, extra_flags=flags, out=path, only=only)
     return name, path
 
 
