@@ -48,7 +48,10 @@ class KernelTimer:
         if name in ("gn_gemm_ex", "gn_gemm_split", "gn_gemm_f16x2"):
             return f"gn_gemm[{args[6]}x{args[7]}x{args[8]}]"
         if name in ("gn_gemm_group", "gn_gemm_group_split", "gn_gemm_group_f16x2"):   # several independent problems in one launch
-            return "gn_gemm[" + "+".join(f"{args[0][i].M}x{args[0][i].N}x{args[0][i].K}" for i in range(args[1])) + "]"
+            # (a trailing "g" marks a problem with the gated-residual epilogue C = res + act(.) * gate: the HTR edge update)
+            return "gn_gemm[" + "+".join(f"{args[0][i].M}x{args[0][i].N}x{args[0][i].K}"
+                                         + ("g" if (args[0][i].gate and not args[0][i].gate_mode and args[0][i].res) else "")
+                                         for i in range(args[1])) + "]"
         return name
 
     #: X_in argument of the two message entries: None = the zero-X_in launch of the first interaction
@@ -58,8 +61,6 @@ class KernelTimer:
         tag = self.tag_of(name, args)
         if self.wanted is not None and tag not in self.wanted:
             return None
-        if name == "gn_message_fused":               # args[0]: byref(gn_fused_desc)
-            return tag + "|first" if not args[0]._obj.X_in else tag
         k = self.X_IN_ARG.get(name)
         return tag + "|first" if (k is not None and args[k] is None) else tag
 
@@ -99,7 +100,7 @@ def algorithmic_bytes_message(N, E, F, M, D, first_nd=None):
 LINE_BUDGET = 6000
 
 _ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "us_per_launch", "launches_per_step",
-              "algorithmic_bytes_per_launch", "algorithmic_tflops", "executed_terms_per_product")
+              "algorithmic_bytes_per_launch", "algorithmic_tflops", "executed_terms_per_product", "mfma_busy")
 
 
 def _roof_compact(r, name_len=60):
@@ -132,6 +133,7 @@ def _side_compact(so):
     o = {"value": so.get("value"), "ms_per_step": so.get("ms_per_step"), "steps": so.get("steps"),
          "gather_frac": _frac(g), "gather_frac_general": _frac(g, "general_launches"),
          "htr_frac": _frac(so.get("roofline_htr_edge")), "msg_bwd_frac": _frac(so.get("roofline_message_backward")),
+         "htr_bwd_frac": _frac(so.get("roofline_htr_backward")),
          "gemm_frac": _frac(so.get("roofline")), "gemm_alg_tflops": (so.get("roofline") or {}).get("algorithmic_tflops")}
     return {k: v for k, v in o.items() if v is not None}
 
@@ -142,15 +144,18 @@ def compact_line(full):
     ``full`` is the complete record (what round 3 printed); it is written to a side file by ``emit``."""
     out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                 "scaling", "vs_baseline", "dtype", "data", "config", "n_ranks_seen", "energy_vector_len",
-                                "energy_checksum", "launch_mode") if k in full}
+                                "energy_checksum", "rank_ms_per_step", "launch_mode") if k in full and full[k] is not None}
     out["roofline"] = _roof_compact(full.get("roofline"))
     if out["roofline"] is not None:
         live = str((full.get("roofline") or {}).get("traffic_source", "")).startswith("measured in this run")
         out["roofline"]["traffic_source"] = ("live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE sub-runs of this bench (2 x FETCH + WRITE)"
                                              if live else "committed profiles/pmc_traffic.json (rocprofv3 --pmc; FETCH_SIZE x2 + WRITE_SIZE)")
-    for k in ("roofline_gather_scatter", "roofline_htr_edge", "roofline_message_backward"):
-        if k in full:
+    for k in ("roofline_gather_scatter", "roofline_htr_edge", "roofline_message_backward", "roofline_htr_backward",
+              "roofline_gated_gemm"):
+        if full.get(k):
             out[k] = _roof_compact(full[k])
+            if k in ("roofline_htr_backward", "roofline_gated_gemm"):      # (the byte formula travels with the two new records)
+                out[k]["bytes"] = str(full[k].get("note", ""))[:150]
     also_f, also = full.get("also") or {}, {}
     for k, v in also_f.items():
         if k == "other_projection_modes":
@@ -158,10 +163,9 @@ def compact_line(full):
                            "gemm_alg_tflops": (o.get("roofline") or {}).get("algorithmic_tflops")} for m, o in v.items()}
         elif k == "forward_only":
             also[k] = {"value": v.get("value"), "ms_per_step": v.get("ms_per_step"), "steps": v.get("steps"),
-                       "fused_message": v.get("fused_message"),
-                       "fused_ab_ms_per_step": (v.get("fused_message_ab") or {}).get("ms_per_step"),
-                       "fused_kernel_us": (v.get("fused_message_ab") or {}).get("kernel_us"),
                        "cpu_value": (v.get("cpu_baseline") or {}).get("value")}
+        elif k == "static_topology":
+            also[k] = {"value": v.get("value"), "ms_per_step": v.get("ms_per_step"), "steps": v.get("steps")}
         elif k in ("single_molecule_latency", "hipgraph_replay_full_batch"):
             also[k] = {kk: v.get(kk) for kk in ("molecules", "eager_ms_per_step", "hipgraph_replay_ms_per_step",
                                                 "bit_identical_to_eager")}
@@ -173,7 +177,8 @@ def compact_line(full):
         out["also"] = also
     cb = full.get("cpu_baseline")
     if cb:
-        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "cpu_model") if k in cb}
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "cpu_model", "host_cores_physical",
+                                                   "thread_sweep_8_molecules", "largest_batch") if k in cb}
         out["cpu_baseline"]["sample"] = str(cb.get("sample_short") or cb.get("sample", ""))[:160]
     if full.get("full_record"):
         out["full_record"] = full["full_record"]
@@ -218,6 +223,8 @@ def main():
     ap.add_argument("--no-workloads", action="store_true", help="skip the short C3 / C5 side measurements")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="take roofline.traffic from the committed PMC passes instead of two rocprofv3 sub-runs of this script")
+    ap.add_argument("--static-topology", action="store_true",
+                    help="time the step on a cached topology (CSR / CSC / molecule offsets built once): an MD loop on a fixed neighbour list")
     ap.add_argument("--replay", action="store_true", help="hipGraph replay of the static-topology step (EnergyForces(replay=True)) instead of eager launches")
     ap.add_argument("--full-json", default=None,
                     help="where the FULL record goes (default: gpurun_out/bench_full.json next to this file, when that "
@@ -340,6 +347,12 @@ def worker(a):
         # BASELINE configs[2] and configs[4] on the same model family (single GPU)
         wl["md22_ac_ala3_b64"] = measure(a, "md22_ac_ala3", 64, 2, 10, 2, rank, world, dev, dist)
         wl["md22_nanotube_b8_lmax3"] = measure(a, "md22_nanotube", 8, 3, 10, 2, rank, world, dev, dist)
+    static = None
+    if sides and not a.static_topology and not a.replay:
+        import copy
+        a_st = copy.copy(a)
+        a_st.static_topology = True
+        static = measure(a_st, a.workload, a.batch, a.lmax, max(10, a.steps // 2), 2, rank, world, dev, dist)
     fwd = None
     if sides and not a.no_forward_only:
         fwd = forward_only(a, res["rep"], res["head"], dev)
@@ -350,8 +363,13 @@ def worker(a):
         out = res["out"]
         also = out.setdefault("also", {})
         sub = lambda so: {**{k: so[k] for k in ("value", "unit", "ms_per_step", "steps", "roofline",
-                                                 "roofline_gather_scatter", "roofline_htr_edge", "roofline_message_backward")},
+                                                 "roofline_gather_scatter", "roofline_htr_edge", "roofline_message_backward",
+                                                 "roofline_htr_backward")},
                           "config": so["config"]["workload"]}
+        if static is not None:
+            so = static["out"]
+            also["static_topology"] = {"value": so["value"], "ms_per_step": so["ms_per_step"], "steps": so["steps"],
+                                       "note": "the same step with the CSR / CSC index arrays and molecule offsets cached across steps"}
         if lat is not None:
             also["single_molecule_latency"] = lat
         if lat_batch is not None:                  # the headline batch as ONE hipGraph replay per step (fixed edge list)
@@ -411,59 +429,28 @@ def graph_latency(a, rep, head, dev, n_mol=1, iters=200):
 
 def forward_only(a, rep, head, dev, steps=20):
     """The path's own API, forward only: representation forward + Atomwise energy, no force backward
-    (`EnergyForces(..., forces=False)`: ping-pong work buffers, nothing saved).  Same workload and model as the headline.
-    Timed twice in one process: with gn_message_fused (edge projection + softmax + message as one kernel, no
-    [E,(1+M)F] stream: what ships for inference) and with the three-kernel sequence (`rep.fuse_message = False`)."""
-    from gotennet_amd import _lib, engine, synthetic
+    (`EnergyForces(..., forces=False)`: ping-pong work buffers, nothing saved).  Same workload and model as the headline,
+    fresh topology every step like the headline."""
+    from gotennet_amd import synthetic
     from gotennet_amd.graph import distance
-    from gotennet_amd.outputs import molecule_ptr
     from gotennet_amd.pipeline import EnergyForces
     B = a.batch
     pos, batch, z = synthetic.make_batch(a.workload, B, seed=0)
     pos, batch, z = pos.to(dev), batch.to(dev), z.to(dev)
     ei, ed, ev = distance(pos, batch, 5.0, 32)
-    mol_ptr = molecule_ptr(batch, B)
-    ef = EnergyForces(rep, head, check_edges=False)
-
-    def timed():
-        for _ in range(3):
-            e, _ = ef(z, ei, ed, ev, batch, B, mol_ptr=mol_ptr, forces=False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            e, _ = ef(z, ei, ed, ev, batch, B, mol_ptr=mol_ptr, forces=False)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        assert torch.isfinite(e).all()
-        return dt, e
-
-    old = rep.fuse_message
-    tot = cnt = None
-    try:
-        dt0, e0 = timed()                                # what ships: the default of GotenNet.fuse_message (False)
-        rep.fuse_message = True                          # the opt-in fused kernel, same process
-        fused_on = engine.fused_message_ok(rep.config())
-        if fused_on:
-            dt1, e1 = timed()
-            kt = KernelTimer(wanted={"gn_message_fused"})    # per-launch time of the fused kernel (HIP events, one step)
-            _lib.TIMER = kt
-            ef(z, ei, ed, ev, batch, B, mol_ptr=mol_ptr, forces=False)
-            torch.cuda.synchronize()
-            _lib.TIMER = None
-            tot, cnt = kt.summary(split_first=True)
-    finally:
-        rep.fuse_message = old
-        _lib.TIMER = None
-    out = {"metric": "molecules/sec (energy only: representation forward + Atomwise head, no forces)",
-           "value": round(B * steps / dt0, 1), "unit": "molecules/s", "ms_per_step": round(1e3 * dt0 / steps, 3),
-           "steps": steps, "config": f"{a.workload} batch={B}, same model as the headline line",
-           "fused_message": bool(old)}
-    if fused_on:
-        out["fused_message_ab"] = {"ms_per_step": round(1e3 * dt1 / steps, 3), "value": round(B * steps / dt1, 1),
-                                   "kernel_us": {k: round(1e3 * tot[k] / cnt[k], 1) for k in tot},
-                                   "energy_rel_diff": float((e1 - e0).abs().max() / e0.abs().max()),
-                                   "note": "gn_message_fused (edge projection + softmax + message, no eproj stream), opt-in"}
-    return out
+    ef = EnergyForces(rep, head, check_edges=False, cache_topology=False)
+    for _ in range(3):
+        e, _ = ef(z, ei, ed, ev, batch, B, forces=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e, _ = ef(z, ei, ed, ev, batch, B, forces=False)
+    torch.cuda.synchronize()
+    dt0 = time.perf_counter() - t0
+    assert torch.isfinite(e).all()
+    return {"metric": "molecules/sec (energy only: representation forward + Atomwise head, no forces)",
+            "value": round(B * steps / dt0, 1), "unit": "molecules/s", "ms_per_step": round(1e3 * dt0 / steps, 3),
+            "steps": steps, "config": f"{a.workload} batch={B}, same model as the headline line"}
 
 
 #: launches of the GATA message stage (gotennet.py:452-559, 613-640): scores + segment softmax + message + aggregate.
@@ -509,7 +496,11 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
     # replay (pipeline.EnergyForces(replay=True): after two steps on one edge list the eager step is recorded into ONE
     # hipGraph and replayed on the step's fresh inputs; same launches, bit-identical).  Measured on the C2 batch: 7.90 vs
     # 7.84 ms eager -- the host runs 2x ahead of the GPU here, so the headline stays the eager path.
-    step_fn = EnergyForces(rep, head, check_edges=False, replay=a.replay)
+    # The HEADLINE pays what a fresh batch costs: no topology cache (the int64 -> CSR conversion, the by-source view, the
+    # out-degree count run every step) and the molecule offsets are computed inside the step; `also.static_topology` is the
+    # same step on a cached topology (an MD loop on a fixed neighbour list).
+    fresh = not (a.static_topology or a.replay)
+    step_fn = EnergyForces(rep, head, check_edges=False, replay=a.replay, cache_topology=not fresh)
 
     pos, batch, z = synthetic.make_batch(workload, B, seed=0, first_molecule=rank * B)
     pos, batch, z = pos.to(dev), batch.to(dev), z.to(dev)
@@ -521,7 +512,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
     e_all = torch.zeros(B * world, dtype=torch.float32, device=dev)
 
     def step():
-        e, f = step_fn(z, ei, ed, ev, batch, B, mol_ptr=mol_ptr)
+        e, f = step_fn(z, ei, ed, ev, batch, B, mol_ptr=None if fresh else mol_ptr)
         if dist is not None:                               # the one data-path collective (RCCL over xGMI)
             reduce_energies(e[:, 0], rank * B, B * world, out=e_all)
         return e, f
@@ -565,7 +556,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
     # every step cost 0.115 ms/step (8.11 vs 7.995 ms, same process), i.e. the measurement perturbed `value` by 1.4 %;
     # the per-launch averages are the same either way (111.1 us for the message stage in both).
     dom_tags = {t for t in tot if family(t) == dominant}
-    always = stage_tags | {HTR_TAG, MSGB_TAG}
+    always = stage_tags | {HTR_TAG, MSGB_TAG, "gn_htr_backward"}
     ev_steps = min(3, steps)
     kt = KernelTimer(wanted=set())
     _lib.TIMER = kt
@@ -581,7 +572,13 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
     step_fn.replay = replay
     _lib.TIMER = None
     replayed = bool(replay and step_fn._graph_state is not None)
+    rank_ms = None
     if dist is not None:
+        # every rank's own time (a list in the record: the first multi-GPU run shows skew, not just the maximum), then the MAX
+        tl = torch.zeros(world, dtype=torch.float64, device=dev)
+        tl[rank] = dt
+        dist.all_reduce(tl, op=dist.ReduceOp.SUM)
+        rank_ms = [round(1e3 * float(v) / steps, 3) for v in tl.tolist()]
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -606,7 +603,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
             if family(tag) != "gn_gemm":
                 continue
             fl = sum(2.0 * m_ * n_ * k_ for m_, n_, k_ in
-                     (tuple(int(v) for v in part.split("x")) for part in tag[8:-1].split("+")))
+                     (tuple(int(v) for v in part.rstrip("g").split("x")) for part in tag[8:-1].split("+")))
             flops += fl * cnt[tag]
             t_ms += tot[tag]
             n += cnt[tag]
@@ -627,7 +624,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
         # split modes: the kernel EXECUTES several 16-bit MFMA flops per algorithmic fp32 flop (six bf16 terms, or three
         # fp16 terms with block exponents), so it is priced against the dense 16-bit matrix peak:
         # achieved = terms x algorithmic flops / time
-        terms, kname, what = ((3, "gn::gemm_f16x2_mfma + gn::gemm_f16x2_panel", "3 fp16 MFMAs on 2 scaled fp16 planes") if _engine_mode() == "f16x2"
+        terms, kname, what = ((3, "gn::gemm_f16x2_mfma + gn::gemm_f16x2_colpipe + gn::gemm_f16x2_panel", "3 fp16 MFMAs on 2 scaled fp16 planes") if _engine_mode() == "f16x2"
                               else (6, "gn::gemm_bf16x3_mfma", "6 bf16 MFMAs on 3 bf16 planes"))
         return dict(kernel=f"{kname} (all projection launches; every fp32 product as {what}, fp32 accumulate)",
                     bound="mfma", achieved=round(terms * ach, 1), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
@@ -702,6 +699,40 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
                          "(x, v, q|k, X_in, g_h1, g_X1 read; g_x, g_v, g_q|g_k, g_X written); the kernels read eproj in "
                          "both passes, so PMC traffic above this figure is the second read")
 
+    def roof_htr_backward():
+        """gn_htr_backward (by-target + by-source passes of one layer): compulsory bytes / duration."""
+        tag = "gn_htr_backward"
+        if tag not in tot:
+            return None
+        us = 1e3 * tot[tag] / cnt[tag]
+        nbytes = 4 * E * (4 * F + 2 * D) + 16 * E + 4 * N * 4 * D * F
+        ach = nbytes / (us * 1e-6) / 1e9
+        return dict(kernel=tag + " (target + source passes of one layer)", bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic(tag, lmax, workload, B),
+                    us_per_launch=round(us, 2), launches_per_step=cnt[tag] // ev_steps, algorithmic_bytes_per_launch=nbytes,
+                    note="bytes = 4E(4F + 2D) + 16E + 4N*4DF: g_t', pre_t, w read and g_pre_t written [E,F]; rl read, g_rl written "
+                         "[E,D]; 2 x int64 index; EQ, EK read and g_EQ, g_EK written [N,D,F]")
+
+    def roof_gated_gemm():
+        """The HTR edge update t' = t + SiLU(W_t t + b) * w as ONE projection launch (gotennet.py:611): HBM-priced, it moves
+        four [E,F] streams (t read -- operand and residual are the same rows --, w read, t' and the pre-activation written)
+        around a [E x F x F] product."""
+        tags = [t for t in tot if family(t) == "gn_gemm" and any(part.endswith("g") for part in t[8:-1].split("+"))]
+        if not tags:
+            return None
+        t_ms = sum(tot[t] for t in tags)
+        n = sum(cnt[t] for t in tags)
+        us = 1e3 * t_ms / n
+        nbytes = 4 * E * F * 4 + 2 * 4 * F * F
+        ach = nbytes / (us * 1e-6) / 1e9
+        fl = 2.0 * E * F * F
+        return dict(kernel="gn_gemm gated residual launch " + tags[0][7:], bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, us_per_launch=round(us, 2),
+                    launches_per_step=n // dom_steps, algorithmic_bytes_per_launch=nbytes,
+                    algorithmic_tflops=round(fl / (us * 1e-6) / 1e12, 1),
+                    note="bytes = 4 x 4EF (t read once: operand AND residual, w read, t' written, pre-activation written for the "
+                         "backward) + the weight planes; the rider product of the launch (gamma_m.0, atom-sized) is not priced")
+
     def roof_other(name):
         t_ms = sum(tot[t] for t in tot if family(t) == name)
         n = sum(cnt[t] for t in tot if family(t) == name)
@@ -722,14 +753,21 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
                                    "sep_dir/sep_tensor, energy+forces",
                        "global_batch": B * world, "parallelism": f"dp{world} (molecule shards, 1 all-reduce)"},
             "n_ranks_seen": n_ranks_seen, "energy_vector_len": int(e_vec.numel()), "energy_checksum": energy_checksum,
+            "rank_ms_per_step": rank_ms,
             "launch_mode": (f"hipGraph replay of the static-topology step ({steps - ev_steps} of {steps} timed steps; the last "
-                            f"{ev_steps} run eagerly under HIP-event brackets)" if replayed else "eager launches"),
+                            f"{ev_steps} run eagerly under HIP-event brackets)" if replayed else
+                            ("eager launches; fresh batch every step (CSR / CSC / out-degree / molecule offsets rebuilt inside the timed step)"
+                             if fresh else "eager launches; static topology (index arrays cached across steps)")),
             "roofline": roof_gemm_family() if dominant == "gn_gemm" else
             (roof_message() if dominant in MSG_STAGE else roof_other(dominant)),
             "roofline_gather_scatter": roof_message(),
             "roofline_htr_edge": roof_htr(),
             "roofline_message_backward": roof_msg_backward(),
+            "roofline_htr_backward": roof_htr_backward(),
+            "roofline_gated_gemm": roof_gated_gemm(),
         }
+        if LIVE_TRAFFIC.get("_key") == (workload, B, lmax) and "mfma_busy" in LIVE_TRAFFIC and out["roofline"].get("bound") == "mfma":
+            out["roofline"]["mfma_busy"] = LIVE_TRAFFIC["mfma_busy"]
         # the stage fractions again INSIDE `roofline` (a consumer that keeps only that object still sees them)
         out["roofline"]["stages"] = {k: ({kk: out[k][kk] for kk in ("kernel", "bound", "achieved", "peak", "unit", "frac",
                                                                        "us_per_launch", "algorithmic_bytes_per_launch", "traffic")}
@@ -800,9 +838,9 @@ def live_traffic(a):
     tabs = {}
     try:
         with tempfile.TemporaryDirectory(prefix="gn_pmc_", dir="/tmp") as td:
-            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-                out = os.path.join(td, counter)
-                cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "r", "--", sys.executable,
+            for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"):
+                out = os.path.join(td, counter.split()[0])
+                cmd = [exe, "--kernel-trace", "--pmc", *counter.split(), "-d", out, "-o", "r", "--", sys.executable,
                        os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", str(a.batch),
                        "--lmax", str(a.lmax), "--workload", a.workload, "--no-lmax4", "--no-split", "--no-graph",
                        "--no-workloads", "--no-cpu-baseline", "--no-forward-only", "--no-live-traffic"]
@@ -812,8 +850,18 @@ def live_traffic(a):
                 dbs = [os.path.join(r, fn) for r, _, fns in os.walk(out) for fn in fns if fn.endswith("_results.db")]
                 if not dbs:
                     return {}
-                tabs[counter] = _pmc_counter_table(dbs[0], counter)
-        return _traffic_entry(tabs["FETCH_SIZE"], tabs["WRITE_SIZE"])
+                for cn in counter.split():
+                    tabs[cn] = _pmc_counter_table(dbs[0], cn)
+        ent = _traffic_entry(tabs["FETCH_SIZE"], tabs["WRITE_SIZE"])
+        # matrix-pipe occupancy of the projection family INSIDE the step: SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of
+        # the 1024 SIMDs, GRBM_GUI_ACTIVE the active cycles of the 8 XCDs (128 SIMDs each)
+        mb, ga = tabs.get("SQ_VALU_MFMA_BUSY_CYCLES", {}), tabs.get("GRBM_GUI_ACTIVE", {})
+        gem = [k for k in mb if "gn::gemm_" in k and k in ga]
+        if ent and gem:
+            busy = sum(mb[k][0] * mb[k][1] for k in gem)
+            act = sum(ga[k][0] * ga[k][1] for k in gem)
+            ent["mfma_busy"] = round(busy / (128.0 * act), 4) if act else None
+        return ent
     except Exception as exc:                                   # noqa: BLE001 -- a measurement aid must never fail the bench
         print(f"# live traffic pass failed ({type(exc).__name__}: {exc}); using the committed PMC passes", file=sys.stderr)
         return {}
@@ -842,14 +890,42 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(rep, head, workload, lmax, n_mol=8, runs=5, forces=True):
-    """The CPU oracle (checker) timed on this box's host cores (BASELINE.md section 3 protocol): energy+forces via
-    autograd on a bounded sample of the same workload and model, 1 warm-up + median of ``runs`` runs with all host
-    cores (capped at 64 threads), plus a single-thread figure on a smaller sample."""
+def _physical_cores():
+    """Physical cores of the host (unique (socket, core) pairs of /proc/cpuinfo; logical count / 2 when that is unreadable)."""
+    try:
+        pairs, phys = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                pairs.add((phys, line.split(":", 1)[1].strip()))
+        if pairs:
+            return len(pairs)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def _mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / 1048576.0
+    except Exception:
+        pass
+    return 32.0
+
+
+def cpu_baseline(rep, head, workload, lmax, forces=True):
+    """The CPU oracle (checker) timed on this box's host cores (BASELINE.md section 3 protocol).  A thread sweep
+    (1 / 16 / 64 / all physical cores) on an 8-molecule sample picks the thread count; the figure is then measured at that
+    count on the LARGEST batch the bound allows: energy+forces (torch autograd) on up to 64 molecules -- what fits both the
+    host RAM (~0.6 GB of autograd state per molecule at lmax 2, the reference itself needs > 62 GB for 128) and ~10 s of CPU
+    work --, energy only on the full batch of the headline.  1 warm-up, then one timed run per configuration; the sweep
+    table is part of the record."""
     from gotennet_amd import synthetic
     from oracle import gotennet_oracle as orc
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    phys = _physical_cores()
     sd = {k: v.detach().cpu() for k, v in rep.state_dict().items()}
     hsd = {k: v.detach().cpu() for k, v in head.state_dict().items()}
     c = rep.config()
@@ -864,10 +940,11 @@ def cpu_baseline(rep, head, workload, lmax, n_mol=8, runs=5, forces=True):
             h, _ = orc.gotennet_forward(sd, cfg, z, ei, w, vec)
             return orc.atomwise_energy(hsd, h, batch, nm, z=z)
 
-    def timed(nm, nthreads, nruns):
+    def timed(nm, nthreads, nruns=1, warm=True):
         torch.set_num_threads(nthreads)
         pos, batch, z = synthetic.make_batch(workload, nm, seed=0)
-        run_once(z, pos, batch, nm)                                      # warm-up
+        if warm:
+            run_once(z, pos.clone(), batch, nm)
         ts = []
         for _ in range(nruns):
             t0 = time.perf_counter()
@@ -876,18 +953,30 @@ def cpu_baseline(rep, head, workload, lmax, n_mol=8, runs=5, forces=True):
         ts.sort()
         return ts[len(ts) // 2]
 
-    t_all = timed(n_mol, threads, runs)
-    t_one = timed(2, 1, 3)
-    return {"value": round(n_mol / t_all, 2), "unit": "molecules/s", "cores": threads, "kind": "port",
-            "cpu_model": _cpu_model(), "host_cores": cores, "torch": torch.__version__,
-            "single_thread": {"value": round(2 / t_one, 3), "unit": "molecules/s", "cores": 1,
-                              "sample": f"2 molecules of {workload}, median of 3 runs after 1 warm-up"},
-            "sample_short": f"{n_mol} molecules of {workload}, " + ("energy+forces (autograd)" if forces else "energy only")
-                            + f", CPU oracle port, median of {runs} runs, {threads} threads",
-            "sample": f"{n_mol} molecules of {workload} (same model: F=256, L=6, lmax={lmax}), "
-                      + ("energy+forces by torch autograd" if forces else "energy only (forward + head, no_grad)")
-                      + f" on the CPU oracle (oracle/gotennet_oracle.py), median of {runs} runs after 1 warm-up, "
-                      f"{threads} threads"}
+    old_threads = torch.get_num_threads()
+    try:
+        sweep = {}
+        for nt in sorted({1, min(16, phys), min(64, phys), phys}):
+            sweep[nt] = round(8 / timed(8, nt, nruns=2), 2)
+        best_nt = max(sweep, key=sweep.get)
+        n_atoms = synthetic.WORKLOADS[workload][0]
+        per_mol_gb = 0.6 * (n_atoms / 21.0) * (((lmax + 1) ** 2 - 1) / 8.0 + 1.0) / 2.0
+        nm_big = 128 if not forces else int(max(8, min(64, _mem_available_gb() * 0.4 / per_mol_gb)))
+        nm_big = min(nm_big, synthetic.WORKLOADS[workload][2] if workload != "rmd17_aspirin" else 128)
+        t_big = timed(nm_big, best_nt, nruns=1, warm=False)              # (the sweep warmed the allocator and the thread pool)
+    finally:
+        torch.set_num_threads(old_threads)
+    val_big, val_sweep = nm_big / t_big, sweep[best_nt]
+    value, nm_used = (val_big, nm_big) if val_big >= val_sweep else (val_sweep, 8)     # report the best, as BASELINE.md asks
+    what = "energy+forces (torch autograd)" if forces else "energy only (forward + head, no_grad)"
+    return {"value": round(value, 2), "unit": "molecules/s", "cores": best_nt, "kind": "port",
+            "cpu_model": _cpu_model(), "host_cores_logical": os.cpu_count(), "host_cores_physical": phys, "torch": torch.__version__,
+            "thread_sweep_8_molecules": {str(k): v for k, v in sweep.items()},
+            "largest_batch": {"molecules": nm_big, "value": round(val_big, 2), "threads": best_nt},
+            "sample_short": f"{nm_used} molecules of {workload}, {what}, CPU oracle port, best of a 1/16/64/{phys}-thread sweep: {best_nt} threads",
+            "sample": f"{nm_used} molecules of {workload} (same model: F=256, L=6, lmax={lmax}), {what} on the CPU oracle "
+                      f"(oracle/gotennet_oracle.py); thread sweep on 8 molecules {sweep} molecules/s, then {nm_big} molecules at "
+                      f"{best_nt} threads: {val_big:.2f} molecules/s; the better of the two is `value`"}
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GN_LIB_PATH") or os.path.join(_PKG, "libgotennet_hip.so")
 
 GN_ERR_BAD_ARG = 10001
-ABI_VERSION = 7
+ABI_VERSION = 8
 LMAX_SLICED = 0x100      # GN_LMAX_SLICED: OR-ed into the lmax argument of the message / HTR entry points
 LMAX_MEAN, LMAX_MAX = 0x200, 0x400      # GN_LMAX_MEAN / GN_LMAX_MAX: the reference's aggr = "mean" / "max" (message entries)
 
@@ -29,14 +29,6 @@ class GemmDesc(C.Structure):
                 ("res", _P), ("gate", _P), ("gate_mode", _I), ("pre_out", _P),
                 ("pro_mode", _I), ("pro_lo", _I), ("pro_hi", _I), ("a_pre", _P), ("ldp", _I),
                 ("a_gate", _P), ("ldg", _I), ("A2", _P), ("A3", _P), ("a_seg", _I), ("act_kind", _I)]
-
-
-class FusedDesc(C.Structure):
-    """gn_fused_desc of include/gotennet_hip.h (gn_message_fused)."""
-    _fields_ = [("t", _P), ("W", _P), ("bias", _P), ("q", _P), ("k", _P), ("ldqk", _I), ("x", _P), ("v", _P), ("ldxv", _I),
-                ("X_in", _P), ("h_in", _P), ("h_out", _P), ("X_out", _P), ("rl", _P), ("cut", _P),
-                ("rowptr", _P), ("src", _P), ("outdeg", _P), ("tile_first", _P), ("n_tiles", _P), ("tile_cap", _I),
-                ("attn_ws", _P), ("N", _I), ("F", _I), ("H", _I), ("lmax", _I), ("sep_dir", _I), ("sep_tensor", _I)]
 
 
 SIGNATURES = {
@@ -57,10 +49,6 @@ SIGNATURES = {
     "gn_eqff_fused_supported": [_I, _I, _I],
     "gn_eqff_fused_forward": [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     "gn_eqff_fused_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P],
-    "gn_edge_tiles_cap": [_I, _L],
-    "gn_edge_tiles": [_P, _I, _I, _P, _P, _P],
-    "gn_message_fused_supported": [_I, _I, _I, _I, _I, _I],
-    "gn_message_fused": [_P, _I, _P],
     "gn_htr_edge": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "gn_eqff_context": [_P, _P, _F, _I, _I, _I, _P, _P],
     "gn_eqff_update": [_P, _P, _I, _I, _I, _P, _P, _P],
@@ -121,7 +109,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes
-        fn.restype = C.c_long if name in ("gn_split_bf16x3_size", "gn_split_f16x2_size", "gn_edge_tiles_cap") else C.c_int
+        fn.restype = C.c_long if name in ("gn_split_bf16x3_size", "gn_split_f16x2_size") else C.c_int
     if lib.gn_abi_version(None) != ABI_VERSION:
         raise GotenNetHipError("libgotennet_hip.so ABI version mismatch; rebuild")
     _lib = lib

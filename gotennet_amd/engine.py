@@ -59,6 +59,8 @@ class PackedWeights:
     rb0: torch.Tensor; rb1: torch.Tensor          # radial-basis parameter vectors (means/betas, freqs, offsets/widths)
     layers: List[LayerWeights] = field(default_factory=list)
     T: dict = field(default_factory=dict)
+    emb_idx: Optional[torch.Tensor] = None        # model embedded in a power-of-two width (embed.py): real channel f sits at emb_idx[f]
+    F_model: int = 0                              # ... and its real width (0: not embedded)
 
 
 #: A/B and test switch: False runs the first interaction through the general kernels on the zero tensor
@@ -135,11 +137,11 @@ class Config:
     gemm_mode: str = ""       # projection arithmetic of THIS model ("f16x2" | "split" | "f32"; "" = engine.GEMM_MODE, the default)
     sliced: bool = False      # run lmax <= 4 on the degree-sliced kernel family too (GN_LMAX_SLICED in the lmax argument)
     aggr: int = 0             # the reference's `aggr` (gotennet.py:84,638): 0 "add", 1 "mean", 2 "max" (forward only)
+    Fc: int = 0               # width of the NodeInit LayerNorm intermediate when the model is embedded in a power-of-two F (embed.py; 0 = F)
+    F_model: int = 0          # the model's real n_atom_basis when embedded (0 = F)
     fuse_eqff: Optional[bool] = None   # the node-local EQFF chain as ONE kernel each way where covered (eqff_fused_ok).  None =
                               # auto: on for systems of at most EQFF_FUSED_MAX_ATOMS atoms (launch-bound: -17 % on a one-molecule
                               # step, -2 % at 32 molecules), off above (a wash at the 128-molecule batch)
-    fuse_message: bool = False  # inference (nothing saved): edge projection + softmax + message as ONE kernel (gn_message_fused,
-                                # no [E,(1+M)F] stream); opt-in: measured 2-10 % slower than the three kernels
 
     @property
     def Fe(self) -> int:
@@ -336,7 +338,6 @@ class Graph:
         self.cut = torch.empty(E, **f32)
         self.perm = self.colptr = self.tgt_by_src = None
         self.edge_diff = self.edge_vec = None
-        self._tiles = None
         if edge_vec is not None:
             self.set_geometry(edge_diff, edge_vec)
 
@@ -356,17 +357,6 @@ class Graph:
         call("gn_edge_vectors", ptr(pos), ptr(self.src), ptr(self.dst), self.E, ptr(self.edge_vec), ptr(self.edge_diff),
              _stream())
         self.set_geometry(self.edge_diff, self.edge_vec)
-
-    def tiles(self):
-        """Edge-row tiles of gn_message_fused (<= 128 consecutive CSR rows cut on target boundaries), built on the device
-        once per topology; the capacity is a host-side bound (no read-back).  -> (tile_first, n_tiles, cap)."""
-        if self._tiles is None:
-            cap = int(_lib.load().gn_edge_tiles_cap(self.N, self.E))
-            tile_first = torch.empty(cap + 1, dtype=torch.int32, device=self.src.device)
-            n_tiles = torch.empty(1, dtype=torch.int32, device=self.src.device)
-            call("gn_edge_tiles", ptr(self.rowptr), self.N, cap, ptr(tile_first), ptr(n_tiles), _stream())
-            self._tiles = (tile_first, n_tiles, cap)
-        return self._tiles
 
     def csc(self):
         """Edges grouped by source (stable): integer index plumbing, no host sync."""
@@ -397,6 +387,12 @@ class Tape:
     layers: List[LayerTape] = field(default_factory=list)
 
 
+def check_backward_supported(cfg: Config) -> None:
+    """Raise NotImplementedError -- BEFORE any launch -- for the configurations whose force path does not exist."""
+    if cfg.aggr == 2:
+        raise NotImplementedError("aggr='max': the message stage has a forward kernel only (no input-gradient / forces)")
+
+
 def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: bool = False,
             trace: Optional[list] = None):
     """-> (h [N,F], X [N,D,F], tape or None).  ``save`` keeps what ``backward`` needs;
@@ -404,6 +400,8 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
     F_, R, H, D, M, lmax = cfg.F, cfg.R, cfg.H, cfg.D, cfg.M, cfg.lmax
     Fe = cfg.Fe
     N, E = g.N, g.E
+    if save:
+        check_backward_supported(cfg)               # before any launch: a saving forward is only run for a backward
     proj = _Proj(cfg)
     gemm, gemm_group = proj.gemm, proj.group
     dev = z32.device
@@ -417,12 +415,13 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
     ctx0 = new(N, 2 * F_)
     call("gn_node_init", ptr(z32), ptr(g.rowptr), ptr(g.src), ptr(feat), 2 * F_, ptr(g.cut),
          ptr(pw.A_na), ptr(pw.A_nbr), N, F_, ptr(ctx0), _stream())
-    y_pre = new(N, F_)
-    gemm(ctx0, 2 * F_, pw.Wa, pw.ba, y_pre, F_, N, F_, 2 * F_)
-    y = new(N, F_)
-    call("gn_layernorm_silu", ptr(y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, N, F_, ptr(y), cfg.act, _stream())
+    Fc = cfg.Fc or F_                              # (an embedded model keeps this intermediate compact: LayerNorm over the real channels)
+    y_pre = new(N, Fc)
+    gemm(ctx0, 2 * F_, pw.Wa, pw.ba, y_pre, Fc, N, Fc, 2 * F_)
+    y = new(N, Fc)
+    call("gn_layernorm_silu", ptr(y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, N, Fc, ptr(y), cfg.act, _stream())
     h = new(N, F_)
-    gemm(y, F_, pw.Wb, pw.bb, h, F_, N, F_, F_)
+    gemm(y, Fc, pw.Wb, pw.bb, h, F_, N, F_, Fc)
     t = new(E, F_)
     call("gn_edge_init", ptr(h), ptr(g.rowptr), ptr(g.src), feat.data_ptr() + 4 * F_, 2 * F_, N, F_, ptr(t), _stream())
     if save:
@@ -431,12 +430,11 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
     X = torch.zeros((N, D, F_), **f32)            # gotennet.py:992
     lde = (1 + M) * F_
     nact, g1act = new(N, 4 * F_), new(N, F_)       # activated copies (scratch, shared by all layers)
-    fused = (not save) and trace is None and E > 0 and fused_message_ok(cfg)
     eq_fused, eq_arith = eqff_fused_ok(cfg, N), (1 if proj.mode == "split" else 2)
     if not save:                                   # inference: ping-pong work buffers, reused by every layer
         h2, X2, t2 = new(N, F_), new(N, D, F_), new(E, F_)
         nproj, xs, vs = new(N, 4 * F_), new(N, M * F_), new(N, M * F_)
-        eproj, attn = (None if fused else new(E, lde)), new(E, H)
+        eproj, attn = new(E, lde), new(E, H)
         EQ, EK, Xp, w = new(N, D, Fe), new(N, D, Fe), new(N, D, F_), new(E, Fe)
         ctx, pre_g1, mm = new(N, 2 * F_), new(N, F_), new(N, 2 * F_)
 
@@ -472,7 +470,7 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
         # pre-activation copy is what the backward needs.
         first = zero_X_in(cfg, li)                  # X is the zero tensor made above: no tensor-gate blocks
         We, be, ne = _We_first(cfg, lw) if first else (lw.We, lw.be, lde)
-        gemm_group([None if fused else dict(A=t, lda=F_, W=We, bias=be, C=eproj, ldc=lde, rows=E, nout=ne, K=F_),
+        gemm_group([dict(A=t, lda=F_, W=We, bias=be, C=eproj, ldc=lde, rows=E, nout=ne, K=F_),
                     dict(A=h, lda=F_, W=lw.Wn1, bias=lw.bn1, C=nact, ldc=4 * F_, rows=N, nout=4 * F_, K=F_,
                          act=(2 * F_, 4 * F_), pre_out=nproj if save else None)])
         nv = _value_first(cfg, lw) if first else M * F_
@@ -480,12 +478,8 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
                          K=F_, a_off=2 * F_),
                     dict(A=nact, lda=4 * F_, W=lw.Wv20 if first else lw.Wv2, bias=lw.bv2, C=vs, ldc=M * F_, rows=N, nout=nv,
                          K=F_, a_off=3 * F_)])
-        # ---- message / softmax / aggregate / residual (452-559, 613-640, 426-427); inference: with the edge
-        # projection inside (no eproj stream)
-        if fused:
-            message_stage_fused(cfg, g, t, We, be, nact, xs, vs, attn, h, None if first else X, h2, X2)
-        else:
-            message_stage(cfg, g, nact, xs, vs, eproj, attn, h, None if first else X, h2, X2)
+        # ---- message / softmax / aggregate / residual (452-559, 613-640, 426-427)
+        message_stage(cfg, g, nact, xs, vs, eproj, attn, h, None if first else X, h2, X2)
         h, h2 = h2, h
         X, X2 = X2, X
         # every product of the updated X (X W_vu^T for EQFF; EQ and the per-degree EK_l for HTR) in one launch
@@ -532,7 +526,10 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
             gemm(g1act, F_, lw.Wm1, lw.bm1, mm, 2 * F_, N, 2 * F_, F_)
             call("gn_eqff_update", ptr(mm), ptr(Xp), N, F_, D, ptr(h), ptr(X), _stream())
         if trace is not None:
-            trace.append((h.clone(), X.clone(), t.clone()))
+            trace.append((h.clone(), X.clone(), t.clone()) if pw.emb_idx is None else
+                         tuple(v.index_select(v.dim() - 1, pw.emb_idx) for v in (h, X, t)))
+    if pw.emb_idx is not None:                     # embedded model: the real channels, in the model's own order
+        h, X = h.index_select(1, pw.emb_idx), X.index_select(2, pw.emb_idx)
     return h, X, tape
 
 
@@ -646,32 +643,6 @@ def eqff_fused_ok(cfg: Config, n_atoms: Optional[int] = None) -> bool:
     return bool(_lib.load().gn_eqff_fused_supported(cfg.F, cfg.act, 1 if mode == "split" else 2))
 
 
-def fused_message_ok(cfg: Config) -> bool:
-    """gn_message_fused covers this model (SiLU, lmax <= 4, F a power of two >= 128, a plane arithmetic) and is switched on."""
-    mode = resolve_mode(cfg.gemm_mode)
-    if not cfg.fuse_message or cfg.sliced or cfg.aggr or mode not in _PLANE_MODES:
-        return False
-    return bool(_lib.load().gn_message_fused_supported(cfg.F, cfg.H, cfg.lmax, cfg.M, cfg.act, 1 if mode == "split" else 2))
-
-
-def message_stage_fused(cfg: Config, g: "Graph", t, We, be, nact, xs, vs, attn_ws, h, X, h2, X2):
-    """Edge projection + scores + segment softmax + message + aggregate + residual as ONE launch (gn_message_fused):
-    the inference form of ``gemm(t, [W_re; W_rs])`` -> ``message_stage`` without eproj.  ``X`` None: first interaction
-    (``We`` / ``be`` are then the prefix without the tensor-gate blocks)."""
-    mode = resolve_mode(cfg.gemm_mode)
-    tile_first, n_tiles, cap = g.tiles()
-    d = _lib.FusedDesc()
-    d.t, d.W, d.bias = ptr(t), ptr(split_weight(We, mode)), ptr(be)
-    d.q, d.k, d.ldqk = ptr(nact), nact.data_ptr() + 4 * cfg.F, 4 * cfg.F
-    d.x, d.v, d.ldxv = ptr(xs), ptr(vs), cfg.M * cfg.F
-    d.X_in, d.h_in, d.h_out, d.X_out = ptr(X), ptr(h), ptr(h2), ptr(X2)
-    d.rl, d.cut, d.rowptr, d.src, d.outdeg = ptr(g.rl), ptr(g.cut), ptr(g.rowptr), ptr(g.src), ptr(g.outdeg)
-    d.tile_first, d.n_tiles, d.tile_cap, d.attn_ws = ptr(tile_first), ptr(n_tiles), cap, ptr(attn_ws)
-    d.N, d.F, d.H, d.lmax, d.sep_dir, d.sep_tensor = g.N, cfg.F, cfg.H, cfg.lmax, int(cfg.sep_dir), int(cfg.sep_tensor)
-    import ctypes
-    call("gn_message_fused", ctypes.byref(d), 1 if mode == "split" else 2, _stream())
-
-
 def _edge_update_composed(cfg: Config, lw: LayerWeights, t, w_raw, t2, E: int, pre_t):
     """t2 = t + gamma_t(t) * gamma_w(w) for the non-default variants (gotennet.py:236-291, 611):
     gamma_w = [LayerNorm "ln"] -> [SiLU "linwa"] -> W_edp "linw"/"linwa" [-> LayerNorm "postln"] -> [gate];
@@ -767,8 +738,7 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
     gemm, gemm_group = proj.gemm, proj.group
     f32 = dict(dtype=torch.float32, device=z32.device)
     new = lambda *shape: torch.empty(shape, **f32)
-    if cfg.aggr == 2:
-        raise NotImplementedError("aggr='max': the message stage has a forward kernel only (no input-gradient / forces)")
+    check_backward_supported(cfg)
     colptr, perm = g.csc()
     lde = (1 + M) * F_
     eq_fused, eq_arith = eqff_fused_ok(cfg, N), (1 if proj.mode == "split" else 2)
@@ -781,6 +751,11 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
     ga_parts = new(G, E, H) if G > 1 else None
     rl_slice = lambda q: g_rl_parts.data_ptr() + 4 * q * E * D
     cut_slice = lambda q: g_cut_parts.data_ptr() + 4 * q * E
+    if pw.emb_idx is not None:                     # embedded model: gradients arrive in the real layout
+        z_ = torch.zeros((N, F_), **f32)
+        gh = z_.index_copy_(1, pw.emb_idx, gh.contiguous())
+        if gX is not None:
+            gX = torch.zeros((N, D, F_), **f32).index_copy_(2, pw.emb_idx, gX.contiguous())
     gh = gh.contiguous()
     gX = torch.zeros((N, D, F_), **f32) if gX is None else gX.contiguous()
     gh_caller, gX_caller = gh, gX                  # read-only: never enter the work-buffer rotation below
@@ -908,11 +883,12 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
     g_feat = new(E, 2 * F_)
     call("gn_edge_init_backward", ptr(gt), ptr(tape.h0), ptr(tape.feat), 2 * F_, ptr(g.rowptr), ptr(g.src),
          ptr(colptr), ptr(perm), N, F_, ptr(g_feat), ptr(gh), _stream())
-    gy = new(N, F_)
-    gemm(gh, F_, _T(pw, "Wb"), None, gy, F_, N, F_, F_)
-    gy1 = new(N, F_)
-    call("gn_layernorm_silu_backward", ptr(tape.y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, ptr(gy), N, F_, ptr(gy1), cfg.act, _stream())
-    gemm(gy1, F_, _T(pw, "Wa"), None, g_ctx, 2 * F_, N, 2 * F_, F_)
+    Fc = cfg.Fc or F_
+    gy = new(N, Fc)
+    gemm(gh, F_, _T(pw, "Wb"), None, gy, Fc, N, Fc, F_)
+    gy1 = new(N, Fc)
+    call("gn_layernorm_silu_backward", ptr(tape.y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, ptr(gy), N, Fc, ptr(gy1), cfg.act, _stream())
+    gemm(gy1, Fc, _T(pw, "Wa"), None, g_ctx, 2 * F_, N, 2 * F_, Fc)
     call("gn_node_init_backward", ptr(g_ctx), ptr(z32), ptr(tape.feat), 2 * F_, ptr(g.cut), ptr(pw.A_nbr),
          ptr(g.rowptr), ptr(g.src), N, F_, ptr(g_feat), cut_slice(G * L), _stream())
     g_phi = new(E, R)

@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
-from . import engine
+from . import embed, engine
 from ._lib import GotenNetHipError
 from .layers import (BASIS_CODE, MLP, CosineCutoff, Dense, EdgeInit, NodeInit, activation_kind,
                      get_weight_init_by_string, resolve_activation, str2basis)
@@ -163,8 +163,10 @@ class GATA(_LayerPackCache, nn.Module):
         if self.edge_vec_dim != n_atom_basis and not info["lin_w"] and edge_updates:
             raise ValueError("evec_dim != n_atom_basis needs a 'linw'/'linwa' edge update (W_edp maps w_ij back to "
                              "n_atom_basis; the reference fails with a shape error otherwise)")
-        if self.edge_vec_dim < 16 or self.edge_vec_dim > 1024 or self.edge_vec_dim & (self.edge_vec_dim - 1):
-            raise NotImplementedError("evec_dim must be a power of two in [16, 1024] on the HIP path (<= 256 for forces)")
+        if evec_dim is not None and evec_dim != n_atom_basis and (
+                self.edge_vec_dim < 16 or self.edge_vec_dim > 1024 or self.edge_vec_dim & (self.edge_vec_dim - 1)):
+            raise NotImplementedError("evec_dim (when it differs from n_atom_basis) must be a power of two in [16, 1024] on the "
+                                      "HIP path, and at most 256 for forces")
         if self.edge_mlp_dim % 4:
             raise NotImplementedError("emlp_dim must be a multiple of 4 on the HIP path")
         self.layernorm_, self.steerable_norm_ = layer_norm, steerable_norm
@@ -369,7 +371,6 @@ class GotenNet(nn.Module):
                  sep_dir: bool = False, sep_tensor: bool = False, edge_ln: str = ""):
         super().__init__()
         self._packed = self._packed_key = self._packed_params = None
-        self._packed_calls = 0
         self.scale_edge = scale_edge
         if type(weight_init) == str:
             weight_init = get_weight_init_by_string(weight_init)
@@ -415,10 +416,6 @@ class GotenNet(nn.Module):
         #: True: lmax <= 4 runs on the degree-sliced kernel family as well (GN_LMAX_SLICED; tests hold the two families
         #: against each other)
         self.sliced_kernels = False
-        #: True: inference calls (nothing saved for a backward) run edge projection + softmax + message as ONE kernel
-        #: (gn_message_fused: no [E, (1+M)F] stream) where the model is covered (engine.fused_message_ok).  Off by default:
-        #: measured 2-10 % slower than the three-kernel sequence on MI355X
-        self.fuse_message = False
         #: the EQFF chain after X_p (context, gamma_m, update; and its input-gradient) as one kernel each way where covered
         #: (engine.eqff_fused_ok: F in {128, 256}, SiLU, a plane arithmetic).  None = auto: on for calls of at most
         #: engine.EQFF_FUSED_MAX_ATOMS atoms (a one-molecule step is launch-bound: 2.31 -> 1.91 ms; 32 molecules -2 %), off
@@ -442,8 +439,8 @@ class GotenNet(nn.Module):
         ``packed_weights`` notices parameter updates through autograd's version counter (optimizer steps,
         ``load_state_dict``, ``copy_`` / ``fill_`` under ``torch.no_grad()``) and through ``data_ptr`` (``.to()``,
         ``.cuda()``).  A write through ``param.data`` (``p.data.copy_(...)``, EMA weight swaps written that way) bumps
-        NEITHER: call this method after such a write -- and after replacing a parameter OBJECT of a submodule (the kept
-        tensor list is refreshed every 32nd call only)."""
+        NEITHER: call this method after such a write.  (A replaced parameter OBJECT is noticed: every slot of the module
+        tree is checked for identity on each call.)"""
         self._packed = self._packed_key = self._packed_params = None
 
     def load_state_dict(self, *args, **kwargs):
@@ -483,6 +480,15 @@ class GotenNet(nn.Module):
         return net
 
     def config(self) -> engine.Config:
+        """The kernels' view of the model.  A width that is not a power of two runs embedded in the next one (embed.py):
+        ``F`` is then the padded width, ``F_model`` the real one."""
+        cfg = self._config_real()
+        if embed.needs_embedding(cfg.F):
+            embed.check(cfg.F, cfg.H, cfg)
+            cfg = embed.embedded_config(cfg)
+        return cfg
+
+    def _config_real(self) -> engine.Config:
         g0 = self.gata_list[0]
         return engine.Config(F=self.n_atom_basis, L=self.n_interactions, R=self.n_rbf, H=self.num_heads,
                              lmax=self.lmax, M=g0.multiplier, cutoff=float(self.cutoff), eps=float(self.epsilon),
@@ -494,23 +500,31 @@ class GotenNet(nn.Module):
                              lin_w=g0.update_info["lin_w"], lin_ln=g0.update_info["lin_ln"],
                              evec=g0.edge_vec_dim, emlp=g0.edge_mlp_dim, act=self.act_kind,
                              gemm_mode=engine.resolve_mode(self.gemm_mode), sliced=bool(self.sliced_kernels),
-                             fuse_message=bool(self.fuse_message), fuse_eqff=self.fuse_eqff, aggr=g0.aggr_kind)
+                             fuse_eqff=self.fuse_eqff, aggr=g0.aggr_kind)
+
+    def _param_slots(self):
+        """(owner's ``_parameters`` / ``_buffers`` dict, name, tensor) of every parameter and buffer of the tree."""
+        out = []
+        for m in self.modules():
+            out += [(m._parameters, n, t) for n, t in m._parameters.items() if t is not None]
+            out += [(m._buffers, n, t) for n, t in m._buffers.items() if t is not None]
+        return out
 
     def packed_weights(self) -> engine.PackedWeights:
         """Concatenate the projections that share an input into single GEMM operands
         (cached; rebuilt when any parameter is modified or moved)."""
-        # (walking the module tree costs 0.3 ms -- a sixth of the host time of a one-molecule eager step: the tensor list is
-        #  kept, every call checks the addresses / version counters of the kept tensors, every 32nd call and every
-        #  ``_apply`` (``.to`` / ``.cuda`` / ``.float``) or ``load_state_dict`` walks the tree again)
-        params = self._packed_params
-        self._packed_calls += 1
-        if params is None or (self._packed_calls & 31) == 0:
-            params = self._packed_params = list(self.parameters()) + list(self.buffers())
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        # (walking the module tree costs 0.3 ms -- a sixth of the host time of a one-molecule eager step: the walk is kept as
+        #  (owner dict, name, tensor) triples.  Every call checks that each slot still holds THAT tensor object -- a replaced
+        #  Parameter (torch.func.functional_call, a parent module's load_state_dict(assign=True), parametrize,
+        #  ``layer.weight = nn.Parameter(...)``) fails the identity test and triggers a new walk -- and compares the
+        #  addresses / version counters of the kept tensors: O(P) dictionary look-ups, no tree walk)
+        slots = self._packed_params
+        if slots is None or any(d.get(n) is not t for d, n, t in slots):
+            slots = self._packed_params = self._param_slots()
+            self._packed = None
+        key = tuple((t.data_ptr(), t._version) for _, _, t in slots)
         if self._packed is not None and key == self._packed_key:
             return self._packed
-        params = self._packed_params = list(self.parameters()) + list(self.buffers())
-        key = tuple((p.data_ptr(), p._version) for p in params)
         c = lambda *ts: torch.cat([t.detach() for t in ts], dim=0).contiguous()
         d = lambda t: t.detach().contiguous()
         ni, ei = self.node_init, self.edge_init
@@ -526,6 +540,10 @@ class GotenNet(nn.Module):
         for gata, eq in zip(self.gata_list, self.eqff_list):
             lw = _pack_eqff(eq, _pack_gata(gata))
             pw.layers.append(lw)
+        if embed.needs_embedding(self.n_atom_basis):    # not a power of two: the equivalent model of the padded width
+            real = self._config_real()
+            embed.check(real.F, real.H, real)
+            pw = embed.embed_pack(pw, real.F, real.H, real.M)
         self._packed, self._packed_key = pw, key
         return pw
 
@@ -560,14 +578,16 @@ class GotenNet(nn.Module):
             self._warned_inference_only = True
 
     def forward(self, atomic_numbers: Tensor, edge_index: Tensor, edge_diff: Tensor, edge_vec: Tensor,
-                _trace: Optional[list] = None) -> Tuple[Tensor, Tensor]:
+                _trace: Optional[list] = None, _sorted: Optional[bool] = None) -> Tuple[Tensor, Tensor]:
+        """``_sorted`` (internal): this CALL's edge list is target-major (the wrapper's own radius graph); None = the
+        module's ``assume_sorted_edges``.  A per-call argument, not module state: calls from several threads do not race."""
         self._check_inputs(atomic_numbers, edge_index, edge_diff, edge_vec)
         cfg, pw = self.config(), self.packed_weights()
         N = atomic_numbers.shape[0]
         edge_index = edge_index.contiguous()
         edge_diff = edge_diff.to(torch.float32).contiguous()
         edge_vec = edge_vec.to(torch.float32).contiguous()
-        if not self.assume_sorted_edges:                    # one host sync; skipped when assume_sorted_edges
+        if not (self.assume_sorted_edges if _sorted is None else _sorted):   # one host sync; skipped for sorted lists
             edge_index, edge_diff, edge_vec, _ = engine.sorted_edges(edge_index, edge_diff, edge_vec, N)
         z32 = atomic_numbers.to(torch.int32)
         self._warn_if_training()
@@ -594,8 +614,4 @@ class GotenNetWrapper(GotenNet):
             self._check_inputs(atomic_numbers, torch.zeros((2, 0), dtype=torch.int64), pos.new_zeros(0), pos.new_zeros((0, 3)))
             return _RepresentationPosFn.apply(pos, self, atomic_numbers.to(torch.int32), batch)
         edge_index, edge_diff, edge_vec = distance(pos, batch, self.cutoff, self.max_num_neighbors)
-        sorted_flag, self.assume_sorted_edges = self.assume_sorted_edges, True   # radius graph is target-major
-        try:
-            return super().forward(atomic_numbers, edge_index, edge_diff, edge_vec)
-        finally:
-            self.assume_sorted_edges = sorted_flag
+        return super().forward(atomic_numbers, edge_index, edge_diff, edge_vec, _sorted=True)   # radius graph is target-major

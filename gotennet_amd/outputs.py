@@ -57,7 +57,9 @@ class ScaleShift(nn.Module):
 
 def molecule_ptr(batch: torch.Tensor, n_mol: int) -> torch.Tensor:
     """int32 [n_mol+1] offsets of each molecule in the (sorted) batch vector -- index plumbing."""
-    cnt = torch.bincount(batch, minlength=n_mol)
+    # (torch.bincount reads max(batch) back to size its output: a host synchronisation per call; index_add_ does not)
+    cnt = torch.zeros(n_mol, dtype=torch.int32, device=batch.device)
+    cnt.index_add_(0, batch, torch.ones_like(batch, dtype=torch.int32))
     out = torch.zeros(n_mol + 1, dtype=torch.int32, device=batch.device)
     out[1:] = torch.cumsum(cnt, 0)
     return out

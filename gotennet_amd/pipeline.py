@@ -111,22 +111,31 @@ class EnergyForces:
         e, y, pre1 = self.head.energy_raw(h, z32, mol_ptr, n_mol, mode=cfg.gemm_mode)
         if not forces:
             return e, None
-        gh = self.head.grad_h_raw(pre1, cfg.F, mode=cfg.gemm_mode)
+        gh = self.head.grad_h_raw(pre1, cfg.F_model or cfg.F, mode=cfg.gemm_mode)
         g_vec, g_diff = engine.backward(cfg, pw, z32, g, tape, gh, None)
         return e, engine.pos_gradient(g, g_vec, g_diff, sign=-1.0)
 
     # ---- hipGraph replay of the eager step on a cached topology --------------------------------------------------
     def _replay_ok(self, gs, cfg, pw, N, edge_index, n_mol) -> bool:
+        # (the head's scalars -- last bias, scale / shift, AtomwiseV3's molecule shift -- are baked into the captured kernel
+        #  arguments and its transposed weights are captured pointers: its cache key is part of the replay key)
         ok = (self._topo is not None and self._topo[1] is edge_index and not edge_index.is_inference()
-              and gs["key"] == (self._topo[0], cfg, id(pw), n_mol) and self._topo[0][1] == edge_index._version)
+              and gs["key"] == (self._topo[0], cfg, id(pw), n_mol, self._head_key()) and self._topo[0][1] == edge_index._version)
         if not ok:
             self._graph_state = None
         return ok
 
+    def _head_key(self):
+        """Everything of the head a recorded step depends on: its packed-cache key (parameter addresses / versions,
+        incl. the ScaleShift buffers) and the host scalars that become kernel arguments."""
+        packed = self.head._packed()
+        c = packed[1] if isinstance(packed, tuple) else packed
+        return (id(self.head), c["key"], c.get("scale"), c.get("shift"), c.get("b2"), c.get("mol_shift"))
+
     def _capture(self, cfg, pw, g, z32, edge_index, n_mol, mol_ptr):
         dev = z32.device
         order = self._topo[3]
-        st = dict(key=(self._topo[0], cfg, id(pw), n_mol), g=g, order=order, z32=z32.clone(), mol_ptr=mol_ptr.clone(),
+        st = dict(key=(self._topo[0], cfg, id(pw), n_mol, self._head_key()), g=g, order=order, z32=z32.clone(), mol_ptr=mol_ptr.clone(),
                   ed=torch.empty(g.E, dtype=torch.float32, device=dev), ev=torch.empty((g.E, 3), dtype=torch.float32, device=dev))
         st["ed"].copy_(g.edge_diff)
         st["ev"].copy_(g.edge_vec)
@@ -204,7 +213,7 @@ class CapturedStep:
         g.set_positions(self.pos)
         h, X, tape = engine.forward(cfg, pw, self.z32, g, save=True)
         e, y, pre1 = self.head.energy_raw(h, self.z32, self.mol_ptr, self.n_mol, mode=cfg.gemm_mode)
-        gh = self.head.grad_h_raw(pre1, cfg.F, mode=cfg.gemm_mode)
+        gh = self.head.grad_h_raw(pre1, cfg.F_model or cfg.F, mode=cfg.gemm_mode)
         g_vec, g_diff = engine.backward(cfg, pw, self.z32, g, tape, gh, None)
         return e, engine.pos_gradient(g, g_vec, g_diff, sign=-1.0)
 

@@ -38,7 +38,7 @@ extern "C" {
 
 #define GN_OK 0
 #define GN_ERR_BAD_ARG 10001     /* shape/flag combination the kernels do not implement */
-#define GN_ABI_VERSION 7
+#define GN_ABI_VERSION 8
 /* OR-ed into the `lmax` ARGUMENT of gn_message_aggregate, gn_message_backward(_groups), gn_htr_edge and
  * gn_htr_backward: run this call on the degree-sliced kernel family at lmax <= 4 as well (the family that serves
  * lmax 5..8).  An explicit per-call request -- the library reads no environment variable and keeps no switch; every
@@ -253,37 +253,6 @@ int gn_eqff_fused_forward(const float* Xp, const void* W0p, const float* b0, con
 int gn_eqff_fused_backward(const float* gh, const float* gX, const float* mm, const float* Xp, const float* ctx,
                            const float* pre_g1, const void* W1Tp, const void* W0Tp, int N, int F, int D,
                            float* gXp, float* gh1, int arith, void* stream);
-
-/* ---- K5 + K6 fused: the message stage without the [E, (1+M)F] edge-projection stream (inference) ------------- */
-/* The reference materialises t_attn | t_filter = [W_re; W_rs] t_ij + b per edge (gotennet.py:406-407) and consumes it in
- * `message` / `aggregate` (452-559, 613-640).  When nothing is kept for a backward that stream need not exist:
- * gn_message_fused is the edge projection (the plane arithmetics of gn_gemm_split / gn_gemm_f16x2) with scores, segment
- * softmax, message, segmented reduction and residual as its epilogue -- same inputs and outputs as the sequence
- * gn_gemm_*(t, [W_re; W_rs]) -> gn_attn_softmax -> gn_message_aggregate, minus eproj and a.
- * Work units are TILES of <= 128 consecutive CSR edge rows cut on target boundaries, built once per topology by
- * gn_edge_tiles (tile_first[k] = first target of tile k, tile_first[*n_tiles] = N; tile_first holds `cap` + 1 ints with
- * cap = gn_edge_tiles_cap(N, E), a host-side upper bound that also sizes the launch grid -- no read-back).
- * Supported (gn_message_fused_supported != 0): F a power of two in [128, 1024], H <= 16 with F/H a multiple of 4 and
- * <= 128, lmax <= 4, SiLU, arith 1 (3 x bf16 planes) or 2 (2 x fp16 planes); everything else runs the three-kernel
- * sequence.  X_in == NULL: the first interaction (X = 0), `W` / `bias` then hold the prefix without the tensor-gate
- * blocks.  attn_ws: [E, H] scratch, touched only for targets with more than 128 incoming edges. */
-typedef struct gn_fused_desc {
-    const float* t;                 /* [E, F] edge state t_ij                                  */
-    const void* W;                  /* planes of [W_re; W_rs] written by gn_split_bf16x3 / gn_split_f16x2 */
-    const float* bias;              /* [(1 + blocks) F] or NULL                                */
-    const float* q; const float* k; int ldqk;
-    const float* x; const float* v; int ldxv;
-    const float* X_in; const float* h_in; float* h_out; float* X_out;
-    const float* rl; const float* cut;
-    const int* rowptr; const int* src; const int* outdeg;
-    const int* tile_first; const int* n_tiles; int tile_cap;
-    float* attn_ws;
-    int N, F, H, lmax, sep_dir, sep_tensor;
-} gn_fused_desc;
-long gn_edge_tiles_cap(int N, long E);
-int gn_edge_tiles(const int* rowptr, int N, int cap, int* tile_first, int* n_tiles, void* stream);
-int gn_message_fused_supported(int F, int H, int lmax, int M, int act, int arith);
-int gn_message_fused(const gn_fused_desc* d, int arith, void* stream);
 
 /* ---- K7 HTR edge weights -------------------------------------------------------------- */
 /* w[e,f] = sum_l sum_m P(EQ[i])_m * P(EK[j])_m with P(a) = a - (a . rl_l) rl_l per degree block

@@ -87,6 +87,47 @@ def test_packed_cache_invalidation_hooks():
     assert net.packed_weights() is not pw3
 
 
+def test_packed_cache_sees_replaced_parameter_objects():
+    """A Parameter OBJECT that is replaced -- torch.func.functional_call, a PARENT module's load_state_dict(assign=True),
+    ``layer.weight = nn.Parameter(...)`` -- leaves the old tensors unchanged: the pack is keyed on the identity of every
+    slot of the module tree, so the very next call repacks (it used to take up to 32 calls)."""
+    import gotennet_amd
+    mk = lambda: gotennet_amd.GotenNet(n_atom_basis=32, n_interactions=2, n_rbf=8, cutoff_fn=gotennet_amd.CosineCutoff(5.0), lmax=2)
+    net = mk()
+    pw0 = net.packed_weights()
+    new_w = torch.nn.Parameter(torch.randn(32, 32))
+    net.gata_list[0].W_q.weight = new_w                                         # plain attribute replacement
+    pw1 = net.packed_weights()
+    assert pw1 is not pw0 and torch.equal(pw1.layers[0].Wn1[:32], new_w)
+    assert net.packed_weights() is pw1
+
+    class Parent(torch.nn.Module):
+        def __init__(self, rep):
+            super().__init__()
+            self.representation = rep
+
+    parent, donor = Parent(net), Parent(mk())
+    parent.load_state_dict(donor.state_dict(), assign=True)                     # never reaches GotenNet.load_state_dict
+    pw2 = net.packed_weights()
+    assert pw2 is not pw1 and torch.equal(pw2.layers[0].Wn1[:32], donor.representation.gata_list[0].W_q.weight)
+    # functional_call: the swapped-in tensors are packed inside the call, the module's own again after it
+    other = {k: v.detach().clone() + 1.0 for k, v in net.named_parameters()}
+    seen = {}
+
+    def probe(self_net):
+        seen["inside"] = self_net.packed_weights().layers[0].Wn1[:32].clone()
+        return torch.zeros(())
+
+    orig_forward = type(net).forward
+    try:
+        type(net).forward = lambda self, *a, **k: probe(self)
+        torch.func.functional_call(net, other, ())
+    finally:
+        type(net).forward = orig_forward
+    assert torch.equal(seen["inside"], other["gata_list.0.W_q.weight"])
+    assert torch.equal(net.packed_weights().layers[0].Wn1[:32], net.gata_list[0].W_q.weight)
+
+
 # --------------------------------------------------------------------------------------------------- GPU
 def _mirror(cfg, sd):
     from tests.test_hip_parity import _net_from_case
@@ -618,6 +659,60 @@ def test_energy_forces_replays_static_topology_bit_identically():
     assert rep._graph_state is not None and rep._graph_state["order"] is not None
     rep.clear_cache()
     assert rep._graph_state is None and rep._topo is None
+
+
+@pytest.mark.gpu
+def test_replay_follows_the_head():
+    """The recorded step bakes the head's host scalars (last bias, scale / shift) into kernel arguments and captures the
+    pointers of its transposed weights: a head that changes after the capture -- an in-place update, load_state_dict, a
+    new mean / stddev -- must drop the graph, not replay the old head."""
+    from tests.test_hip_forces import _head_from_case
+    from gotennet_amd.graph import distance
+    from gotennet_amd.pipeline import EnergyForces
+    cfg, sd, head_sd, t = load_case("l2_sep_f32")
+    net, head = _mirror(cfg, sd), _head_from_case(cfg, head_sd)
+    z, batch, pos = t["z"].cuda(), t["batch"].cuda(), t["pos"].cuda()
+    ei, ed, ev = distance(pos, batch, cfg["cutoff"], 32)
+    rep = EnergyForces(net, head, replay=True)
+    for _ in range(4):
+        e_old, f_old = rep(z, ei, ed, ev, batch, cfg["n_mol"])
+    assert rep._graph_state is not None
+    with torch.no_grad():                                                       # optimiser-style in-place update of the head
+        for p_ in head.parameters():
+            p_.mul_(1.5)
+        if hasattr(head.standardize, "stddev"):
+            head.standardize.stddev.mul_(2.0)
+            head.standardize.mean.add_(0.25)
+    e_new, f_new = rep(z, ei, ed, ev, batch, cfg["n_mol"])
+    e_ref, f_ref = EnergyForces(net, head)(z, ei, ed, ev, batch, cfg["n_mol"])
+    assert torch.equal(e_new, e_ref) and torch.equal(f_new, f_ref)
+    assert not torch.equal(e_new, e_old)
+    for _ in range(3):                                                          # ... and records again on the new head
+        e2, f2 = rep(z, ei, ed, ev, batch, cfg["n_mol"])
+    assert rep._graph_state is not None and torch.equal(e2, e_ref) and torch.equal(f2, f_ref)
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_rccl_path():
+    """`bench.py --force-dist`: RCCL initialised with ONE rank (the boxes the driver reaches have one GPU): process group,
+    barrier, the per-step all-reduce of the energy vector all run; the record says one rank was seen and its checksum
+    equals the plain run's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8", "--no-lmax4", "--no-split",
+            "--no-graph", "--no-workloads", "--no-cpu-baseline", "--no-forward-only", "--no-live-traffic"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = []
+    for extra in ([], ["--force-dist"]):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    plain, dist_ = outs
+    assert dist_["n_ranks_seen"] == 1 and dist_["energy_vector_len"] == 8
+    assert dist_["energy_checksum"] == plain["energy_checksum"]
+    assert dist_["rank_ms_per_step"] and len(dist_["rank_ms_per_step"]) == 1
 
 
 # --------------------------------------------------------------------------------------------------- AtomwiseV3

@@ -528,3 +528,52 @@ def test_softmax_beyond_the_lds_capacity():
     (g_hip,) = torch.autograd.grad((h ** 2).sum() + (X ** 2).sum(), vec_d)
     real = src != dst                                  # (a self-loop's vector is pos[i] - pos[i]: its gradient never reaches a position)
     assert rel_err(g_hip.cpu()[real], g_ref[real]) < TOL
+
+
+@pytest.mark.parametrize("F,H,lmax", [(192, 8, 2), (96, 4, 3), (48, 4, 1), (200, 8, 2), (384, 8, 2)])
+def test_feature_width_not_a_power_of_two(F, H, lmax):
+    """n_atom_basis that is not a power of two (the reference takes any multiple of num_heads, gotennet.py:767-793) runs
+    embedded in the next power-of-two width (gotennet_amd/embed.py: zero-padded weights, channels placed head by head, the
+    attention scale folded into gamma_v, the NodeInit LayerNorm kept compact): (h, X) against the oracle, and -- where the
+    padded width has a force path (<= 256) -- energies and forces."""
+    import gotennet_amd
+    from oracle import gotennet_oracle as orc
+    from gotennet_amd.outputs import Atomwise
+    from gotennet_amd.pipeline import EnergyForces
+    torch.manual_seed(F)
+    kw = dict(n_atom_basis=F, n_interactions=3, n_rbf=16, num_heads=H, scale_edge=(F % 3 == 0), lmax=lmax, sep_dir=True,
+              sep_tensor=True)
+    net = gotennet_amd.GotenNet(cutoff_fn=gotennet_amd.CosineCutoff(5.0), **kw)
+    with torch.no_grad():                                        # biases are zero-initialised: make them count
+        for n_, p_ in net.named_parameters():
+            if n_.endswith("bias"):
+                p_.normal_(0.0, 0.1)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    cfg = orc.default_config(**kw)
+    pos, batch, z = _synthetic(3, 13, 3.5, seed=F)
+    ei, w, vec = orc.distance(pos, batch, 5.0)
+    h_ref, X_ref = orc.gotennet_forward(sd, cfg, z, ei, w, vec)
+    net = net.cuda().eval()
+    c = net.config()
+    assert c.F_model == F and c.F >= F and (c.F & (c.F - 1)) == 0
+    h, X = net(z.cuda(), ei.cuda(), w.cuda(), vec.cuda())
+    assert h.shape == (39, F) and X.shape == (39, (lmax + 1) ** 2 - 1, F)
+    assert rel_err(h.cpu(), h_ref) < TOL and rel_err(X.cpu(), X_ref) < TOL
+    if c.F > 256:
+        return                                                    # (the padded width has no force path yet: forward only)
+    head = Atomwise(n_in=F, n_hidden=32, derivative="forces", activation="silu")
+    hsd = {k: v.clone() for k, v in head.state_dict().items()}
+    e_ref, f_ref, _ = orc.energy_and_forces(sd, cfg, hsd, z, pos, batch, 3)
+    e, f = EnergyForces(net, head.cuda().eval())(z.cuda(), ei.cuda(), w.cuda(), vec.cuda(), batch.cuda(), 3)
+    assert rel_err(e.cpu(), e_ref) < TOL and rel_err(f.cpu(), f_ref) < TOL
+    # the reference-style call (autograd through the representation) on the same model
+    p = pos.cuda().requires_grad_(True)
+    from gotennet_amd.graph import distance
+    gi, gw, gv = distance(p, batch.cuda(), 5.0, 32)
+    hh, XX = net(z.cuda(), gi, gw, gv)
+    (gp,) = torch.autograd.grad((hh * hh).sum() + (XX * XX).sum(), p)
+    pr = pos.clone().requires_grad_(True)
+    ei2, w2, v2 = orc.distance(pr, batch, 5.0)
+    h2, X2 = orc.gotennet_forward(sd, cfg, z, ei2, w2, v2)
+    (gr,) = torch.autograd.grad((h2 * h2).sum() + (X2 * X2).sum(), pr)
+    assert rel_err(gp.cpu(), gr) < TOL

@@ -1,6 +1,5 @@
 #!/usr/bin/env python
-"""Small systems as one hipGraph replay per step (EnergyForces(replay=True)): ms/step with GotenNet.fuse_eqff forced on / off,
-and the energy-only forward with / without fuse_message, for 1 / 8 / 32 molecules.   python tools/small_system_ab.py"""
+"""Small systems as one hipGraph replay per step (EnergyForces(replay=True)): ms/step with GotenNet.fuse_eqff forced on / off for 1 / 8 / 32 molecules.   python tools/small_system_ab.py"""
 import os
 import sys
 import time
@@ -58,5 +57,3 @@ def run(B, forces, n=100, **attrs):
 for B in (1, 8, 32):
     a, b = run(B, True, fuse_eqff=True), run(B, True, fuse_eqff=False)
     print(f"b={B} energy+forces, one replay per step: fuse_eqff on {a:.3f} ms | off {b:.3f} ms")
-    a, b = run(B, False, fuse_message=True), run(B, False, fuse_message=False)
-    print(f"b={B} energy only, one replay per step:   fuse_message on {a:.3f} ms | off {b:.3f} ms")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""In-process A/B of the energy+force step for a boolean attribute of GotenNet (fuse_eqff, fuse_message, ...):
+"""In-process A/B of the energy+force step for a boolean attribute of GotenNet (fuse_eqff, ...):
 python tools/step_ab.py ATTR [workload batch lmax]   -> ms/step with ATTR = True / False, alternating, 3 rounds."""
 import os
 import sys
