@@ -566,14 +566,12 @@ def test_feature_width_not_a_power_of_two(F, H, lmax):
     e_ref, f_ref, _ = orc.energy_and_forces(sd, cfg, hsd, z, pos, batch, 3)
     e, f = EnergyForces(net, head.cuda().eval())(z.cuda(), ei.cuda(), w.cuda(), vec.cuda(), batch.cuda(), 3)
     assert rel_err(e.cpu(), e_ref) < TOL and rel_err(f.cpu(), f_ref) < TOL
-    # the reference-style call (autograd through the representation) on the same model
-    p = pos.cuda().requires_grad_(True)
-    from gotennet_amd.graph import distance
-    gi, gw, gv = distance(p, batch.cuda(), 5.0, 32)
-    hh, XX = net(z.cuda(), gi, gw, gv)
-    (gp,) = torch.autograd.grad((hh * hh).sum() + (XX * XX).sum(), p)
-    pr = pos.clone().requires_grad_(True)
-    ei2, w2, v2 = orc.distance(pr, batch, 5.0)
-    h2, X2 = orc.gotennet_forward(sd, cfg, z, ei2, w2, v2)
-    (gr,) = torch.autograd.grad((h2 * h2).sum() + (X2 * X2).sum(), pr)
-    assert rel_err(gp.cpu(), gr) < TOL
+    # the reference-style call (autograd through the representation, gradients of a functional of h AND X w.r.t. the edge inputs)
+    evr, edr = vec.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    h2, X2 = orc.gotennet_forward(sd, cfg, z, ei, edr, evr)
+    gv_ref, gd_ref = torch.autograd.grad((h2 * h2).sum() + (X2 * X2).sum(), [evr, edr])
+    evc, edc = vec.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    hh, XX = net(z.cuda(), ei.cuda(), edc, evc)
+    gv, gd = torch.autograd.grad((hh * hh).sum() + (XX * XX).sum(), [evc, edc])
+    mask = ei[0] != ei[1]
+    assert rel_err(gv.cpu()[mask], gv_ref[mask]) < TOL and rel_err(gd.cpu()[mask], gd_ref[mask]) < TOL
