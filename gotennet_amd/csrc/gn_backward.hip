@@ -1164,15 +1164,17 @@ extern "C" int gn_message_backward(
     float* g_eproj, float* g_s, float* g_nproj, int ldn, float* g_x, float* g_v, float* g_X_out,
     float* g_rl, float* g_cut, float* ga_parts, long E,
     int N, int F, int H, int lmax_arg, int sep_dir, int sep_tensor, int act, void* stream) {
-    const int lmax = lmax_arg & 0xff;               // GN_LMAX_SLICED / GN_LMAX_MEAN may ride in the argument ("max" has no backward)
-    if ((lmax_arg & ~(0xff | GN_LMAX_SLICED | GN_LMAX_MEAN)) || !bwd_dim_ok(F) || N < 0 || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || lmax < 1 || lmax > 8 ||
+    const int lmax = lmax_arg & 0xff;               // GN_LMAX_SLICED / GN_LMAX_MEAN / GN_LMAX_MAX may ride in the argument
+    const bool amax = (lmax_arg & GN_LMAX_MAX) != 0;
+    if (amax && ((lmax_arg & GN_LMAX_MEAN) || !ga_parts || !X_in)) return GN_ERR_BAD_ARG;   // "max": ga_parts = the [E, 1 + D, F] workspace
+    if ((lmax_arg & ~(0xff | GN_LMAX_SLICED | GN_LMAX_MEAN | GN_LMAX_MAX)) || !bwd_dim_ok(F) || N < 0 || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || lmax < 1 || lmax > 8 ||
         (ldxv & 3) || (lde & 3) || (ldqk & 3) || (ldn & 3) || g_X_out == g_X1 || act < 0 || act >= GN_ACT_COUNT)
         return GN_ERR_BAD_ARG;
     if (!X_in && (act != GN_ACT_SILU || gn_use_highl(lmax_arg))) return GN_ERR_BAD_ARG;   // zero-X_in form: register-tiled SiLU kernels only
     if (N == 0) return GN_OK;
     gn::MsgBwdArgs p{x, v, ldxv, eproj, lde, a, qk, ldqk, X_in, rl, cut, outdeg, g_h1, g_X1,
                      rowptr, src, dst, colptr, perm, g_eproj, g_s, g_nproj, ldn, g_x, g_v, g_X_out, g_rl, g_cut,
-                     N, F, H, (float)(1.0 / sqrt((double)F)), act, (lmax_arg & GN_LMAX_MEAN) ? 1 : 0};
+                     N, F, H, (float)(1.0 / sqrt((double)F)), act, (lmax_arg & GN_LMAX_MEAN) ? 1 : 0, amax ? ga_parts : nullptr};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(gn::xcd_grid(N)), block(256);
     if (gn_use_highl(lmax_arg) || act != GN_ACT_SILU) return gn_highl_message_backward(p, lmax, sep_dir, sep_tensor, st);

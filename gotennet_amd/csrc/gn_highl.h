@@ -46,6 +46,9 @@ struct MsgBwdArgs {
     float inv_sqrt_f;
     int act;                                           // GN_ACT_*: t_attn = act(W_re t + b)
     int mean;                                          // aggr = "mean" (degree-sliced kernels only): messages scaled by 1 / in-degree
+    const float* g_edge;                               // aggr = "max" (degree-sliced kernels only): [E, 1 + D, F] upstream gradient of
+                                                       // every MESSAGE (row 0: scalar, rows 1..D: tensor), routed to the arg-max
+                                                       // edges by hl_max_route_kernel; NULL: the per-target rows g_h1 / g_X1
 };
 
 // gamma_w (gotennet.py:285-291): 0 identity, 1 nn.Sigmoid ("gated"), 2 nn.Tanh ("gatedt"), 3 nn.SiLU ("act")

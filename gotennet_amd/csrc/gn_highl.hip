@@ -134,6 +134,72 @@ __device__ __forceinline__ float4 hl_gate_grad(const HlShape& S, int b, const fl
     return go;
 }
 
+// ------------------------------------------------------------------ aggr = "max": route the upstream gradient to the arg-max edges
+// The reference reduces the per-edge messages with scatter(..., reduce="max") (gotennet.py:638-639; torch amax): the
+// gradient of an output element goes to the message(s) that attain the maximum, split evenly among exact ties.  One
+// workgroup per target, one output row at a time: the messages are recomputed (same expressions as hl_msg_fwd_kernel)
+// three times -- maximum, tie count, routed write -- and the result is the [E, 1 + D, F] array of per-MESSAGE gradients
+// that the three backward kernels then read in place of the per-target rows g_h1 / g_X1.
+__global__ __launch_bounds__(256) void hl_max_route_kernel(const MsgBwdArgs p, const HlShape S, float* __restrict__ g_edge) {
+    __shared__ __attribute__((aligned(16))) float red[1024];
+    const int N = p.N, F = p.F, H = p.H, D = S.D, M = S.M;
+    const int i = xcd_item(blockIdx.x, N);
+    if (i < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    const int e0 = p.rowptr[i], e1 = p.rowptr[i + 1];
+    if (e1 == e0) return;                            // (uniform: no incoming edge, nothing to route)
+    const int per_head = (M * F) / H;
+    const size_t rowsz = (size_t)(1 + D) * F;
+    const float NEG = -INFINITY;
+    for (int r = 0; r <= D; ++r) {                   // r = 0: the scalar row; r >= 1: tensor row m = r - 1 of degree l
+        int l = 0;
+        if (r) { l = 1; while ((l + 1) * (l + 1) - 1 <= r - 1) ++l; }
+        const int bd = r ? S.dir_block(l) : 0, bt = r ? S.ten_block(l) : 0;
+        const int hd = (bd * F + c0) / per_head, ht = (bt * F + c0) / per_head;
+        auto msg = [&](int e) -> float4 {
+            const int j = p.src[e];
+            const float ce = p.cut[e];
+            const float* xr = p.x + (size_t)j * p.ldxv + c0;
+            const float* vr = p.v + (size_t)j * p.ldxv + c0;
+            const float* tr = p.eproj + (size_t)e * p.lde + F + c0;
+            const float* ar = p.a + (size_t)e * H;
+            auto gate = [&](int b, int hb) {
+                const float4 sp = (ld4(tr + b * F) * ld4(xr + b * F)) * ce;
+                return fma4(ar[hb], ld4(vr + b * F), sp);
+            };
+            if (r == 0) return gate(0, hd);
+            const float4 gd = gate(bd, hd), gt = gate(bt, ht);
+            return fma4(ld4(p.X_in + ((size_t)j * D + (r - 1)) * F + c0), gt, gd * p.rl[(size_t)e * D + (r - 1)]);
+        };
+        float4 mx = make_float4(NEG, NEG, NEG, NEG);
+        for (int e = e0 + slot; e < e1; e += ns) mx = max4(mx, msg(e));
+        st4(&red[slot * F + c0], mx);
+        __syncthreads();
+        mx = ld4(red + c0);
+        for (int k = 1; k < ns; ++k) mx = max4(mx, ld4(red + k * F + c0));
+        __syncthreads();
+        float4 cnt = zero4();
+        for (int e = e0 + slot; e < e1; e += ns) {
+            const float4 c = msg(e);
+            cnt.x += c.x == mx.x ? 1.f : 0.f; cnt.y += c.y == mx.y ? 1.f : 0.f;
+            cnt.z += c.z == mx.z ? 1.f : 0.f; cnt.w += c.w == mx.w ? 1.f : 0.f;
+        }
+        st4(&red[slot * F + c0], cnt);
+        __syncthreads();
+        cnt = red4(red, c0, F, ns);
+        __syncthreads();
+        float4 g = r ? ld4(p.g_X1 + ((size_t)i * D + (r - 1)) * F + c0) : ld4(p.g_h1 + (size_t)i * F + c0);
+        g.x = cnt.x > 0.f ? g.x / cnt.x : 0.f; g.y = cnt.y > 0.f ? g.y / cnt.y : 0.f;
+        g.z = cnt.z > 0.f ? g.z / cnt.z : 0.f; g.w = cnt.w > 0.f ? g.w / cnt.w : 0.f;
+        for (int e = e0 + slot; e < e1; e += ns) {
+            const float4 c = msg(e);
+            st4(g_edge + (size_t)e * rowsz + (size_t)r * F + c0,
+                make_float4(c.x == mx.x ? g.x : 0.f, c.y == mx.y ? g.y : 0.f, c.z == mx.z ? g.z : 0.f, c.w == mx.w ? g.w : 0.f));
+        }
+    }
+}
+
 // ------------------------------------------------------------------ message backward, by target (all degrees, one launch)
 // per edge: g_tf, g_cut, g_rl, head sums of g_a; then softmax backward and the score gradients (g_ta, g_q)
 __global__ __launch_bounds__(256) void hl_msg_bwd_target_kernel(const MsgBwdArgs p, const HlShape S) {
@@ -148,12 +214,16 @@ __global__ __launch_bounds__(256) void hl_msg_bwd_target_kernel(const MsgBwdArgs
     const int per_head = (M * F) / H;
     // aggr = "mean": every message of this target carries 1 / in-degree (the residual paths do not)
     const float inv = p.mean ? 1.0f / (float)(e1 > e0 ? e1 - e0 : 1) : 1.0f;
-    const float4 gdh = ld4(p.g_h1 + (size_t)i * F + c0) * inv;
-    const float* gXi = p.g_X1 + (size_t)i * D * F + c0;
+    const float4 gdh_t = ld4(p.g_h1 + (size_t)i * F + c0) * inv;
+    const float* gXi_t = p.g_X1 + (size_t)i * D * F + c0;
 
     for (int e = e0 + slot; e < e1; e += ns) {
         const int j = p.src[e];
         const float ce = p.cut[e];
+        // aggr = "max": this edge's own routed gradient rows instead of the target's
+        const float* ge = p.g_edge ? p.g_edge + (size_t)e * (1 + D) * F + c0 : nullptr;
+        const float4 gdh = ge ? ld4(ge) : gdh_t;
+        const float* gXi = ge ? ge + F : gXi_t;
         const float* xr = p.x + (size_t)j * p.ldxv + c0;
         const float* vr = p.v + (size_t)j * p.ldxv + c0;
         const float* tr = p.eproj + (size_t)e * p.lde + F + c0;
@@ -242,8 +312,9 @@ __global__ __launch_bounds__(256) void hl_msg_bwd_source_gates_kernel(const MsgB
             const float ce = p.cut[e];
             const float4 tfb = ld4_nt(p.eproj + (size_t)e * p.lde + F + c0 + b * F);
             const float ab = p.a[(size_t)e * H + hb];
-            float4 go = b == 0 ? ld4(p.g_h1 + (size_t)i * F + c0)
-                               : hl_gate_grad(S, b, p.g_X1 + (size_t)i * D * F + c0, Xj, p.rl + (size_t)e * D, F);
+            const float* ge = p.g_edge ? p.g_edge + (size_t)e * (1 + D) * F + c0 : nullptr;     // aggr = "max": routed rows
+            float4 go = b == 0 ? ld4(ge ? ge : p.g_h1 + (size_t)i * F + c0)
+                               : hl_gate_grad(S, b, ge ? ge + F : p.g_X1 + (size_t)i * D * F + c0, Xj, p.rl + (size_t)e * D, F);
             if (p.mean) go = go * (1.0f / (float)(p.rowptr[i + 1] - p.rowptr[i]));      // (edge e exists: in-degree >= 1)
             acc[0] = fma4(go, tfb * ce, acc[0]);
             acc[1] = fma4(ab, go, acc[1]);
@@ -287,7 +358,7 @@ __global__ __launch_bounds__(256) void hl_msg_bwd_source_X_kernel(const MsgBwdAr
         const float4 tfb = ld4_nt(p.eproj + (size_t)e * p.lde + F + c0 + b * F);
         const float4 ot = fma4(p.a[(size_t)e * H + hb], ld4(p.v + (size_t)j * p.ldxv + b * F + c0),
                                (tfb * ld4(p.x + (size_t)j * p.ldxv + b * F + c0)) * p.cut[e]);   // forward tensor gate
-        const float* gXi = p.g_X1 + ((size_t)i * D + M0) * F + c0;
+        const float* gXi = p.g_edge ? p.g_edge + ((size_t)e * (1 + D) + 1 + M0) * F + c0 : p.g_X1 + ((size_t)i * D + M0) * F + c0;
         const float4 otm = p.mean ? ot * (1.0f / (float)(p.rowptr[i + 1] - p.rowptr[i])) : ot;
 #pragma unroll
         for (int mm = 0; mm < ROWS; ++mm) acc[mm] = fma4(ld4(gXi + (size_t)mm * F), otm, acc[mm]);
@@ -498,6 +569,8 @@ int gn_highl_message_backward(const gn::MsgBwdArgs& p, int lmax, int sep_dir, in
     if (lmax < 1 || lmax > 8) return GN_ERR_BAD_ARG;
     const gn::HlShape S(lmax, sep_dir, sep_tensor);
     const dim3 grid(gn::xcd_grid(p.N)), block(256);
+    if (p.g_edge)                                    // aggr = "max": per-message gradients first (p.g_edge is the caller's workspace)
+        hipLaunchKernelGGL(gn::hl_max_route_kernel, grid, block, 0, st, p, S, const_cast<float*>(p.g_edge));
     hipLaunchKernelGGL(gn::hl_msg_bwd_target_kernel, grid, block, 0, st, p, S);      // g_s first: the source pass reads it
     hipLaunchKernelGGL(gn::hl_msg_bwd_source_gates_kernel, grid, block, 0, st, p, S);
     GN_HL_PER_DEGREE(hl_msg_bwd_source_X_kernel, p, S);

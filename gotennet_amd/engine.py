@@ -136,7 +136,7 @@ class Config:
     emlp: int = 0             # emlp_dim: hidden width of the 2-layer gamma_t (0 = F)
     gemm_mode: str = ""       # projection arithmetic of THIS model ("f16x2" | "split" | "f32"; "" = engine.GEMM_MODE, the default)
     sliced: bool = False      # run lmax <= 4 on the degree-sliced kernel family too (GN_LMAX_SLICED in the lmax argument)
-    aggr: int = 0             # the reference's `aggr` (gotennet.py:84,638): 0 "add", 1 "mean", 2 "max" (forward only)
+    aggr: int = 0             # the reference's `aggr` (gotennet.py:84,638): 0 "add", 1 "mean", 2 "max"
     Fc: int = 0               # width of the NodeInit LayerNorm intermediate when the model is embedded in a power-of-two F (embed.py; 0 = F)
     F_model: int = 0          # the model's real n_atom_basis when embedded (0 = F)
     fuse_eqff: Optional[bool] = None   # the node-local EQFF chain as ONE kernel each way where covered (eqff_fused_ok).  None =
@@ -389,8 +389,10 @@ class Tape:
 
 def check_backward_supported(cfg: Config) -> None:
     """Raise NotImplementedError -- BEFORE any launch -- for the configurations whose force path does not exist."""
-    if cfg.aggr == 2:
-        raise NotImplementedError("aggr='max': the message stage has a forward kernel only (no input-gradient / forces)")
+    if cfg.F > 256 or cfg.Fe > 256:
+        what = f"n_atom_basis={cfg.F_model} (runs embedded in width {cfg.F})" if cfg.F_model else f"n_atom_basis={cfg.F}"
+        raise NotImplementedError(f"{what}: the input-gradient kernels tile one edge row over at most 64 lanes x 4 channels "
+                                  "(width <= 256); wider models run forward only")
 
 
 def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: bool = False,
@@ -749,6 +751,8 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
     n_rl, n_cut = L + sum(lw.Wt is not None for lw in pw.layers), G * L + 1
     g_rl_parts, g_cut_parts = new(n_rl, E, D), new(n_cut, E)
     ga_parts = new(G, E, H) if G > 1 else None
+    if cfg.aggr == 2:                              # aggr = "max": the per-message gradient workspace of the routing kernel
+        ga_parts = new(E, 1 + D, F_)
     rl_slice = lambda q: g_rl_parts.data_ptr() + 4 * q * E * D
     cut_slice = lambda q: g_cut_parts.data_ptr() + 4 * q * E
     if pw.emb_idx is not None:                     # embedded model: gradients arrive in the real layout

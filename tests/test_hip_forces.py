@@ -375,9 +375,11 @@ def test_forces_high_degree_cluster():
     assert float(f.sum(0).abs().max()) < 1e-3 * float(f.abs().max())
 
 
-def test_aggr_max_is_forward_only():
-    """aggr='max' (gotennet.py:84,638) runs the message stage forward (fixture opt_aggr_max_l3 in test_hip_parity) and refuses
-    the force path before any backward launch."""
+def test_aggr_max_forces_match_reference():
+    """aggr='max' (gotennet.py:84,638-639): the element-wise maximum over the incoming messages, and its input-gradient -- the
+    upstream gradient of every output element routed to the arg-max edge (hl_max_route_kernel) -- against the reference's
+    energies and forces (fixture opt_aggr_max_l3) and the oracle on a second system; bit-reproducible."""
+    from oracle import gotennet_oracle as orc
     from gotennet_amd.pipeline import EnergyForces
     cfg, sd, head_sd, t = load_case("opt_aggr_max_l3")
     net, head = _net_from_case(cfg, sd), _head_from_case(cfg, head_sd)
@@ -385,5 +387,15 @@ def test_aggr_max_is_forward_only():
     args = [t[k].cuda() for k in ("z", "edge_index", "edge_diff", "edge_vec", "batch")] + [cfg["n_mol"]]
     e, _ = EnergyForces(net, head)(*args, forces=False)
     assert rel_err(e.cpu(), t["energy"]) < 1e-4
-    with pytest.raises(NotImplementedError):
-        EnergyForces(net, head)(*args)
+    e, f = EnergyForces(net, head)(*args)
+    assert rel_err(e.cpu(), t["energy"]) < 1e-4 and rel_err(f.cpu(), t["forces"]) < TOL
+    e2, f2 = EnergyForces(net, head)(*args)
+    assert torch.equal(e, e2) and torch.equal(f, f2)
+    # another geometry of the same model, against the oracle's autograd through scatter_reduce(amax)
+    g = torch.Generator().manual_seed(4)
+    pos = t["pos"] + 0.05 * torch.randn(t["pos"].shape, generator=g)
+    e_ref, f_ref, _ = orc.energy_and_forces(sd, cfg, head_sd, t["z"], pos, t["batch"], cfg["n_mol"])
+    from gotennet_amd.graph import distance
+    ei, w, vec = distance(pos.cuda(), t["batch"].cuda(), cfg["cutoff"], 32)
+    e, f = EnergyForces(net, head)(t["z"].cuda(), ei, w, vec, t["batch"].cuda(), cfg["n_mol"])
+    assert rel_err(e.cpu(), e_ref) < 1e-4 and rel_err(f.cpu(), f_ref) < TOL
