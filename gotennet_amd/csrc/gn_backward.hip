@@ -859,8 +859,7 @@ __global__ __launch_bounds__(256) void node_init_bwd_kernel(
             gc = hsum4(ga * ld4(feat + (size_t)e * ldf + c0));
         }
         st4(g_feat + (size_t)e * ldf + c0, gfn);
-        gc = group_sum(gc, lps);
-        if (lp == 0) g_cut[e] = gc;
+        slot_sum_store(gc, lps, lp, g_cut + e, (size_t)rowptr[N]);       // (F > 256: one partial slice per 64-lane part)
     }
 }
 
@@ -1076,6 +1075,9 @@ __global__ void head_grad_kernel(const float* __restrict__ pre1, const float* __
 
 // ====================================================================================== C ABI
 static bool bwd_dim_ok(int F) { return F >= 16 && F <= 256 && gn::is_pow2(F); }
+// F = 512 / 1024 (a slot spans 2 / 4 waves): the degree-sliced kernels and the init kernels only; the per-edge scalar
+// gradients then come as F / 256 partial slices per call (gn_common.h slot_sum_store)
+static bool bwd_dim_ok_wide(int F) { return F >= 16 && F <= 1024 && gn::is_pow2(F); }
 
 #define GN_SWITCH_LMAX(KERNEL, grid, block, st, ...)                                                   \
     switch (lmax) {                                                                                    \
@@ -1103,12 +1105,12 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
                                const int* colptr, const int* perm, int N, int F, int lmax_arg, int mode,
                                float* gEQ, float* gEK, float* g_rl, float* g_pre_t, int act, void* stream) {
     const int lmax = lmax_arg & 0xff;               // GN_LMAX_SLICED may ride in the argument (gn_use_highl)
-    if ((lmax_arg & ~(0xff | GN_LMAX_SLICED)) || !bwd_dim_ok(F) || N < 0 || lmax < 1 || lmax > 8 || mode < 0 || mode > 31 ||
+    if ((lmax_arg & ~(0xff | GN_LMAX_SLICED)) || !bwd_dim_ok_wide(F) || N < 0 || lmax < 1 || lmax > 8 || mode < 0 || mode > 31 ||
         act < 0 || act >= GN_ACT_COUNT)
         return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (gn_use_highl(lmax_arg) || (!mode && act != GN_ACT_SILU))
+    if (gn_use_highl(lmax_arg) || F > 256 || (!mode && act != GN_ACT_SILU))      // (F > 256: g_rl comes as F / 256 partial slices)
         return gn_highl_htr_backward(g_t_out, pre_t, w, w_raw, EQ, EK, rl, rowptr, src, dst, colptr, perm, N, F, lmax,
                                      mode, gEQ, gEK, g_rl, g_pre_t, act, st);
     if (mode)
@@ -1167,17 +1169,18 @@ extern "C" int gn_message_backward(
     const int lmax = lmax_arg & 0xff;               // GN_LMAX_SLICED / GN_LMAX_MEAN / GN_LMAX_MAX may ride in the argument
     const bool amax = (lmax_arg & GN_LMAX_MAX) != 0;
     if (amax && ((lmax_arg & GN_LMAX_MEAN) || !ga_parts || !X_in)) return GN_ERR_BAD_ARG;   // "max": ga_parts = the [E, 1 + D, F] workspace
-    if ((lmax_arg & ~(0xff | GN_LMAX_SLICED | GN_LMAX_MEAN | GN_LMAX_MAX)) || !bwd_dim_ok(F) || N < 0 || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || lmax < 1 || lmax > 8 ||
+    if ((lmax_arg & ~(0xff | GN_LMAX_SLICED | GN_LMAX_MEAN | GN_LMAX_MAX)) || !bwd_dim_ok_wide(F) || N < 0 || H <= 0 || !gn::is_pow2(H) || (F / 4) % H || (F / 4) / H > 64 || lmax < 1 || lmax > 8 ||
         (ldxv & 3) || (lde & 3) || (ldqk & 3) || (ldn & 3) || g_X_out == g_X1 || act < 0 || act >= GN_ACT_COUNT)
         return GN_ERR_BAD_ARG;
-    if (!X_in && (act != GN_ACT_SILU || gn_use_highl(lmax_arg))) return GN_ERR_BAD_ARG;   // zero-X_in form: register-tiled SiLU kernels only
+    if (!X_in && (act != GN_ACT_SILU || gn_use_highl(lmax_arg) || F > 256)) return GN_ERR_BAD_ARG;   // zero-X_in form: register-tiled SiLU kernels only
     if (N == 0) return GN_OK;
     gn::MsgBwdArgs p{x, v, ldxv, eproj, lde, a, qk, ldqk, X_in, rl, cut, outdeg, g_h1, g_X1,
                      rowptr, src, dst, colptr, perm, g_eproj, g_s, g_nproj, ldn, g_x, g_v, g_X_out, g_rl, g_cut,
                      N, F, H, (float)(1.0 / sqrt((double)F)), act, (lmax_arg & GN_LMAX_MEAN) ? 1 : 0, amax ? ga_parts : nullptr};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(gn::xcd_grid(N)), block(256);
-    if (gn_use_highl(lmax_arg) || act != GN_ACT_SILU) return gn_highl_message_backward(p, lmax, sep_dir, sep_tensor, st);
+    // (F > 256: the degree-sliced kernels; g_rl / g_cut come as F / 256 partial slices, the caller sized them so)
+    if (gn_use_highl(lmax_arg) || F > 256 || act != GN_ACT_SILU) return gn_highl_message_backward(p, lmax, sep_dir, sep_tensor, st);
     if (X_in && gn_message_backward_groups(lmax_arg, sep_dir, sep_tensor, act) > 1) {
         // degree groups: target passes (head sums and cut slices per group) -> attention backward -> source passes
         if (ga_parts == nullptr || E <= 0) return GN_ERR_BAD_ARG;
@@ -1246,7 +1249,7 @@ extern "C" int gn_eqff_backward_b(const float* g_ctx, const float* ctx, const fl
 extern "C" int gn_edge_init_backward(const float* g_t0, const float* h, const float* feat, int ldf,
                                      const int* rowptr, const int* src, const int* colptr, const int* perm,
                                      int N, int F, float* g_feat, float* g_h, void* stream) {
-    if (!bwd_dim_ok(F) || N < 0 || (ldf & 3)) return GN_ERR_BAD_ARG;
+    if (!bwd_dim_ok_wide(F) || N < 0 || (ldf & 3)) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipLaunchKernelGGL(gn::edge_init_bwd_kernel, dim3(gn::xcd_grid(N)), dim3(256), 0, (hipStream_t)stream,
                        g_t0, h, feat, ldf, rowptr, src, colptr, perm, N, F, g_feat, g_h);
@@ -1257,7 +1260,7 @@ extern "C" int gn_edge_init_backward(const float* g_t0, const float* h, const fl
 extern "C" int gn_node_init_backward(const float* g_ctx, const int* z, const float* feat, int ldf, const float* cut,
                                      const float* A_nbr, const int* rowptr, const int* src, int N, int F,
                                      float* g_feat, float* g_cut, void* stream) {
-    if (!bwd_dim_ok(F) || N < 0 || (ldf & 3)) return GN_ERR_BAD_ARG;
+    if (!bwd_dim_ok_wide(F) || N < 0 || (ldf & 3)) return GN_ERR_BAD_ARG;
     if (N == 0) return GN_OK;
     hipLaunchKernelGGL(gn::node_init_bwd_kernel, dim3(gn::xcd_grid(N)), dim3(256), 0, (hipStream_t)stream,
                        g_ctx, z, feat, ldf, cut, A_nbr, rowptr, src, N, F, g_feat, g_cut);

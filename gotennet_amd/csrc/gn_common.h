@@ -137,6 +137,16 @@ __device__ __forceinline__ float group_sum(float v, int width) {
     for (int o = 1; o < width; o <<= 1) v += __shfl_xor(v, o, GN_WAVE);
     return v;
 }
+// Sum over the lanes of a slot and store, for slots that may be WIDER than a wave (F = 512 / 1024: 128 / 256 lanes per
+// edge): every 64-lane part of the slot stores its own partial into slice `lp / 64` of the output (slices are `stride`
+// floats apart).  Used for the per-edge scalar gradients (g_rl, g_cut), which are written as slices and added in a fixed
+// order by gn_edge_geometry_backward anyway -- no cross-wave reduction, no barrier inside the ragged edge loops.
+__device__ __forceinline__ void slot_sum_store(float v, int lps, int lp, float* out, size_t stride, bool valid = true) {
+    const int w = lps < GN_WAVE ? lps : GN_WAVE;
+    const float s = group_sum(v, w);
+    if (valid && (lp & (w - 1)) == 0) out[(size_t)(lp >> 6) * stride] = s;
+}
+
 // Sum K values (K a power of two, K <= width) over aligned groups of `width` lanes with a
 // value-halving butterfly: ~K + log2(width) shuffles instead of K log2(width).  On return the lane
 // whose in-group index lp satisfies lp % (width / K) == 0 holds the total of value lp / (width / K) in v[0].

@@ -217,7 +217,16 @@ __global__ __launch_bounds__(256) void hl_msg_bwd_target_kernel(const MsgBwdArgs
     const float4 gdh_t = ld4(p.g_h1 + (size_t)i * F + c0) * inv;
     const float* gXi_t = p.g_X1 + (size_t)i * D * F + c0;
 
-    for (int e = e0 + slot; e < e1; e += ns) {
+    // Slots wider than a wave (F = 512 / 1024): the per-edge scalars go out as one partial slice per 64-lane part
+    // (slot_sum_store), and the head-sum staging row is shared by the slot's waves, so every slot runs the same number of
+    // trips (a slot past the end repeats the last edge without storing) and two barriers fence the row.
+    const bool wide = lps > GN_WAVE;
+    const size_t E_all = (size_t)p.rowptr[N];
+    const int trips = (e1 - e0 + ns - 1) / ns;
+    for (int it = 0; it < trips; ++it) {
+        const int e_raw = e0 + it * ns + slot;
+        const bool valid = e_raw < e1;
+        const int e = valid ? e_raw : e1 - 1;
         const int j = p.src[e];
         const float ce = p.cut[e];
         // aggr = "max": this edge's own routed gradient rows instead of the target's
@@ -236,29 +245,29 @@ __global__ __launch_bounds__(256) void hl_msg_bwd_target_kernel(const MsgBwdArgs
         for (int b = 0; b < M; ++b) {
             const float4 go = b == 0 ? gdh : hl_gate_grad(S, b, gXi, Xj, re, F) * inv;
             const float4 tfb = ld4_nt(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
-            st4_nt(gtr + b * F, (go * xb) * ce);
+            if (valid) st4_nt(gtr + b * F, (go * xb) * ce);
             cutp += hsum4(go * tfb * xb);
             hrow[b * lps + lp] = hsum4(go * vb);
             if (S.is_dir(b)) {
                 const float4 od = fma4(ar[(b * F + c0) / per_head], vb, (tfb * xb) * ce);      // forward direction gate
                 const int m_lo = S.lo(b) * S.lo(b) - 1, m_hi = (S.hi(b) + 1) * (S.hi(b) + 1) - 1;
                 for (int m = m_lo; m < m_hi; ++m) {
-                    const float s = group_sum(hsum4(ld4(gXi + (size_t)m * F) * od), lps) * inv;
-                    if (lp == 0) p.g_rl[(size_t)e * D + m] = s;
+                    slot_sum_store(hsum4(ld4(gXi + (size_t)m * F) * od) * inv, lps, lp, p.g_rl + (size_t)e * D + m, E_all * D, valid);
                 }
             }
         }
-        cutp = group_sum(cutp, lps);
-        if (lp == 0) p.g_cut[e] = cutp;
-        // head sums (same staging as msg_bwd_target_body: a slot never spans waves, wave-ordered LDS accesses)
+        slot_sum_store(cutp, lps, lp, p.g_cut + e, E_all, valid);
+        // head sums (same staging as msg_bwd_target_body; a slot within one wave: wave-ordered LDS accesses, no barrier)
+        if (wide) __syncthreads();
         {
             const int rpl = lps / H, hh = lp / rpl, part = lp - hh * rpl;
             const float* hp = hrow + hh * (M * rpl) + part * M;
             float hv = hp[0];
             for (int k = 1; k < M; ++k) hv += hp[k];
             hv = group_sum(hv, rpl);
-            if (part == 0) p.g_s[(size_t)e * H + hh] = hv;
+            if (valid && part == 0) p.g_s[(size_t)e * H + hh] = hv;
         }
+        if (wide) __syncthreads();
     }
     __syncthreads();
     // softmax backward per head:  g_s = a g_a - (a / nrm) sum_e' a g_a
@@ -469,8 +478,7 @@ __global__ __launch_bounds__(256) void hl_htr_bwd_target_kernel(
             const float r = re[m];
             acc[mm] = fma4(gw, ek + pb * (-c * r), acc[mm]);
             const float4 t4 = gw * ((eq * pb + pa * ek) * (-c) + papb * (rej ? 2.0f * r : 0.0f));
-            const float s = group_sum(hsum4(t4), lps);
-            if (lp == 0) g_rl[(size_t)e * D + m] = s;
+            slot_sum_store(hsum4(t4), lps, lp, g_rl + (size_t)e * D + m, (size_t)rowptr[N] * D);
         }
     }
     reduce_rows<ROWS>(acc, red, slot, c0, F, ns,

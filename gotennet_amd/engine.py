@@ -71,7 +71,8 @@ def zero_X_in(cfg: "Config", li: int) -> bool:
     """Layer ``li`` of ``forward`` sees the all-zero X that forward itself creates (gotennet.py:992) and the kernels have
     the zero-X_in form (register-tiled SiLU kernels, lmax <= 4): every tensor-gate term of that layer is 0 * gate, so its
     blocks of the edge projection are neither computed nor read, and nothing consumes the gradient w.r.t. X_in."""
-    return ZERO_X_FIRST and li == 0 and cfg.lmax <= 4 and cfg.act == 0 and not cfg.steerable_norm and not cfg.sliced and cfg.aggr == 0
+    return (ZERO_X_FIRST and li == 0 and cfg.lmax <= 4 and cfg.act == 0 and not cfg.steerable_norm and not cfg.sliced
+            and cfg.aggr == 0 and not cfg.wide)
 
 
 def _We_first(cfg: "Config", lw) -> Tuple[torch.Tensor, torch.Tensor, int]:
@@ -159,6 +160,21 @@ class Config:
     def lmax_arg(self) -> int:
         """The ``lmax`` argument of the message / HTR entry points: GN_LMAX_SLICED rides in it."""
         return self.lmax | (_lib.LMAX_SLICED if self.sliced else 0)
+
+    @property
+    def wide(self) -> bool:
+        """A slot (one edge row, F / 4 lanes) spans several waves: the input-gradient kernels are the degree-sliced family
+        and the per-edge scalar gradients come as F / 256 partial slices per call."""
+        return self.F > 256 or self.Fe > 256
+
+    @property
+    def lmax_arg_bwd(self) -> int:
+        """... of the BACKWARD entry points: F > 256 runs the degree-sliced kernels there."""
+        return self.lmax_arg | (_lib.LMAX_SLICED if self.wide else 0)
+
+    @property
+    def lmax_arg_msg_bwd(self) -> int:
+        return self.lmax_arg_msg | (_lib.LMAX_SLICED if self.wide else 0)
 
     @property
     def lmax_arg_msg(self) -> int:
@@ -389,10 +405,9 @@ class Tape:
 
 def check_backward_supported(cfg: Config) -> None:
     """Raise NotImplementedError -- BEFORE any launch -- for the configurations whose force path does not exist."""
-    if cfg.F > 256 or cfg.Fe > 256:
-        what = f"n_atom_basis={cfg.F_model} (runs embedded in width {cfg.F})" if cfg.F_model else f"n_atom_basis={cfg.F}"
-        raise NotImplementedError(f"{what}: the input-gradient kernels tile one edge row over at most 64 lanes x 4 channels "
-                                  "(width <= 256); wider models run forward only")
+    if cfg.wide and (cfg.F // 4) // cfg.H > 64:
+        raise NotImplementedError(f"n_atom_basis={cfg.F_model or cfg.F} with {cfg.H} heads: the input-gradient kernels keep one "
+                                  "attention head inside one wave (at most 256 channels per head)")
 
 
 def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, save: bool = False,
@@ -747,14 +762,21 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
 
     # every contributing kernel writes its own slice; the geometry backward sums them in a fixed order
     L = len(pw.layers)
-    G = _lib.load().gn_message_backward_groups(cfg.lmax_arg_msg, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act)
-    n_rl, n_cut = L + sum(lw.Wt is not None for lw in pw.layers), G * L + 1
+    G = _lib.load().gn_message_backward_groups(cfg.lmax_arg_msg_bwd, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act)
+    # W: partial slices per writing call (a slot wider than a wave writes one per 64-lane part: F / 256, Fe / 256 for HTR)
+    Wm, Wh = max(1, F_ // 256), max(1, Fe // 256)
+    n_htr = sum(lw.Wt is not None for lw in pw.layers)
+    n_rl, n_cut = Wm * L + Wh * n_htr, Wm * (G * L + 1)
     g_rl_parts, g_cut_parts = new(n_rl, E, D), new(n_cut, E)
     ga_parts = new(G, E, H) if G > 1 else None
     if cfg.aggr == 2:                              # aggr = "max": the per-message gradient workspace of the routing kernel
         ga_parts = new(E, 1 + D, F_)
     rl_slice = lambda q: g_rl_parts.data_ptr() + 4 * q * E * D
     cut_slice = lambda q: g_cut_parts.data_ptr() + 4 * q * E
+    htr_slice = {}                                 # layer -> first g_rl slice of its HTR backward (after the message slices)
+    for li_, lw_ in enumerate(pw.layers):
+        if lw_.Wt is not None:
+            htr_slice[li_] = Wm * L + Wh * len(htr_slice)
     if pw.emb_idx is not None:                     # embedded model: gradients arrive in the real layout
         z_ = torch.zeros((N, F_), **f32)
         gh = z_.index_copy_(1, pw.emb_idx, gh.contiguous())
@@ -792,13 +814,13 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
             if cfg.composed_update:                # gt_a = gt + gamma_t backward; g_w = gamma_w backward
                 g_w = _edge_update_composed_backward(cfg, lw, lt, gt, gt_a, E)
                 call("gn_htr_backward", ptr(g_w), None, None, None, ptr(lt.EQ), ptr(lt.EK), ptr(g.rl),
-                     ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm), N, Fe, cfg.lmax_arg, cfg.htr_mode | 16,
-                     ptr(gEQ), ptr(gEK), rl_slice(L + li), None, cfg.act, _stream())
+                     ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm), N, Fe, cfg.lmax_arg_bwd, cfg.htr_mode | 16,
+                     ptr(gEQ), ptr(gEK), rl_slice(htr_slice[li]), None, cfg.act, _stream())
                 gemm_group([m1])
             else:
                 call("gn_htr_backward", ptr(gt), ptr(lt.pre_t), ptr(lt.w), ptr(lt.w_raw), ptr(lt.EQ), ptr(lt.EK),
-                     ptr(g.rl), ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm), N, Fe, cfg.lmax_arg,
-                     cfg.htr_mode, ptr(gEQ), ptr(gEK), rl_slice(L + li), ptr(g_pre_t), cfg.act, _stream())
+                     ptr(g.rl), ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm), N, Fe, cfg.lmax_arg_bwd,
+                     cfg.htr_mode, ptr(gEQ), ptr(gEK), rl_slice(htr_slice[li]), ptr(g_pre_t), cfg.act, _stream())
                 # gt_a = gt + ((gt * w) * SiLU'(pre_t)) Wt; the atom-sized gamma_m product rides in its launch
                 gemm_group([dict(A=g_pre_t, lda=F_, W=_T(lw, "Wt"), C=gt_a, ldc=F_, rows=E, nout=F_, K=F_, res=gt), m1])
             gt_in = gt_a
@@ -844,14 +866,14 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
                     break
         # ---- message backward
         if first and G > 1:                        # one launch instead of G degree groups: one g_cut slice is written
-            g_cut_parts[G * li + 1:G * li + G].zero_()
+            g_cut_parts[G * li + 1:G * li + G].zero_()       # (never together with wide slots: zero_X_in excludes them)
         call("gn_message_backward", ptr(lt.xs), ptr(lt.vs), M * F_, ptr(lt.eproj), lde, ptr(lt.attn),
              ptr(lt.nproj), 4 * F_, None if first else ptr(lt.X_in), ptr(g.rl), ptr(g.cut), ptr(g.outdeg),
              ptr(gh1), ptr(gX1), ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm),
              ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), None if first else ptr(gX2),
-             rl_slice(li), cut_slice(G * li),
+             rl_slice(Wm * li), cut_slice(Wm * G * li),
              ptr(ga_parts), E,
-             N, F_, H, cfg.lmax_arg_msg, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act, _stream())
+             N, F_, H, cfg.lmax_arg_msg_bwd, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act, _stream())
         # the edge-sized W_e^T product leaves 0.7 of its last tile round idle: the two K-heavy atom-sized products
         # (g_x W_s2, g_v W_v2; 60 us as a launch of their own) ride there; W_n1^T needs their output and follows alone
         if first:                                  # the tensor-gate columns of g_eproj were not written: K-prefix
@@ -894,7 +916,7 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
     call("gn_layernorm_silu_backward", ptr(tape.y_pre), ptr(pw.ln_w), ptr(pw.ln_b), 1e-5, ptr(gy), N, Fc, ptr(gy1), cfg.act, _stream())
     gemm(gy1, Fc, _T(pw, "Wa"), None, g_ctx, 2 * F_, N, 2 * F_, Fc)
     call("gn_node_init_backward", ptr(g_ctx), ptr(z32), ptr(tape.feat), 2 * F_, ptr(g.cut), ptr(pw.A_nbr),
-         ptr(g.rowptr), ptr(g.src), N, F_, ptr(g_feat), cut_slice(G * L), _stream())
+         ptr(g.rowptr), ptr(g.src), N, F_, ptr(g_feat), cut_slice(Wm * G * L), _stream())
     g_phi = new(E, R)
     gemm(g_feat, 2 * F_, _T(pw, "Winit"), None, g_phi, R, E, R, 2 * F_)
     g_vec, g_diff = new(E, 3), new(E)

@@ -82,7 +82,8 @@ def test_edge_level_autograd_boundary(name):
     assert rel_err(gd.cpu()[mask], gd_ref[mask]) < TOL
 
 
-@pytest.mark.parametrize("F,L,lmax", [(128, 2, 2), (256, 2, 2), (64, 2, 4), (64, 3, 3), (256, 2, 3), (256, 2, 4)])
+@pytest.mark.parametrize("F,L,lmax", [(128, 2, 2), (256, 2, 2), (64, 2, 4), (64, 3, 3), (256, 2, 3), (256, 2, 4),
+                                      (512, 2, 2), (512, 2, 3), (1024, 2, 1)])      # (> 256: a slot spans 2 / 4 waves)
 def test_forces_match_oracle_wide(F, L, lmax):
     import gotennet_amd
     from gotennet_amd.graph import distance

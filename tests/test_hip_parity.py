@@ -534,8 +534,8 @@ def test_softmax_beyond_the_lds_capacity():
 def test_feature_width_not_a_power_of_two(F, H, lmax):
     """n_atom_basis that is not a power of two (the reference takes any multiple of num_heads, gotennet.py:767-793) runs
     embedded in the next power-of-two width (gotennet_amd/embed.py: zero-padded weights, channels placed head by head, the
-    attention scale folded into gamma_v, the NodeInit LayerNorm kept compact): (h, X) against the oracle, and -- where the
-    padded width has a force path (<= 256) -- energies and forces."""
+    attention scale folded into gamma_v, the NodeInit LayerNorm kept compact): (h, X) against the oracle, and
+    energies and forces (384 runs as 512: slots wider than a wave)."""
     import gotennet_amd
     from oracle import gotennet_oracle as orc
     from gotennet_amd.outputs import Atomwise
@@ -559,8 +559,6 @@ def test_feature_width_not_a_power_of_two(F, H, lmax):
     h, X = net(z.cuda(), ei.cuda(), w.cuda(), vec.cuda())
     assert h.shape == (39, F) and X.shape == (39, (lmax + 1) ** 2 - 1, F)
     assert rel_err(h.cpu(), h_ref) < TOL and rel_err(X.cpu(), X_ref) < TOL
-    if c.F > 256:
-        return                                                    # (the padded width has no force path yet: forward only)
     head = Atomwise(n_in=F, n_hidden=32, derivative="forces", activation="silu")
     hsd = {k: v.clone() for k, v in head.state_dict().items()}
     e_ref, f_ref, _ = orc.energy_and_forces(sd, cfg, hsd, z, pos, batch, 3)
