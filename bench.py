@@ -144,7 +144,8 @@ def compact_line(full):
     ``full`` is the complete record (what round 3 printed); it is written to a side file by ``emit``."""
     out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                 "scaling", "vs_baseline", "dtype", "data", "config", "n_ranks_seen", "energy_vector_len",
-                                "energy_checksum", "rank_ms_per_step", "launch_mode") if k in full and full[k] is not None}
+                                "energy_checksum", "rank_ms_per_step", "launch_mode")
+           if k in full and not (k == "rank_ms_per_step" and full[k] is None)}
     out["roofline"] = _roof_compact(full.get("roofline"))
     if out["roofline"] is not None:
         live = str((full.get("roofline") or {}).get("traffic_source", "")).startswith("measured in this run")

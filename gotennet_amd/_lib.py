@@ -35,6 +35,8 @@ SIGNATURES = {
     "gn_abi_version": [C.POINTER(C.c_char_p)],
     "gn_build_csr": [_P, _I, _I, _P, _P, _P, _P],
     "gn_check_edges": [_P, _I, _I, _P, _P],
+    "gn_build_csc": [_P, _P, _I, _I, _P, _P, _P, _P, _P],
+    "gn_molecule_ptr": [_P, _I, _I, _P, _P],
     "gn_cosine_cutoff": [_P, _I, _F, _P, _P],
     "gn_out_degree": [_P, _I, _P, _P],
     "gn_edge_geometry": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P],

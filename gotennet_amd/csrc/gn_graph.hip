@@ -69,7 +69,97 @@ __global__ void edge_vectors_kernel(const float* __restrict__ pos, const int* __
     edge_diff[e] = (j == i) ? 0.0f : sqrtf(vx * vx + vy * vy + vz * vz);
 }
 
+// ---- by-source (CSC) view of a target-major edge list, stable: perm lists the CSR edge ids of every source in increasing
+// order (= what torch.sort(src, stable=True) gives), without a sort: count -> scan -> scatter (integer atomics: the ORDER
+// inside a bucket is arbitrary at this point, its CONTENT is not) -> rank every bucket entry among its bucket's ids.
+__global__ void csc_count_kernel(const int* __restrict__ src, int E, int* __restrict__ cnt) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) atomicAdd(cnt + src[e], 1);
+}
+// one workgroup: colptr = exclusive scan of cnt (N + 1 entries), cursor = a copy of colptr[0..N) for the scatter
+__global__ __launch_bounds__(1024) void csc_scan_kernel(const int* __restrict__ cnt, int N, int* __restrict__ colptr,
+                                                        int* __restrict__ cursor) {
+    __shared__ int part[16];
+    __shared__ int carry;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < N; base += 1024) {
+        const int n = base + t;
+        const int v = n < N ? cnt[n] : 0;
+        int incl = v;                                            // inclusive scan inside the wave
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) part[wave] = incl;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; ++w) before += part[w];
+        if (n < N) {
+            colptr[n] = before + incl - v;
+            cursor[n] = before + incl - v;
+        }
+        __syncthreads();
+        if (t == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (t == 0) colptr[N] = carry;
+}
+__global__ void csc_scatter_kernel(const int* __restrict__ src, int E, int* __restrict__ cursor, int* __restrict__ tmp) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) tmp[atomicAdd(cursor + src[e], 1)] = e;
+}
+// one wave per source: entry j of the bucket goes to position #{k : id_k < id_j} (ids are distinct)
+__global__ __launch_bounds__(256) void csc_rank_kernel(const int* __restrict__ colptr, const int* __restrict__ tmp,
+                                                       const int* __restrict__ dst, int N, int* __restrict__ perm,
+                                                       int* __restrict__ tgt_by_src) {
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= N) return;
+    const int p0 = colptr[s], d = colptr[s + 1] - p0;
+    for (int j = lane; j < d; j += 64) {
+        const int id = tmp[p0 + j];
+        int r = 0;
+        for (int k = 0; k < d; ++k) r += tmp[p0 + k] < id ? 1 : 0;
+        perm[p0 + r] = id;
+        tgt_by_src[p0 + r] = dst[id];
+    }
+}
+
+// offsets of the molecules in a SORTED batch vector: mol_ptr[m] = first atom with batch >= m  (m = 0 .. n_mol)
+__global__ void molecule_ptr_kernel(const int64_t* __restrict__ batch, int N, int n_mol, int* __restrict__ mol_ptr) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n > N) return;
+    const int64_t lo = n == 0 ? 0 : batch[n - 1] + 1;            // molecules lo .. hi start at atom n
+    const int64_t hi = n == N ? n_mol : batch[n];
+    for (int64_t m = lo; m <= hi && m <= n_mol; ++m) mol_ptr[m] = n;
+}
+
 }  // namespace gn
+
+extern "C" int gn_build_csc(const int* src, const int* dst, int E, int N, int* colptr, int* perm, int* tgt_by_src,
+                            int* work, void* stream) {
+    if (E < 0 || N < 0 || !colptr || (E > 0 && (!src || !dst || !perm || !tgt_by_src || !work))) return GN_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int* cnt = work;                                             // [N] counts, then the scatter cursor
+    int* tmp = work + N;                                         // [E] bucket contents before ranking
+    if (N > 0 && hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)N, st) != hipSuccess) return (int)hipGetLastError();
+    if (E > 0) hipLaunchKernelGGL(gn::csc_count_kernel, dim3((E + 255) / 256), dim3(256), 0, st, src, E, cnt);
+    hipLaunchKernelGGL(gn::csc_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, N, colptr, cnt);
+    if (E > 0) {
+        hipLaunchKernelGGL(gn::csc_scatter_kernel, dim3((E + 255) / 256), dim3(256), 0, st, src, E, cnt, tmp);
+        hipLaunchKernelGGL(gn::csc_rank_kernel, dim3((N + 3) / 4), dim3(256), 0, st, colptr, tmp, dst, N, perm, tgt_by_src);
+    }
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
+
+extern "C" int gn_molecule_ptr(const int64_t* batch, int N, int n_mol, int* mol_ptr, void* stream) {
+    if (N < 0 || n_mol < 0 || !mol_ptr || (N > 0 && !batch)) return GN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gn::molecule_ptr_kernel, dim3((N + 256) / 256), dim3(256), 0, (hipStream_t)stream, batch, N, n_mol, mol_ptr);
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+}
 
 extern "C" int gn_edge_vectors(const float* pos, const int* src, const int* dst, int E, float* edge_vec,
                                float* edge_diff, void* stream) {

@@ -375,14 +375,14 @@ class Graph:
         self.set_geometry(self.edge_diff, self.edge_vec)
 
     def csc(self):
-        """Edges grouped by source (stable): integer index plumbing, no host sync."""
+        """Edges grouped by source (stable order: gn_build_csc), no host sync."""
         if self.perm is None:
-            self.perm = torch.sort(self.src, stable=True).indices.to(torch.int32)
-            cnt = torch.zeros(self.N, dtype=torch.int32, device=self.src.device)
-            cnt.index_add_(0, self.src.long(), torch.ones_like(self.src))    # (torch.bincount reads its size back: a sync)
-            self.colptr = torch.zeros(self.N + 1, dtype=torch.int32, device=self.src.device)
-            self.colptr[1:] = torch.cumsum(cnt, 0)
-            self.tgt_by_src = self.dst[self.perm.long()].contiguous()   # target of each by-source entry
+            i32 = dict(dtype=torch.int32, device=self.src.device)
+            self.colptr, self.perm = torch.empty(self.N + 1, **i32), torch.empty(self.E, **i32)
+            self.tgt_by_src = torch.empty(self.E, **i32)        # target of each by-source entry
+            work = torch.empty(self.N + self.E, **i32)
+            call("gn_build_csc", ptr(self.src), ptr(self.dst), self.E, self.N, ptr(self.colptr), ptr(self.perm),
+                 ptr(self.tgt_by_src), ptr(work), _stream())
         return self.colptr, self.perm
 
 

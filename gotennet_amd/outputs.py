@@ -57,10 +57,13 @@ class ScaleShift(nn.Module):
 
 def molecule_ptr(batch: torch.Tensor, n_mol: int) -> torch.Tensor:
     """int32 [n_mol+1] offsets of each molecule in the (sorted) batch vector -- index plumbing."""
-    # (torch.bincount reads max(batch) back to size its output: a host synchronisation per call; index_add_ does not)
+    out = torch.empty(n_mol + 1, dtype=torch.int32, device=batch.device)
+    if batch.is_cuda and batch.dtype == torch.int64:           # one launch, no host read (torch.bincount synchronises)
+        call("gn_molecule_ptr", ptr(batch.contiguous()), batch.shape[0], n_mol, ptr(out), engine._stream())
+        return out
     cnt = torch.zeros(n_mol, dtype=torch.int32, device=batch.device)
     cnt.index_add_(0, batch, torch.ones_like(batch, dtype=torch.int32))
-    out = torch.zeros(n_mol + 1, dtype=torch.int32, device=batch.device)
+    out[0] = 0
     out[1:] = torch.cumsum(cnt, 0)
     return out
 

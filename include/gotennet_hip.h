@@ -75,6 +75,17 @@ int gn_build_csr(const int64_t* edge_index, int E, int N, int* src, int* dst, in
  * non-decreasing, |= 2 when any index lies outside [0, N).  GotenNet.forward / EnergyForces sort or raise on it. */
 int gn_check_edges(const int64_t* edge_index, int E, int N, int* flag, void* stream);
 
+/* By-source (CSC) view of a target-major edge list for the force backward's by-source passes: colptr [N + 1],
+ * perm [E] = the CSR edge ids of every source in increasing order (what a stable sort of `src` gives), tgt_by_src [E] =
+ * dst[perm].  Built without a sort (count, one-workgroup scan, scatter, per-bucket ranking): four small launches and a
+ * memset instead of the ~18 of torch.sort / index_add_ / cumsum.  work: N + E ints of scratch.  Integer arithmetic only. */
+int gn_build_csc(const int* src, const int* dst, int E, int N, int* colptr, int* perm, int* tgt_by_src, int* work,
+                 void* stream);
+
+/* Offsets of the molecules in a SORTED int64 batch vector (the heads' segment boundaries, outputs.py:349-357 scatter over
+ * `batch`): mol_ptr [n_mol + 1], mol_ptr[m] = first atom whose batch index is >= m.  One launch, no host read. */
+int gn_molecule_ptr(const int64_t* batch, int N, int n_mol, int* mol_ptr, void* stream);
+
 /* Out-degree of every node counted over ALL edges incl. self-loops
  * (gotennet.py:986-989: scatter(ones, edge_index[0])).  outdeg must be zeroed by the caller. */
 int gn_out_degree(const int* src, int E, int* outdeg, void* stream);

@@ -768,3 +768,35 @@ def test_atomwise_v3_matches_reference_kat(agg):
                              int(t["n_mol"]), 1.7, 0.35, z=t["z"], aggregation=aggregation)
     (g64,) = torch.autograd.grad(y64.sum(), h64)
     assert rel_err(gh.cpu(), g64) < TOL
+
+
+@pytest.mark.gpu
+def test_device_csc_and_molecule_offsets_match_torch():
+    """gn_build_csc (count / scan / scatter / per-bucket ranking) against a stable sort by source, bit-exact: random graphs
+    with empty sources, a source of out-degree 700, more atoms than one scan chunk, no edges; gn_molecule_ptr against
+    bincount + cumsum incl. empty molecules at both ends."""
+    from gotennet_amd._lib import call, ptr
+    from gotennet_amd.outputs import molecule_ptr
+    g = torch.Generator().manual_seed(0)
+    for N, E in ((1, 1), (50, 0), (300, 4000), (5000, 90000), (3000, 2500)):
+        src = torch.randint(0, N, (E,), generator=g)
+        if E > 1000:
+            src[:700] = 7                                        # one hub
+            src[src == 11] = 12                                  # one source without edges
+        dst = torch.sort(torch.randint(0, N, (E,), generator=g)).values       # target-major
+        s32, d32 = src.to(torch.int32).cuda(), dst.to(torch.int32).cuda()
+        colptr = torch.empty(N + 1, dtype=torch.int32, device="cuda")
+        perm, tgt = torch.empty(E, dtype=torch.int32, device="cuda"), torch.empty(E, dtype=torch.int32, device="cuda")
+        work = torch.empty(N + E, dtype=torch.int32, device="cuda")
+        call("gn_build_csc", ptr(s32), ptr(d32), E, N, ptr(colptr), ptr(perm), ptr(tgt), ptr(work), None)
+        torch.cuda.synchronize()
+        ref_perm = torch.sort(src, stable=True).indices
+        ref_col = torch.zeros(N + 1, dtype=torch.int64)
+        ref_col[1:] = torch.bincount(src, minlength=N).cumsum(0)
+        assert torch.equal(colptr.cpu().long(), ref_col)
+        assert torch.equal(perm.cpu().long(), ref_perm) and torch.equal(tgt.cpu().long(), dst[ref_perm])
+    for n_mol, sizes in ((1, [5]), (6, [0, 3, 0, 0, 4, 0]), (4, [2, 2, 2, 2]), (3, [0, 0, 0])):
+        batch = torch.arange(n_mol).repeat_interleave(torch.tensor(sizes))
+        ref = torch.zeros(n_mol + 1, dtype=torch.int64)
+        ref[1:] = torch.tensor(sizes).cumsum(0)
+        assert torch.equal(molecule_ptr(batch.cuda(), n_mol).cpu().long(), ref)
