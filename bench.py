@@ -226,6 +226,7 @@ def main():
                     help="take roofline.traffic from the committed PMC passes instead of two rocprofv3 sub-runs of this script")
     ap.add_argument("--static-topology", action="store_true",
                     help="time the step on a cached topology (CSR / CSC / molecule offsets built once): an MD loop on a fixed neighbour list")
+    ap.add_argument("--no-static", action="store_true", help="skip the static-topology side measurement")
     ap.add_argument("--replay", action="store_true", help="hipGraph replay of the static-topology step (EnergyForces(replay=True)) instead of eager launches")
     ap.add_argument("--full-json", default=None,
                     help="where the FULL record goes (default: gpurun_out/bench_full.json next to this file, when that "
@@ -349,7 +350,7 @@ def worker(a):
         wl["md22_ac_ala3_b64"] = measure(a, "md22_ac_ala3", 64, 2, 10, 2, rank, world, dev, dist)
         wl["md22_nanotube_b8_lmax3"] = measure(a, "md22_nanotube", 8, 3, 10, 2, rank, world, dev, dist)
     static = None
-    if sides and not a.static_topology and not a.replay:
+    if sides and not a.static_topology and not a.replay and not a.no_static:
         import copy
         a_st = copy.copy(a)
         a_st.static_topology = True
@@ -844,7 +845,7 @@ def live_traffic(a):
                 cmd = [exe, "--kernel-trace", "--pmc", *counter.split(), "-d", out, "-o", "r", "--", sys.executable,
                        os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", str(a.batch),
                        "--lmax", str(a.lmax), "--workload", a.workload, "--no-lmax4", "--no-split", "--no-graph",
-                       "--no-workloads", "--no-cpu-baseline", "--no-forward-only", "--no-live-traffic"]
+                       "--no-workloads", "--no-cpu-baseline", "--no-forward-only", "--no-live-traffic", "--no-static"]
                 env = dict(os.environ, TMPDIR="/tmp")
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                timeout=240, check=True)

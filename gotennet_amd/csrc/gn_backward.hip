@@ -1074,9 +1074,8 @@ __global__ void head_grad_kernel(const float* __restrict__ pre1, const float* __
 }  // namespace gn
 
 // ====================================================================================== C ABI
-static bool bwd_dim_ok(int F) { return F >= 16 && F <= 256 && gn::is_pow2(F); }
-// F = 512 / 1024 (a slot spans 2 / 4 waves): the degree-sliced kernels and the init kernels only; the per-edge scalar
-// gradients then come as F / 256 partial slices per call (gn_common.h slot_sum_store)
+// F <= 256: every kernel family.  F = 512 / 1024 (a slot spans 2 / 4 waves): the degree-sliced kernels and the init kernels;
+// the per-edge scalar gradients then come as F / 256 partial slices per call (gn_common.h slot_sum_store)
 static bool bwd_dim_ok_wide(int F) { return F >= 16 && F <= 1024 && gn::is_pow2(F); }
 
 #define GN_SWITCH_LMAX(KERNEL, grid, block, st, ...)                                                   \

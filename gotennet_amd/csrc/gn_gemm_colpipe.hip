@@ -47,9 +47,6 @@
 #ifndef GN_CP_MIN_TILES
 #define GN_CP_MIN_TILES 2048    // ... and the group this many 64 x 128 output tiles (four per persistent workgroup); -1: never
 #endif
-#ifndef GN_CP_ABL
-#define GN_CP_ABL 0             // timing probes of variant builds (wrong results): 1 no global stores, 8 no epilogue slices
-#endif
 
 namespace gn {
 
@@ -214,7 +211,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_colpipe(const ClArgs ca) {
                         if (act) v = act4(v, kind);
                         if (gate) v = v * (gate_mode ? dact4(gv[q], kind) : gv[q]);
                         if (res) v = rv[q] + v;
-                        if ((GN_CP_ABL & 1) && v.x != 123.456f) continue;
                         if (gn >= nt_store) st4_nt(C + off, v); else st4(C + off, v);
                     }
                 }
@@ -253,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_colpipe(const ClArgs ca) {
                     if (g + NB < NS) load_b(bo, g + NB, bq[g % NB]);
                     else if (has_next) load_b(bo_next, g + NB - NS, bq[g % NB]);
                     if constexpr (EPI) {
-                        if (!(GN_CP_ABL & 8)) epi_slice(std::integral_constant<int, P ^ 1>{}, g, ps - 1);
+                        epi_slice(std::integral_constant<int, P ^ 1>{}, g, ps - 1);
                     }
                 }
             };
@@ -269,15 +265,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_colpipe(const ClArgs ca) {
             }
             if (ps < ps1) {
                 pass(P1{}, Yes{}, ps, false);
-                if (!(GN_CP_ABL & 8)) {
 #pragma unroll
-                    for (int g = 0; g < NS; g += 2) epi_slice(P1{}, g, ps);
-                }
+                for (int g = 0; g < NS; g += 2) epi_slice(P1{}, g, ps);
             } else {
-                if (!(GN_CP_ABL & 8)) {
 #pragma unroll
-                    for (int g = 0; g < NS; g += 2) epi_slice(P0{}, g, ps - 1);
-                }
+                for (int g = 0; g < NS; g += 2) epi_slice(P0{}, g, ps - 1);
             }
             lds_barrier();                           // the next panel overwrites the planes and the exponents
         }
