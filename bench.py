@@ -822,6 +822,9 @@ def _traffic_entry(f, w):
         out["gn_htr_edge"] = int(sum(byt(k) * f[k][1] for k in htr) / max(f[k][1] for k in htr))
     if mb:
         out["gn_message_backward"] = int(sum(byt(k) * f[k][1] for k in mb) / layers)
+    hb = [k for k in f if "htr_bwd_" in k]
+    if hb:                                       # target + source passes of one layer (the last layer has no HTR stage)
+        out["gn_htr_backward"] = int(sum(byt(k) * f[k][1] for k in hb) / max(f[k][1] for k in hb if "target" in k))
     out["message_stage"] = out["gn_message_aggregate"] + out["gn_attn_softmax"]
     return out
 

@@ -262,6 +262,9 @@ class GATA(_LayerPackCache, nn.Module):
         _require_cuda(h, "GATA")
         if self.training and self.dropout > 0:
             raise NotImplementedError("attention dropout (training mode) is not on the accelerated path; call .eval()")
+        if embed.needs_embedding(self.n_atom_basis):
+            raise NotImplementedError(f"n_atom_basis={self.n_atom_basis}: a stand-alone GATA layer needs a power-of-two width (the slot kernels "
+                                      "tile an edge row over F/4 lanes); inside GotenNet such a model runs embedded in the next one")
         cfg, lw = self.layer_config(), self._layer_pack(_pack_gata)
         hs, ts = h.shape, t_ij.shape
         N, E = h.shape[0], edge_index.shape[1]

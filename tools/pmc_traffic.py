@@ -48,6 +48,7 @@ def entry_for(fetch_path, write_path):
         "gn_htr_edge": int(sum(byt(k) * f[k][1] for k in htr) / max(f[k][1] for k in htr)),
         "gn_gemm_family_avg": int(sum(byt(k) * f[k][1] for k in gem) / n),
         "gn_message_backward": int(sum(byt(k) * f[k][1] for k in mb) / layers) if layers else None,
+        "gn_htr_backward": int(sum(byt(k) * f[k][1] for k in f if "htr_bwd_" in k) / max(1, max([f[k][1] for k in f if "htr_bwd_target" in k] or [1]))),
         "_detail": {k[:110]: {"FETCH_SIZE_KiB": f[k][0], "WRITE_SIZE_KiB": w[k][0], "launches": f[k][1]}
                     for k in msg + [soft] + htr + mb + gem},
     }
