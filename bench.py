@@ -144,7 +144,7 @@ def compact_line(full):
     ``full`` is the complete record (what round 3 printed); it is written to a side file by ``emit``."""
     out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                 "scaling", "vs_baseline", "dtype", "data", "config", "n_ranks_seen", "energy_vector_len",
-                                "energy_checksum", "rank_ms_per_step", "launch_mode")
+                                "energy_checksum", "rank_ms_per_step", "launch_mode", "batches_in_flight")
            if k in full and not (k == "rank_ms_per_step" and full[k] is None)}
     out["roofline"] = _roof_compact(full.get("roofline"))
     if out["roofline"] is not None:
@@ -165,6 +165,8 @@ def compact_line(full):
         elif k == "forward_only":
             also[k] = {"value": v.get("value"), "ms_per_step": v.get("ms_per_step"), "steps": v.get("steps"),
                        "cpu_value": (v.get("cpu_baseline") or {}).get("value")}
+        elif k == "batches_in_flight":
+            also[k] = {n: {"value": o.get("value"), "ms_per_batch": o.get("ms_per_batch")} for n, o in v.items()}
         elif k == "static_topology":
             also[k] = {"value": v.get("value"), "ms_per_step": v.get("ms_per_step"), "steps": v.get("steps")}
         elif k in ("single_molecule_latency", "hipgraph_replay_full_batch"):
@@ -226,7 +228,10 @@ def main():
                     help="take roofline.traffic from the committed PMC passes instead of two rocprofv3 sub-runs of this script")
     ap.add_argument("--static-topology", action="store_true",
                     help="time the step on a cached topology (CSR / CSC / molecule offsets built once): an MD loop on a fixed neighbour list")
-    ap.add_argument("--no-static", action="store_true", help="skip the static-topology side measurement")
+    ap.add_argument("--no-static", action="store_true", help="skip the static-topology / batches-in-flight side measurements")
+    ap.add_argument("--lanes", type=int, default=3,
+                    help="batches in flight: steps are fed round-robin to this many EnergyForces lanes on their own HIP streams "
+                         "(pipeline.InFlight); 1 = one step at a time")
     ap.add_argument("--replay", action="store_true", help="hipGraph replay of the static-topology step (EnergyForces(replay=True)) instead of eager launches")
     ap.add_argument("--full-json", default=None,
                     help="where the FULL record goes (default: gpurun_out/bench_full.json next to this file, when that "
@@ -353,8 +358,11 @@ def worker(a):
     if sides and not a.static_topology and not a.replay and not a.no_static:
         import copy
         a_st = copy.copy(a)
-        a_st.static_topology = True
+        a_st.static_topology, a_st.lanes = True, 1
         static = measure(a_st, a.workload, a.batch, a.lmax, max(10, a.steps // 2), 2, rank, world, dev, dist)
+    inflight = None
+    if sides and not a.no_static:                   # the same fresh-topology step at 1 / 2 / 3 batches in flight
+        inflight = {str(n): in_flight(a, res["rep"], res["head"], dev, a.lmax, lanes=n) for n in (1, 2, 3)}
     fwd = None
     if sides and not a.no_forward_only:
         fwd = forward_only(a, res["rep"], res["head"], dev)
@@ -372,6 +380,8 @@ def worker(a):
             so = static["out"]
             also["static_topology"] = {"value": so["value"], "ms_per_step": so["ms_per_step"], "steps": so["steps"],
                                        "note": "the same step with the CSR / CSC index arrays and molecule offsets cached across steps"}
+        if inflight is not None:
+            also["batches_in_flight"] = inflight
         if lat is not None:
             also["single_molecule_latency"] = lat
         if lat_batch is not None:                  # the headline batch as ONE hipGraph replay per step (fixed edge list)
@@ -394,6 +404,39 @@ def worker(a):
         emit(out, a.full_json)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def in_flight(a, rep, head, dev, lmax, steps=20, lanes=2):
+    """Throughput with `lanes` batches in flight (`pipeline.InFlight`: EnergyForces lanes on their own HIP streams, fed
+    round-robin; eager launches, fresh topology every call like the headline), a different batch per lane.  lanes = 1 is the
+    one-step-at-a-time figure of earlier rounds."""
+    from gotennet_amd import synthetic
+    from gotennet_amd.graph import distance
+    from gotennet_amd.pipeline import InFlight
+    B = a.batch
+    data = []
+    for q in range(lanes):                                   # a different batch per lane
+        pos, batch, z = synthetic.make_batch(a.workload, B, seed=0, first_molecule=q * B)
+        pos, batch, z = pos.to(dev), batch.to(dev), z.to(dev)
+        data.append((z, *distance(pos, batch, 5.0, 32), batch))
+    fl = InFlight(rep, head, lanes=lanes, check_edges=False, cache_topology=False)
+    for it in range(2 * lanes):
+        z, ei, ed, ev, batch = data[it % lanes]
+        fl(z, ei, ed, ev, batch, B)
+    fl.wait()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(steps):
+        z, ei, ed, ev, batch = data[it % lanes]
+        e, f = fl(z, ei, ed, ev, batch, B)
+    fl.wait()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(e).all() and torch.isfinite(f).all()
+    return {"metric": f"molecules/sec (energy+force forward), {lanes} batch(es) in flight", "lanes": lanes,
+            "value": round(B * steps / dt, 1), "unit": "molecules/s", "ms_per_batch": round(1e3 * dt / steps, 3), "steps": steps,
+            "note": "pipeline.InFlight: the launches of one step are a dependent chain; a second step on a second stream puts its "
+                    "memory-bound kernels beside the first step's power-capped matrix kernels.  Batch latency is not improved"}
 
 
 def graph_latency(a, rep, head, dev, n_mol=1, iters=200):
@@ -519,7 +562,25 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
             reduce_energies(e[:, 0], rank * B, B * world, out=e_all)
         return e, f
 
+    # Batches in flight (--lanes > 1): consecutive steps go round-robin to `lanes` EnergyForces objects on their own HIP
+    # streams -- the launches of ONE step are a dependent chain, so a second / third step's memory-bound kernels run beside
+    # the first one's power-capped matrix kernels.  Every step is still one batch of B molecules through the
+    # whole path incl. its all-reduce; the event-bracketed steps at the end of the timed region run ALONE (lanes drained).
+    lanes = 1 if (a.replay or a.lanes < 2) else a.lanes
+    fl = lane_e_all = None
+    if lanes > 1:
+        from gotennet_amd.pipeline import InFlight
+        fl = InFlight(rep, head, lanes=lanes, check_edges=False, cache_topology=not fresh)
+        lane_e_all = [torch.zeros(B * world, dtype=torch.float32, device=dev) for _ in range(lanes)]
+
+    def step_lane():
+        buf = lane_e_all[fl.next_lane]
+        then = (lambda e_, f_: reduce_energies(e_[:, 0], rank * B, B * world, out=buf)) if dist is not None else None
+        return fl(z, ei, ed, ev, batch, B, mol_ptr=None if fresh else mol_ptr, _then=then)
+
     def fence():
+        if fl is not None:
+            fl.wait()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -528,6 +589,9 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
     # ---- untimed: warm-up + per-kernel breakdown to pick the dominant kernel ----------
     for _ in range(max(warmup, 1)):
         step()
+    if fl is not None:
+        for _ in range(max(warmup, 1) * lanes):
+            step_lane()
     fence()
     replay = step_fn.replay
     kt = KernelTimer()
@@ -568,7 +632,12 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
         if it >= steps - ev_steps:                         # the event-bracketed steps run eagerly (a replay has no
             step_fn.replay = False                         # per-launch hooks): K - ev_steps replays + ev_steps eager steps
             kt.wanted = (dom_tags | always) if it == steps - 1 else set(always)
-        e, f = step()
+            if fl is not None and it == steps - ev_steps:
+                fl.wait()                                  # the bracketed steps run one at a time: un-overlapped launch durations
+                torch.cuda.current_stream().synchronize()
+            e, f = step()
+        else:
+            e, f = step_lane() if fl is not None else step()
     fence()
     dt = time.perf_counter() - t0
     step_fn.replay = replay
@@ -758,8 +827,11 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
             "rank_ms_per_step": rank_ms,
             "launch_mode": (f"hipGraph replay of the static-topology step ({steps - ev_steps} of {steps} timed steps; the last "
                             f"{ev_steps} run eagerly under HIP-event brackets)" if replayed else
-                            ("eager launches; fresh batch every step (CSR / CSC / out-degree / molecule offsets rebuilt inside the timed step)"
-                             if fresh else "eager launches; static topology (index arrays cached across steps)")),
+                            (("eager launches; fresh batch every step (CSR / CSC / out-degree / molecule offsets rebuilt inside the timed step)"
+                              if fresh else "eager launches; static topology (index arrays cached across steps)")
+                             + (f"; {lanes} batches in flight on {lanes} HIP streams for the first {steps - ev_steps} timed steps, the last "
+                                f"{ev_steps} (HIP-event brackets) one at a time" if lanes > 1 else "; one step at a time"))),
+            "batches_in_flight": lanes,
             "roofline": roof_gemm_family() if dominant == "gn_gemm" else
             (roof_message() if dominant in MSG_STAGE else roof_other(dominant)),
             "roofline_gather_scatter": roof_message(),
@@ -848,7 +920,7 @@ def live_traffic(a):
                 cmd = [exe, "--kernel-trace", "--pmc", *counter.split(), "-d", out, "-o", "r", "--", sys.executable,
                        os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", str(a.batch),
                        "--lmax", str(a.lmax), "--workload", a.workload, "--no-lmax4", "--no-split", "--no-graph",
-                       "--no-workloads", "--no-cpu-baseline", "--no-forward-only", "--no-live-traffic", "--no-static"]
+                       "--no-workloads", "--no-cpu-baseline", "--no-forward-only", "--no-live-traffic", "--no-static", "--lanes", "1"]
                 env = dict(os.environ, TMPDIR="/tmp")
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                timeout=240, check=True)

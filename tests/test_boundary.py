@@ -800,3 +800,28 @@ def test_device_csc_and_molecule_offsets_match_torch():
         ref = torch.zeros(n_mol + 1, dtype=torch.int64)
         ref[1:] = torch.tensor(sizes).cumsum(0)
         assert torch.equal(molecule_ptr(batch.cuda(), n_mol).cpu().long(), ref)
+
+
+@pytest.mark.gpu
+def test_in_flight_lanes_match_single_lane():
+    """pipeline.InFlight: calls fed round-robin to two EnergyForces lanes on two HIP streams return the bits of the plain
+    object, for interleaved DIFFERENT batches, after wait()."""
+    from tests.test_hip_forces import _head_from_case
+    from gotennet_amd.graph import distance
+    from gotennet_amd.pipeline import EnergyForces, InFlight
+    cfg, sd, head_sd, t = load_case("l2_sep_f32")
+    net, head = _mirror(cfg, sd), _head_from_case(cfg, head_sd)
+    z, batch = t["z"].cuda(), t["batch"].cuda()
+    g = torch.Generator().manual_seed(1)
+    cases = []
+    for _ in range(5):
+        pos = (t["pos"] + 0.05 * torch.randn(t["pos"].shape, generator=g)).cuda()
+        cases.append(distance(pos, batch, cfg["cutoff"], 32))
+    plain = EnergyForces(net, head, check_edges=False)
+    ref = [plain(z, ei, ed, ev, batch, cfg["n_mol"]) for ei, ed, ev in cases]
+    fl = InFlight(net, head, lanes=2, check_edges=False)
+    out = [fl(z, ei, ed, ev, batch, cfg["n_mol"]) for ei, ed, ev in cases]
+    fl.wait()
+    torch.cuda.synchronize()
+    for (e0, f0), (e1, f1) in zip(ref, out):
+        assert torch.equal(e0, e1) and torch.equal(f0, f1)

@@ -10,7 +10,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum" \
            "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_LEVEL_WAVES"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $SET -d gpurun_out/pmc_step_$i -o r -- python bench.py --lmax $L --no-lmax4 --no-split --no-graph --no-workloads --steps 1 --warmup 1 --no-cpu-baseline --no-forward-only --no-live-traffic --no-static > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $SET -d gpurun_out/pmc_step_$i -o r -- python bench.py --lmax $L --no-lmax4 --no-split --no-graph --no-workloads --steps 1 --warmup 1 --no-cpu-baseline --no-forward-only --no-live-traffic --no-static --lanes 1 > /dev/null 2>&1
   python tools/rocprof_summary.py gpurun_out/pmc_step_$i/r_results.db 2>/dev/null | grep -E "avg=" >> gpurun_out/pmc_step_raw.txt
   rm -rf gpurun_out/pmc_step_$i
 done

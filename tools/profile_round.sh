@@ -4,7 +4,7 @@
 #   bash tools/profile_round.sh r03
 R=${1:-r05}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-B="python bench.py --no-lmax4 --no-split --no-graph --no-workloads --no-cpu-baseline --no-forward-only --no-live-traffic --no-static"
+B="python bench.py --no-lmax4 --no-split --no-graph --no-workloads --no-cpu-baseline --no-forward-only --no-live-traffic --no-static --lanes 1"
 for L in 2 4; do
   rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats_l$L -o r -- $B --lmax $L --steps 5 --warmup 2 > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/prof_fetch_l$L -o r -- $B --lmax $L --steps 2 --warmup 1 > /dev/null 2>&1
