@@ -423,6 +423,140 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kerne
     });
 }
 
+// by-source pass that ALSO does the per-edge work of the by-target pass (round 5): the gate gradients `go` of an edge are
+// computed once, here, and everything that needs them -- g_tf, g_cut, g_rl, the head sums of g_a (per edge) and g_x, g_v,
+// g_X (per source) -- leaves this kernel; t_filter is read ONCE (the two-kernel form reads it in both passes: 1.50 x the
+// algorithmic traffic).  The softmax / scores backward then runs by target (attn_bwd_kernel, as in the degree-group form)
+// and g_k by source (msg_bwd_gk_kernel).  lmax <= 2, general launches (X_in != NULL), SiLU.
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
+__global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG) void msg_bwd_merged_kernel(const MsgBwdArgs p, float* __restrict__ ga) {
+    using S = MsgShape<LMAX, SEP_DIR, SEP_TENSOR>;
+    constexpr int D = S::D, M = S::M;
+    constexpr int KP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));
+    constexpr int ROWS = 2 * M + D;                   // [0,M) g_x, [M,2M) g_v, [2M, 2M+D) g_X
+    constexpr int CH = ROWS < 9 ? ROWS : 9;
+    __shared__ __attribute__((aligned(16))) float red[CH * 1024];
+    __shared__ float hsum[256 * M];
+    const int N = p.N, F = p.F, H = p.H;
+    const int j = xcd_item(blockIdx.x, N);
+    if (j < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
+    const int p0 = p.colptr[j], p1 = p.colptr[j + 1];
+    const int per_head = (M * F) / H;
+    int hb[M];
+#pragma unroll
+    for (int b = 0; b < M; ++b) hb[b] = (b * F + c0) / per_head;
+    float4 acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = zero4();
+
+    for (int pp = p0 + slot; pp < p1; pp += ns) {
+        const int e = p.perm[pp];
+        const int i = p.dst[pp];
+        const float ce = p.cut[e];
+        const float* xr = p.x + (size_t)j * p.ldxv + c0;          // own rows, re-read per edge (L1-resident)
+        const float* vr = p.v + (size_t)j * p.ldxv + c0;
+        const float* Xj = p.X_in + (size_t)j * D * F + c0;
+        asm volatile("" : "+v"(xr), "+v"(vr), "+v"(Xj));
+        const float* tr = p.eproj + (size_t)e * p.lde + F + c0;
+        float* gtr = p.g_eproj + (size_t)e * p.lde + F + c0;
+        const float* ar = p.a + (size_t)e * H;
+        const float* re = p.rl + (size_t)e * D;
+        const float* gXi = p.g_X1 + (size_t)i * D * F + c0;
+        float4 gx[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m) gx[m] = ld4(gXi + (size_t)m * F);
+        float pa_h[M], rlp[D];
+        float cutp = 0.f;
+#pragma unroll
+        for (int b = 0; b < M; ++b) {
+            const float4 tfb = ld4_nt(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
+            const float ab = ar[hb[b]];
+            const float4 fw = fma4(ab, vb, (tfb * xb) * ce);       // the forward gate of this block
+            float4 go;
+            if (b == 0) {
+                go = ld4(p.g_h1 + (size_t)i * F + c0);
+            } else {
+                go = zero4();
+#pragma unroll
+                for (int l = S::lo(b); l <= S::hi(b); ++l)
+#pragma unroll
+                    for (int m = S::first_row(l); m < S::first_row(l) + 2 * l + 1; ++m) {
+                        if (S::is_dir(b)) {
+                            go = fma4(re[m], gx[m], go);
+                            rlp[m] = hsum4(gx[m] * fw);
+                        } else {
+                            go = fma4(gx[m], ld4(Xj + (size_t)m * F), go);
+                            acc[2 * M + m] = fma4(gx[m], fw, acc[2 * M + m]);
+                        }
+                    }
+            }
+            st4_nt(gtr + b * F, (go * xb) * ce);
+            cutp += hsum4(go * tfb * xb);
+            pa_h[b] = hsum4(go * vb);
+            acc[b] = fma4(go, tfb * ce, acc[b]);
+            acc[M + b] = fma4(ab, go, acc[M + b]);
+        }
+        cutp = group_sum(cutp, lps);
+        if (lp == 0) p.g_cut[e] = cutp;
+        {   // head sums of g_a (same staging as msg_bwd_target_body: a slot never spans waves, wave-ordered LDS accesses)
+            float* hrow = hsum + slot * (M * lps);
+#pragma unroll
+            for (int b = 0; b < M; ++b) hrow[b * lps + lp] = pa_h[b];
+            const int rpl = lps / H, hh = lp / rpl, part = lp - hh * rpl;
+            const float* hp = hrow + hh * (M * rpl) + part * M;
+            float hv = hp[0];
+#pragma unroll
+            for (int k = 1; k < M; ++k) hv += hp[k];
+            hv = group_sum(hv, rpl);
+            if (part == 0) ga[(size_t)e * H + hh] = hv;
+        }
+        if (lps >= KP) {                             // D rl sums in one butterfly
+            float vals[KP];
+#pragma unroll
+            for (int m = 0; m < KP; ++m) vals[m] = m < D ? rlp[m] : 0.f;
+            multi_group_sum<KP>(vals, lps, lp);
+            const int stride = lps / KP;
+            if ((lp & (stride - 1)) == 0 && lp / stride < D) p.g_rl[(size_t)e * D + lp / stride] = vals[0];
+        } else {
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                const float sv = group_sum(rlp[m], lps);
+                if (lp == 0) p.g_rl[(size_t)e * D + m] = sv;
+            }
+        }
+    }
+    reduce_rows<ROWS>(acc, red, slot, c0, F, ns, [&](int row, float4 sv) {
+        if (row < M) st4(p.g_x + (size_t)j * p.ldxv + row * F + c0, sv);
+        else if (row < 2 * M) st4(p.g_v + (size_t)j * p.ldxv + (row - M) * F + c0, sv);
+        else {
+            const size_t off = ((size_t)j * D + (row - 2 * M)) * F + c0;
+            st4(p.g_X_out + off, ld4(p.g_X1 + off) + sv);
+        }
+    });
+}
+
+// g_k of the gathered source rows, after the softmax backward:  g_k_j = sum_e g_s[e, head] q_i SiLU(t_attn pre-activation)
+__global__ __launch_bounds__(256) void msg_bwd_gk_kernel(const MsgBwdArgs p) {
+    __shared__ __attribute__((aligned(16))) float red[1024];
+    const int N = p.N, F = p.F, H = p.H;
+    const int j = xcd_item(blockIdx.x, N);
+    if (j < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    const int hq = c0 / (F / H);
+    float4 gk[1] = {zero4()};
+    for (int pp = p.colptr[j] + slot; pp < p.colptr[j + 1]; pp += ns) {
+        const int e = p.perm[pp], i = p.dst[pp];
+        const float gs = p.g_s[(size_t)e * H + hq];
+        const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
+        const float4 ta = act4(ld4_nt(p.eproj + (size_t)e * p.lde + c0), GN_ACT_SILU);
+        gk[0] = fma4(gs, qi * ta, gk[0]);
+    }
+    reduce_rows<1>(gk, red, slot, c0, F, ns, [&](int, float4 sv) { st4(p.g_nproj + (size_t)j * p.ldn + F + c0, sv); });
+}
+
 // =========================================================================== degree-grouped backward (lmax >= 3)
 // For lmax >= 3 with sep_dir and sep_tensor the monolithic kernels above need 250+ VGPRs.  Gates are
 // per degree, so the work is cut into degree groups {scalar,1,2}, {3}, {4}: one target-pass and one
@@ -1145,6 +1279,12 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
         if (!X_in) {                                                                                      \
             hipLaunchKernelGGL((gn::msg_bwd_target_kernel<L, SD, ST, true>), grid, block, 0, st, p);      \
             hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST, true>), grid, block, 0, st, p);      \
+            break;                                                                                        \
+        }                                                                                                 \
+        if (GN_MSGB_MERGED && (L) <= 2 && ga_parts != nullptr) {                                          \
+            hipLaunchKernelGGL((gn::msg_bwd_merged_kernel<(L) <= 2 ? (L) : 2, SD, ST>), grid, block, 0, st, p, ga_parts); \
+            hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, 1, (size_t)0);       \
+            hipLaunchKernelGGL(gn::msg_bwd_gk_kernel, grid, block, 0, st, p);                             \
             break;                                                                                        \
         }                                                                                                 \
         hipLaunchKernelGGL((gn::msg_bwd_target_kernel<L, SD, ST>), grid, block, 0, st, p);                \

@@ -59,6 +59,12 @@
                            // cost nothing, the kernel sits at 2 waves/SIMD on registers)
 #endif
 
+#ifndef GN_MSGB_MERGED
+#define GN_MSGB_MERGED 1   // message backward at lmax <= 2 (general launches): 1 = by-source kernel with the per-edge work merged in
+#endif                     // (t_filter read once) + attention backward + g_k; 0 = the by-target / by-source pair
+#ifndef GN_W_MSG_MRG
+#define GN_W_MSG_MRG 2     // waves per SIMD hint of that kernel
+#endif
 #ifndef GN_MSGB_PF3
 #define GN_MSGB_PF3 4      // message backward, target pass: trips of the score-backward phase whose rows are requested before
                            // the softmax-backward barriers (0: none)

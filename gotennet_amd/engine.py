@@ -768,7 +768,7 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
     n_htr = sum(lw.Wt is not None for lw in pw.layers)
     n_rl, n_cut = Wm * L + Wh * n_htr, Wm * (G * L + 1)
     g_rl_parts, g_cut_parts = new(n_rl, E, D), new(n_cut, E)
-    ga_parts = new(G, E, H) if G > 1 else None
+    ga_parts = new(G, E, H)                        # head sums of g_a: G partial slices (degree groups), or the merged kernel's one
     if cfg.aggr == 2:                              # aggr = "max": the per-message gradient workspace of the routing kernel
         ga_parts = new(E, 1 + D, F_)
     rl_slice = lambda q: g_rl_parts.data_ptr() + 4 * q * E * D
