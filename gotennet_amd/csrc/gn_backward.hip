@@ -787,6 +787,117 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC_G) void msg_bwd_source_gro
     });
 }
 
+// degree-group form of msg_bwd_merged_kernel: the by-source pass of a group with the group's per-edge work merged in
+// (g_tf of its blocks, its cut slice, its g_rl rows, its slice of the head sums); g_k is left to msg_bwd_gk_kernel.
+template <int LMAX, int LLO, int LHI, bool SCALAR>
+__global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG_G) void msg_bwd_merged_group_kernel(const MsgBwdArgs p, float* __restrict__ ga_slice,
+                                                                                       float* __restrict__ cut_slice) {
+    constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
+    constexpr int M = 1 + 2 * LMAX;
+    constexpr int NL = LHI - LLO + 1;
+    constexpr int XR = (LHI + 1) * (LHI + 1) - LLO * LLO, M0 = LLO * LLO - 1;
+    constexpr int NB = (SCALAR ? 1 : 0) + 2 * NL;            // value blocks of this group
+    constexpr int ROWS = 2 * NB + XR;                        // g_x, g_v per block, g_X rows
+    constexpr int CH = ROWS < 9 ? ROWS : 9;
+    constexpr int KP = (XR + 8) <= 16 ? 16 : 32;
+    __shared__ __attribute__((aligned(16))) float red[CH * 1024];
+    const int N = p.N, F = p.F, H = p.H;
+    const int j = xcd_item(blockIdx.x, N);
+    if (j < 0) return;
+    const int lps = F >> 2, ns = 256 / lps;
+    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
+    const int p0 = p.colptr[j], p1 = p.colptr[j + 1];
+    const int per_head = (M * F) / H;
+    auto vblock = [&](int k) { return SCALAR ? (k == 0 ? 0 : (k <= NL ? LLO + k - 1 : LMAX + LLO + k - 1 - NL))
+                                             : (k < NL ? LLO + k : LMAX + LLO + k - NL); };
+    float4 acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = zero4();
+
+    for (int pp = p0 + slot; pp < p1; pp += ns) {
+        const int e = p.perm[pp];
+        const int i = p.dst[pp];
+        const float ce = p.cut[e];
+        const float* xr = p.x + (size_t)j * p.ldxv + c0;
+        const float* vr = p.v + (size_t)j * p.ldxv + c0;
+        const float* Xj = p.X_in + (size_t)j * D * F + c0;
+        asm volatile("" : "+v"(xr), "+v"(vr), "+v"(Xj));      // own rows: re-read per edge, not pinned in registers
+        const float* tr = p.eproj + (size_t)e * p.lde + F + c0;
+        float* gtr = p.g_eproj + (size_t)e * p.lde + F + c0;
+        const float* ar = p.a + (size_t)e * H;
+        const float* re = p.rl + (size_t)e * D;
+        const float* gXi = p.g_X1 + (size_t)i * D * F + c0;
+        float cutp = 0.f;
+        float vals[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) vals[k] = 0.f;
+        // one value block: gradient `go` of its gate -> g_tf, cut partial, head partial, g_x / g_v rows; returns the forward gate
+        auto block = [&](int b, int k, float4 go) {
+            const float4 tfb = ld4_nt(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
+            const int hb = (b * F + c0) / per_head;
+            const float ab = ar[hb];
+            st4_nt(gtr + b * F, (go * xb) * ce);
+            cutp += hsum4(go * tfb * xb);
+            const float pa = hsum4(go * vb);
+#pragma unroll
+            for (int h = 0; h < 8; ++h) vals[XR + h] += (hb == h) ? pa : 0.f;
+            acc[k] = fma4(go, tfb * ce, acc[k]);
+            acc[NB + k] = fma4(ab, go, acc[NB + k]);
+            return fma4(ab, vb, (tfb * xb) * ce);
+        };
+        if (SCALAR) block(0, 0, ld4(p.g_h1 + (size_t)i * F + c0));
+#pragma unroll
+        for (int l = LLO; l <= LHI; ++l) {
+            const int kd = (SCALAR ? 1 : 0) + (l - LLO), kt = kd + NL;
+            float4 gx[2 * LHI + 1];
+            float4 god = zero4(), got = zero4();
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                const int m = l * l - 1 + mm;
+                gx[mm] = ld4(gXi + (size_t)m * F);
+                god = fma4(re[m], gx[mm], god);
+                got = fma4(gx[mm], ld4(Xj + (size_t)m * F), got);
+            }
+            const float4 od = block(l, kd, god);
+            const float4 ot = block(LMAX + l, kt, got);
+#pragma unroll
+            for (int mm = 0; mm < 2 * l + 1; ++mm) {
+                const int m = l * l - 1 + mm;
+                vals[m - M0] = hsum4(gx[mm] * od);
+                acc[2 * NB + m - M0] = fma4(gx[mm], ot, acc[2 * NB + m - M0]);
+            }
+        }
+        cutp = group_sum(cutp, lps);
+        if (lp == 0) cut_slice[e] = cutp;
+        if (H <= 8 && lps >= KP) {
+            multi_group_sum<KP>(vals, lps, lp);
+            const int stride = lps / KP;
+            if ((lp & (stride - 1)) == 0) {
+                const int idx = lp / stride;
+                if (idx < XR) p.g_rl[(size_t)e * D + M0 + idx] = vals[0];
+                else if (idx - XR < H) ga_slice[(size_t)e * H + idx - XR] = vals[0];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < XR + 8; ++k) {
+                const float sv = group_sum(vals[k], lps);
+                if (lp == 0) {
+                    if (k < XR) p.g_rl[(size_t)e * D + M0 + k] = sv;
+                    else if (k - XR < H) ga_slice[(size_t)e * H + k - XR] = sv;
+                }
+            }
+        }
+    }
+    reduce_rows<ROWS>(acc, red, slot, c0, F, ns, [&](int row, float4 sv) {
+        if (row < NB) st4(p.g_x + (size_t)j * p.ldxv + vblock(row) * F + c0, sv);
+        else if (row < 2 * NB) st4(p.g_v + (size_t)j * p.ldxv + vblock(row - NB) * F + c0, sv);
+        else {
+            const size_t off = ((size_t)j * D + M0 + (row - 2 * NB)) * F + c0;
+            st4(p.g_X_out + off, ld4(p.g_X1 + off) + sv);
+        }
+    });
+}
+
 // HTR backward per degree group (w = sum_l w_l: the degrees are independent)
 template <int LMAX, int LLO, int LHI, bool FIRST>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT_G) void htr_bwd_target_group_kernel(
@@ -1329,6 +1440,17 @@ extern "C" int gn_message_backward(
                        ga_parts + (size_t)(G) * gs, g_cut + (size_t)(G) * E)
 #define GN_MSGB_S(L, LLO, LHI, SC) \
     hipLaunchKernelGGL((gn::msg_bwd_source_group_kernel<L, LLO, LHI, SC>), grid, block, 0, st, p)
+#define GN_MSGB_M(L, LLO, LHI, SC, G)                                                                        \
+    hipLaunchKernelGGL((gn::msg_bwd_merged_group_kernel<L, LLO, LHI, SC>), grid, block, 0, st, p,            \
+                       ga_parts + (size_t)(G) * gs, g_cut + (size_t)(G) * E)
+        if (GN_MSGB_MERGED_G) {                      // by-source group kernels with the per-edge work merged in: t_filter read once
+            if (lmax == 3) { GN_MSGB_M(3, 1, 2, true, 0); GN_MSGB_M(3, 3, 3, false, 1); }
+            else { GN_MSGB_M(4, 1, 2, true, 0); GN_MSGB_M(4, 3, 3, false, 1); GN_MSGB_M(4, 4, 4, false, 2); }
+            hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, lmax - 1, gs);
+            hipLaunchKernelGGL(gn::msg_bwd_gk_kernel, grid, block, 0, st, p);
+            GN_LAUNCH_CHECK();
+            return GN_OK;
+        }
         if (lmax == 3) {
             GN_MSGB_T(3, 1, 2, true, 0); GN_MSGB_T(3, 3, 3, false, 1);
             hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, 2, gs);

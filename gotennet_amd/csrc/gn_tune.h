@@ -62,6 +62,12 @@
 #ifndef GN_MSGB_MERGED
 #define GN_MSGB_MERGED 1   // message backward at lmax <= 2 (general launches): 1 = by-source kernel with the per-edge work merged in
 #endif                     // (t_filter read once) + attention backward + g_k; 0 = the by-target / by-source pair
+#ifndef GN_MSGB_MERGED_G
+#define GN_MSGB_MERGED_G 1 // ... and its degree-group form at lmax 3 / 4
+#endif
+#ifndef GN_W_MSG_MRG_G
+#define GN_W_MSG_MRG_G 2
+#endif
 #ifndef GN_W_MSG_MRG
 #define GN_W_MSG_MRG 2     // waves per SIMD hint of that kernel
 #endif
