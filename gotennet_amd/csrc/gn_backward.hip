@@ -559,94 +559,10 @@ __global__ __launch_bounds__(256) void msg_bwd_gk_kernel(const MsgBwdArgs p) {
 
 // =========================================================================== degree-grouped backward (lmax >= 3)
 // For lmax >= 3 with sep_dir and sep_tensor the monolithic kernels above need 250+ VGPRs.  Gates are
-// per degree, so the work is cut into degree groups {scalar,1,2}, {3}, {4}: one target-pass and one
-// source-pass launch per group, plus one attention-backward launch (softmax backward needs the head
-// sums of ALL groups).  Value blocks: 0 scalar, l direction gate, LMAX + l tensor gate.
-template <int LMAX, int LLO, int LHI, bool SCALAR>
-__global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_TGT_G) void msg_bwd_target_group_kernel(const MsgBwdArgs p, float* __restrict__ ga_slice,
-                                                                  float* __restrict__ cut_slice) {
-    constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
-    constexpr int M = 1 + 2 * LMAX;
-    constexpr int XR = (LHI + 1) * (LHI + 1) - LLO * LLO, M0 = LLO * LLO - 1;
-    constexpr int KP = (XR + 8) <= 16 ? 16 : 32;
-    const int N = p.N, F = p.F, H = p.H;
-    const int i = xcd_item(blockIdx.x, N);
-    if (i < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
-    const int e0 = p.rowptr[i], e1 = p.rowptr[i + 1];
-    const int per_head = (M * F) / H;
-    const float4 gdh = SCALAR ? ld4(p.g_h1 + (size_t)i * F + c0) : zero4();
-    float4 gdX[XR];
-#pragma unroll
-    for (int m = 0; m < XR; ++m) gdX[m] = ld4(p.g_X1 + ((size_t)i * D + M0 + m) * F + c0);
-
-    for (int e = e0 + slot; e < e1; e += ns) {
-        const int j = p.src[e];
-        const float ce = p.cut[e];
-        const float* xr = p.x + (size_t)j * p.ldxv + c0;
-        const float* vr = p.v + (size_t)j * p.ldxv + c0;
-        const float* tr = p.eproj + (size_t)e * p.lde + F + c0;
-        float* gtr = p.g_eproj + (size_t)e * p.lde + F + c0;
-        const float* ar = p.a + (size_t)e * H;
-        const float* Xj = p.X_in + (size_t)j * D * F + c0;
-        const float* re = p.rl + (size_t)e * D;
-        float cutp = 0.f;
-        float vals[KP];
-#pragma unroll
-        for (int k = 0; k < KP; ++k) vals[k] = 0.f;
-        // one value block: gradient `go` of its gate -> g_tf, cut partial, head partial; returns tf*x*cut + a*v
-        auto block = [&](int b, float4 go, bool need_fwd) {
-            const float4 tfb = ld4_nt(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
-            st4_nt(gtr + b * F, (go * xb) * ce);
-            cutp += hsum4(go * tfb * xb);
-            const int hb = (b * F + c0) / per_head;
-            const float pa = hsum4(go * vb);
-#pragma unroll
-            for (int h = 0; h < 8; ++h) vals[XR + h] += (hb == h) ? pa : 0.f;
-            return need_fwd ? fma4(ar[hb], vb, (tfb * xb) * ce) : zero4();
-        };
-        if (SCALAR) block(0, gdh, false);
-#pragma unroll
-        for (int l = LLO; l <= LHI; ++l) {
-            float4 god = zero4(), got = zero4();
-#pragma unroll
-            for (int mm = 0; mm < 2 * l + 1; ++mm) {
-                const int m = l * l - 1 + mm;
-                god = fma4(re[m], gdX[m - M0], god);
-                got = fma4(gdX[m - M0], ld4(Xj + (size_t)m * F), got);
-            }
-            const float4 od = block(l, god, true);
-            block(LMAX + l, got, false);
-#pragma unroll
-            for (int mm = 0; mm < 2 * l + 1; ++mm) {
-                const int m = l * l - 1 + mm;
-                vals[m - M0] = hsum4(gdX[m - M0] * od);
-            }
-        }
-        cutp = group_sum(cutp, lps);
-        if (lp == 0) cut_slice[e] = cutp;
-        if (H <= 8 && lps >= KP) {
-            multi_group_sum<KP>(vals, lps, lp);
-            const int stride = lps / KP;
-            if ((lp & (stride - 1)) == 0) {
-                const int idx = lp / stride;
-                if (idx < XR) p.g_rl[(size_t)e * D + M0 + idx] = vals[0];
-                else if (idx - XR < H) ga_slice[(size_t)e * H + idx - XR] = vals[0];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < XR + 8; ++k) {
-                const float sv = group_sum(vals[k], lps);
-                if (lp == 0) {
-                    if (k < XR) p.g_rl[(size_t)e * D + M0 + k] = sv;
-                    else if (k - XR < H) ga_slice[(size_t)e * H + k - XR] = sv;
-                }
-            }
-        }
-    }
-}
-
+// per degree, so the work is cut into degree groups {scalar,1,2}, {3}, {4}: one by-source launch per
+// group (msg_bwd_merged_group_kernel below: the group's per-edge work rides in it), one attention-
+// backward launch (softmax backward needs the head sums of ALL groups) and one for g_k.
+// Value blocks: 0 scalar, l direction gate, LMAX + l tensor gate.
 // softmax backward over the summed head gradients of all groups, then scores backward (g_ta, g_q)
 template <bool GS_LDS>
 __device__ __forceinline__ void attn_bwd_body(const MsgBwdArgs& p, const float* __restrict__ ga_parts, int G, size_t gstride,
@@ -705,86 +621,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const MsgBwdArgs p, const
     if (i < 0) return;
     if ((p.rowptr[i + 1] - p.rowptr[i]) * p.H <= GS_CAP) attn_bwd_body<true>(p, ga_parts, G, gstride, red, gsl, i);
     else attn_bwd_body<false>(p, ga_parts, G, gstride, red, gsl, i);
-}
-
-template <int LMAX, int LLO, int LHI, bool SCALAR>
-__global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC_G) void msg_bwd_source_group_kernel(const MsgBwdArgs p) {
-    constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
-    constexpr int M = 1 + 2 * LMAX;
-    constexpr int NL = LHI - LLO + 1;
-    constexpr int XR = (LHI + 1) * (LHI + 1) - LLO * LLO, M0 = LLO * LLO - 1;
-    constexpr int NB = (SCALAR ? 1 : 0) + 2 * NL;            // value blocks of this group
-    constexpr int ROWS = 2 * NB + XR + (SCALAR ? 1 : 0);     // g_x, g_v per block, g_X rows, g_k
-    constexpr int CH = ROWS < 9 ? ROWS : 9;
-    __shared__ __attribute__((aligned(16))) float red[CH * 1024];
-    const int N = p.N, F = p.F, H = p.H;
-    const int j = xcd_item(blockIdx.x, N);
-    if (j < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
-    const int p0 = p.colptr[j], p1 = p.colptr[j + 1];
-    const int per_head = (M * F) / H;
-    const int hq = c0 / (F / H);
-    // local block k -> value block: [scalar], dir LLO..LHI, tensor LLO..LHI
-    auto vblock = [&](int k) { return SCALAR ? (k == 0 ? 0 : (k <= NL ? LLO + k - 1 : LMAX + LLO + k - 1 - NL))
-                                             : (k < NL ? LLO + k : LMAX + LLO + k - NL); };
-    float4 acc[ROWS];
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r] = zero4();
-
-    for (int pp = p0 + slot; pp < p1; pp += ns) {
-        const int e = p.perm[pp];
-        const int i = p.dst[pp];
-        const float ce = p.cut[e];
-        const float* xr = p.x + (size_t)j * p.ldxv + c0;
-        const float* vr = p.v + (size_t)j * p.ldxv + c0;
-        const float* Xj = p.X_in + (size_t)j * D * F + c0;
-        asm volatile("" : "+v"(xr), "+v"(vr), "+v"(Xj));      // own rows: re-read per edge, not pinned in registers
-        const float* tr = p.eproj + (size_t)e * p.lde + F + c0;
-        const float* ar = p.a + (size_t)e * H;
-        const float* re = p.rl + (size_t)e * D;
-        const float* gXi = p.g_X1 + (size_t)i * D * F + c0;
-        if (SCALAR) {
-            const float4 go = ld4(p.g_h1 + (size_t)i * F + c0);
-            acc[0] = fma4(go, ld4(tr) * ce, acc[0]);
-            acc[NB] = fma4(ar[c0 / per_head], go, acc[NB]);
-        }
-#pragma unroll
-        for (int l = LLO; l <= LHI; ++l) {
-            const int kd = (SCALAR ? 1 : 0) + (l - LLO), kt = kd + NL;
-            const int bd = l, bt = LMAX + l;
-            const float4 tfd = ld4_nt(tr + bd * F), tft = ld4_nt(tr + bt * F);
-            const float ad = ar[(bd * F + c0) / per_head], at = ar[(bt * F + c0) / per_head];
-            const float4 ot = fma4(at, ld4(vr + bt * F), (tft * ld4(xr + bt * F)) * ce);   // forward tensor gate
-            float4 god = zero4(), got = zero4();
-#pragma unroll
-            for (int mm = 0; mm < 2 * l + 1; ++mm) {
-                const int m = l * l - 1 + mm;
-                const float4 gx = ld4(gXi + (size_t)m * F);
-                god = fma4(re[m], gx, god);
-                got = fma4(gx, ld4(Xj + (size_t)m * F), got);
-                acc[2 * NB + m - M0] = fma4(gx, ot, acc[2 * NB + m - M0]);
-            }
-            acc[kd] = fma4(god, tfd * ce, acc[kd]);
-            acc[NB + kd] = fma4(ad, god, acc[NB + kd]);
-            acc[kt] = fma4(got, tft * ce, acc[kt]);
-            acc[NB + kt] = fma4(at, got, acc[NB + kt]);
-        }
-        if (SCALAR) {
-            const float gs = p.g_s[(size_t)e * H + hq];
-            const float4 qi = ld4(p.qk + (size_t)i * p.ldqk + c0);
-            const float4 ta = act4(ld4_nt(p.eproj + (size_t)e * p.lde + c0), GN_ACT_SILU);
-            acc[2 * NB + XR] = fma4(gs, qi * ta, acc[2 * NB + XR]);
-        }
-    }
-    reduce_rows<ROWS>(acc, red, slot, c0, F, ns, [&](int row, float4 sv) {
-        if (row < NB) st4(p.g_x + (size_t)j * p.ldxv + vblock(row) * F + c0, sv);
-        else if (row < 2 * NB) st4(p.g_v + (size_t)j * p.ldxv + vblock(row - NB) * F + c0, sv);
-        else if (row < 2 * NB + XR) {
-            const size_t off = ((size_t)j * D + M0 + (row - 2 * NB)) * F + c0;
-            st4(p.g_X_out + off, ld4(p.g_X1 + off) + sv);
-        } else st4(p.g_nproj + (size_t)j * p.ldn + F + c0, sv);
-    });
 }
 
 // degree-group form of msg_bwd_merged_kernel: the by-source pass of a group with the group's per-edge work merged in
@@ -1392,8 +1228,8 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
             hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST, true>), grid, block, 0, st, p);      \
             break;                                                                                        \
         }                                                                                                 \
-        if (GN_MSGB_MERGED && (L) <= 2 && ga_parts != nullptr) {                                          \
-            hipLaunchKernelGGL((gn::msg_bwd_merged_kernel<(L) <= 2 ? (L) : 2, SD, ST>), grid, block, 0, st, p, ga_parts); \
+        if (GN_MSGB_MERGED && ga_parts != nullptr) {     /* general launches: t_filter read once (gn_tune.h) */ \
+            hipLaunchKernelGGL((gn::msg_bwd_merged_kernel<L, SD, ST>), grid, block, 0, st, p, ga_parts);  \
             hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, 1, (size_t)0);       \
             hipLaunchKernelGGL(gn::msg_bwd_gk_kernel, grid, block, 0, st, p);                             \
             break;                                                                                        \
@@ -1432,36 +1268,17 @@ extern "C" int gn_message_backward(
     // (F > 256: the degree-sliced kernels; g_rl / g_cut come as F / 256 partial slices, the caller sized them so)
     if (gn_use_highl(lmax_arg) || F > 256 || act != GN_ACT_SILU) return gn_highl_message_backward(p, lmax, sep_dir, sep_tensor, st);
     if (X_in && gn_message_backward_groups(lmax_arg, sep_dir, sep_tensor, act) > 1) {
-        // degree groups: target passes (head sums and cut slices per group) -> attention backward -> source passes
         if (ga_parts == nullptr || E <= 0) return GN_ERR_BAD_ARG;
         const size_t gs = (size_t)E * H;
-#define GN_MSGB_T(L, LLO, LHI, SC, G)                                                                        \
-    hipLaunchKernelGGL((gn::msg_bwd_target_group_kernel<L, LLO, LHI, SC>), grid, block, 0, st, p,            \
-                       ga_parts + (size_t)(G) * gs, g_cut + (size_t)(G) * E)
-#define GN_MSGB_S(L, LLO, LHI, SC) \
-    hipLaunchKernelGGL((gn::msg_bwd_source_group_kernel<L, LLO, LHI, SC>), grid, block, 0, st, p)
 #define GN_MSGB_M(L, LLO, LHI, SC, G)                                                                        \
     hipLaunchKernelGGL((gn::msg_bwd_merged_group_kernel<L, LLO, LHI, SC>), grid, block, 0, st, p,            \
                        ga_parts + (size_t)(G) * gs, g_cut + (size_t)(G) * E)
-        if (GN_MSGB_MERGED_G) {                      // by-source group kernels with the per-edge work merged in: t_filter read once
-            if (lmax == 3) { GN_MSGB_M(3, 1, 2, true, 0); GN_MSGB_M(3, 3, 3, false, 1); }
-            else { GN_MSGB_M(4, 1, 2, true, 0); GN_MSGB_M(4, 3, 3, false, 1); GN_MSGB_M(4, 4, 4, false, 2); }
-            hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, lmax - 1, gs);
-            hipLaunchKernelGGL(gn::msg_bwd_gk_kernel, grid, block, 0, st, p);
-            GN_LAUNCH_CHECK();
-            return GN_OK;
-        }
-        if (lmax == 3) {
-            GN_MSGB_T(3, 1, 2, true, 0); GN_MSGB_T(3, 3, 3, false, 1);
-            hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, 2, gs);
-            GN_MSGB_S(3, 1, 2, true); GN_MSGB_S(3, 3, 3, false);
-        } else {
-            GN_MSGB_T(4, 1, 2, true, 0);
-            GN_MSGB_T(4, 3, 3, false, 1); GN_MSGB_T(4, 4, 4, false, 2);
-            hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, 3, gs);
-            GN_MSGB_S(4, 1, 2, true);
-            GN_MSGB_S(4, 3, 3, false); GN_MSGB_S(4, 4, 4, false);
-        }
+        // by-source group kernels with the per-edge work merged in (t_filter read once; head sums and cut slices per group)
+        // -> attention backward over the summed head gradients -> g_k
+        if (lmax == 3) { GN_MSGB_M(3, 1, 2, true, 0); GN_MSGB_M(3, 3, 3, false, 1); }
+        else { GN_MSGB_M(4, 1, 2, true, 0); GN_MSGB_M(4, 3, 3, false, 1); GN_MSGB_M(4, 4, 4, false, 2); }
+        hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, lmax - 1, gs);
+        hipLaunchKernelGGL(gn::msg_bwd_gk_kernel, grid, block, 0, st, p);
         GN_LAUNCH_CHECK();
         return GN_OK;
     }

@@ -19,12 +19,6 @@
 #ifndef GN_W_MSG_SRC
 #define GN_W_MSG_SRC 2     // without it the scheduler serialises every row load to reach 3 waves/SIMD: 393 -> 327 us (both passes)
 #endif
-#ifndef GN_W_MSG_TGT_G
-#define GN_W_MSG_TGT_G 0
-#endif
-#ifndef GN_W_MSG_SRC_G
-#define GN_W_MSG_SRC_G 2   // message backward (lmax=4, all passes): 856 -> 711 us per layer (3: 740)
-#endif
 #ifndef GN_W_HTR_TGT
 #define GN_W_HTR_TGT 0     // 2, 3: within noise; 4: 140 -> 268 us
 #endif
@@ -62,9 +56,6 @@
 #ifndef GN_MSGB_MERGED
 #define GN_MSGB_MERGED 1   // message backward at lmax <= 2 (general launches): 1 = by-source kernel with the per-edge work merged in
 #endif                     // (t_filter read once) + attention backward + g_k; 0 = the by-target / by-source pair
-#ifndef GN_MSGB_MERGED_G
-#define GN_MSGB_MERGED_G 1 // ... and its degree-group form at lmax 3 / 4
-#endif
 #ifndef GN_W_MSG_MRG_G
 #define GN_W_MSG_MRG_G 2
 #endif

@@ -322,7 +322,9 @@ int gn_message_backward(const float* x, const float* v, int ldxv, const float* e
 /* Number of degree groups G the message backward uses for these flags (1 = monolithic kernels, lmax >= 5, and every
  * activation other than GN_ACT_SILU -- those run the degree-sliced kernels; lmax 3..4 with sep_dir and sep_tensor
  * and SiLU: {scalar,1,2}, {3}, {4}).  g_cut must then hold G consecutive [E] slices and ga_parts
- * G x [E,H] floats of workspace.
+ * G x [E,H] floats of workspace.  With G = 1, ga_parts ([E,H] floats) selects the single-read form of the register-tiled
+ * kernels (the by-source kernel does the per-edge work, then attention backward, then g_k: t_filter is read once);
+ * ga_parts = NULL keeps the by-target / by-source pair (t_filter read by both).
  * GN_LMAX_MAX in `lmax` (the reference's aggr = "max", gotennet.py:638-639): ga_parts is instead a workspace of
  * E x (1 + D) x F floats -- the upstream gradient of every per-edge MESSAGE, routed to the arg-max edge(s) of each output
  * element (evenly among exact ties, as torch's amax) before the degree-sliced backward kernels run; G = 1, X_in required. */
