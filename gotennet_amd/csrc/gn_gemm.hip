@@ -714,7 +714,7 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     const long cap_big = split ? 768 : 512;
 #else
     const int BMB = 128, BNB = 128;
-    const long cap_big = 512;
+    const long cap_big = GN_GEMM_BIG_CAP;
 #endif
     if (split == 2) {
         const int r = gn_gemm_panel_launch(g, n, st);

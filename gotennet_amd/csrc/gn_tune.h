@@ -72,6 +72,9 @@
 #ifndef GN_GEMM_BIG_MIN
 #define GN_GEMM_BIG_MIN 900    // 128 x 128 projection tiles from this many tiles up (below: 64 x 64)
 #endif
+#ifndef GN_GEMM_BIG_CAP
+#define GN_GEMM_BIG_CAP 512    // persistent workgroups of the 128 x 128 slab kernel (two per CU)
+#endif
 #ifndef GN_GEMM_NT_MB
 #define GN_GEMM_NT_MB 100.0    // outputs of this many MiB and more are stored non-temporally ...
 #endif
