@@ -623,7 +623,9 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
     # the per-launch averages are the same either way (111.1 us for the message stage in both).
     dom_tags = {t for t in tot if family(t) == dominant}
     always = stage_tags | {HTR_TAG, MSGB_TAG, "gn_htr_backward"}
-    ev_steps = min(3, steps)
+    # (with batches in flight the bracketed steps run alone, i.e. slower than the rest: ONE such step -- 6 launches per stage,
+    #  68 projection launches -- instead of three)
+    ev_steps = min(1 if lanes > 1 else 3, steps)
     kt = KernelTimer(wanted=set())
     _lib.TIMER = kt
     fence()
