@@ -202,3 +202,41 @@ def test_library_reads_no_environment():
             assert probe not in text, (path, probe)
     from gotennet_amd import engine
     assert not hasattr(engine, "ACT") and not hasattr(engine, "_act_scope")
+
+
+def test_embedding_map_keeps_heads_and_blocks():
+    """gotennet_amd/embed.py: the channel map g of a width that is not a power of two is injective, keeps every channel in its
+    attention head -- for the F-wide vectors (heads of F/H channels) AND for the flattened M*F-wide gate vectors (heads of
+    M*F/H channels: reference gotennet.py:516-529) -- and embed_pack places weights accordingly (zero padding, compact
+    LayerNorm intermediate, sqrt(Fp/F) folded into gamma_v's last layer)."""
+    import math
+    import gotennet_amd
+    from gotennet_amd import embed
+    for F, H, lmax in ((192, 8, 2), (96, 4, 3), (200, 8, 1), (48, 4, 2), (384, 8, 2), (24, 2, 1)):
+        Fp = embed.padded_width(F)
+        g = embed.channel_map(F, H)
+        assert Fp >= F and (Fp & (Fp - 1)) == 0 and g.numel() == F and g.unique().numel() == F and int(g.max()) < Fp
+        f = torch.arange(F)
+        assert torch.equal(g // (Fp // H), f // (F // H))                        # heads over the F-wide vectors
+        M = 1 + 2 * lmax
+        for m in range(M):                                                       # heads over the flattened M F-wide vectors
+            assert torch.equal((m * Fp + g) // (M * Fp // H), (m * F + f) // (M * F // H)), (F, H, m)
+    net = gotennet_amd.GotenNet(n_atom_basis=192, n_interactions=2, n_rbf=8, cutoff_fn=gotennet_amd.CosineCutoff(5.0), num_heads=8,
+                                lmax=2, sep_dir=True, sep_tensor=True)
+    cfg, pw = net.config(), net.packed_weights()
+    assert (cfg.F, cfg.Fc, cfg.F_model) == (256, 192, 192) and pw.F_model == 192
+    idx = pw.emb_idx
+    g0 = net.gata_list[0]
+    assert pw.Wa.shape == (192, 512) and pw.Wb.shape == (256, 192)               # compact LayerNorm intermediate
+    Wq = pw.layers[0].Wn1[:256]
+    assert torch.equal(Wq[idx][:, idx], g0.W_q.weight.detach())
+    mask = torch.ones(256, dtype=torch.bool); mask[idx] = False
+    assert float(Wq[mask].abs().max()) == 0.0 and float(Wq[:, mask].abs().max()) == 0.0
+    Wv2 = pw.layers[0].Wv2                                                        # [M Fp, Fp], scaled by sqrt(Fp / F)
+    blk = Wv2[256:512][idx][:, idx]
+    assert torch.allclose(blk, g0.gamma_v[1].weight.detach()[192:384] * math.sqrt(256 / 192), rtol=0, atol=0)
+    with pytest.raises(NotImplementedError):                                     # channel norms inside the layers are not embedded
+        gotennet_amd.GotenNet(n_atom_basis=192, n_interactions=1, n_rbf=8, cutoff_fn=gotennet_amd.CosineCutoff(5.0), num_heads=8,
+                              layernorm="layer").config()
+    with pytest.raises(NotImplementedError):
+        gotennet_amd.GotenNet(n_atom_basis=100, n_interactions=1, n_rbf=8, cutoff_fn=gotennet_amd.CosineCutoff(5.0), num_heads=8).config()
