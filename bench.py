@@ -156,7 +156,7 @@ def compact_line(full):
         if full.get(k):
             out[k] = _roof_compact(full[k])
             if k in ("roofline_htr_backward", "roofline_gated_gemm"):      # (the byte formula travels with the two new records)
-                out[k]["bytes"] = str(full[k].get("note", ""))[:150]
+                out[k]["bytes"] = str(full[k].get("note", ""))[:96]
     also_f, also = full.get("also") or {}, {}
     for k, v in also_f.items():
         if k == "other_projection_modes":

@@ -187,7 +187,7 @@ class InFlight:
         dev = next(representation.parameters()).device
         self.lanes = [EnergyForces(representation, head, **kw) for _ in range(max(1, int(lanes)))]
         self.streams = [torch.cuda.Stream(device=dev) for _ in self.lanes]
-        self._k = 0
+        self._k, self._seen = 0, set()
 
     def __call__(self, *args, _then=None, **kw):
         """``_then(energy, forces)`` (optional) runs inside the lane's stream context right after the step is enqueued -- e.g. the
@@ -196,11 +196,25 @@ class InFlight:
         self._k += 1
         st = self.streams[k]
         st.wait_stream(torch.cuda.current_stream(st.device))
+        # The first call of a kind (with / without forces) builds lazily cached operands that ALL lanes share -- packed
+        # weights, their fp16 planes, the transposes of the backward -- on THIS lane's stream: it runs alone, fenced against
+        # the other lanes on both sides.  Later calls find the caches filled and overlap freely.
+        kind = bool(kw.get("forces", True))
+        cold = kind not in self._seen
+        if cold:
+            for other in self.streams:
+                if other is not st:
+                    st.wait_stream(other)
         with torch.cuda.stream(st):
             out = self.lanes[k](*args, **kw)
             if _then is not None:
                 _then(*out)
-            return out
+        if cold:
+            self._seen.add(kind)
+            for other in self.streams:
+                if other is not st:
+                    other.wait_stream(st)
+        return out
 
     @property
     def next_lane(self) -> int:

@@ -804,8 +804,8 @@ def test_device_csc_and_molecule_offsets_match_torch():
 
 @pytest.mark.gpu
 def test_in_flight_lanes_match_single_lane():
-    """pipeline.InFlight: calls fed round-robin to two EnergyForces lanes on two HIP streams return the bits of the plain
-    object, for interleaved DIFFERENT batches, after wait()."""
+    """pipeline.InFlight: calls fed round-robin to three EnergyForces lanes on three HIP streams return the bits of the plain
+    object, for interleaved DIFFERENT batches, after wait() -- starting from a COLD model (nothing packed yet)."""
     from tests.test_hip_forces import _head_from_case
     from gotennet_amd.graph import distance
     from gotennet_amd.pipeline import EnergyForces, InFlight
@@ -817,11 +817,14 @@ def test_in_flight_lanes_match_single_lane():
     for _ in range(5):
         pos = (t["pos"] + 0.05 * torch.randn(t["pos"].shape, generator=g)).cuda()
         cases.append(distance(pos, batch, cfg["cutoff"], 32))
-    plain = EnergyForces(net, head, check_edges=False)
-    ref = [plain(z, ei, ed, ev, batch, cfg["n_mol"]) for ei, ed, ev in cases]
-    fl = InFlight(net, head, lanes=2, check_edges=False)
+    # COLD lanes first: the lazily built operands (weight planes, backward transposes) are made by the first call of each kind
+    # on one lane's stream while the other lanes are fenced off
+    fl = InFlight(net, head, lanes=3, check_edges=False)
     out = [fl(z, ei, ed, ev, batch, cfg["n_mol"]) for ei, ed, ev in cases]
+    out_e = [fl(z, ei, ed, ev, batch, cfg["n_mol"], forces=False) for ei, ed, ev in cases]
     fl.wait()
     torch.cuda.synchronize()
-    for (e0, f0), (e1, f1) in zip(ref, out):
-        assert torch.equal(e0, e1) and torch.equal(f0, f1)
+    plain = EnergyForces(net, head, check_edges=False)
+    ref = [plain(z, ei, ed, ev, batch, cfg["n_mol"]) for ei, ed, ev in cases]
+    for (e0, f0), (e1, f1), (e2, _) in zip(ref, out, out_e):
+        assert torch.equal(e0, e1) and torch.equal(f0, f1) and torch.equal(e0, e2)
