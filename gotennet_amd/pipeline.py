@@ -199,7 +199,7 @@ class InFlight:
         # The first call of a kind (with / without forces) builds lazily cached operands that ALL lanes share -- packed
         # weights, their fp16 planes, the transposes of the backward -- on THIS lane's stream: it runs alone, fenced against
         # the other lanes on both sides.  Later calls find the caches filled and overlap freely.
-        kind = bool(kw.get("forces", True))
+        kind = (bool(kw.get("forces", True)), id(self.lanes[k].rep.packed_weights()))     # (a weight update makes a new pack: cold again)
         cold = kind not in self._seen
         if cold:
             for other in self.streams:
