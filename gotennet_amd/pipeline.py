@@ -195,11 +195,12 @@ class InFlight:
         k = self._k % len(self.lanes)
         self._k += 1
         st = self.streams[k]
+        pack_id = id(self.lanes[k].rep.packed_weights())     # (a stale pack is rebuilt HERE, on the caller's stream, before the lane waits for it)
         st.wait_stream(torch.cuda.current_stream(st.device))
         # The first call of a kind (with / without forces) builds lazily cached operands that ALL lanes share -- packed
         # weights, their fp16 planes, the transposes of the backward -- on THIS lane's stream: it runs alone, fenced against
         # the other lanes on both sides.  Later calls find the caches filled and overlap freely.
-        kind = (bool(kw.get("forces", True)), id(self.lanes[k].rep.packed_weights()))     # (a weight update makes a new pack: cold again)
+        kind = (bool(kw.get("forces", True)), pack_id)       # (a weight update makes a new pack: cold again)
         cold = kind not in self._seen
         if cold:
             for other in self.streams:
