@@ -132,9 +132,51 @@ __device__ __forceinline__ float4 red4(const float* red, int c0, int F, int ns) 
     return s;
 }
 
-// Sum over aligned groups of `width` lanes (power of two, <= 64); every lane gets its group's sum.
+// ---------------------------------------------------------------------------------------- cross-lane exchange
+// xor_lane<OFF>(v): the value of lane (id ^ OFF) -- what __shfl_xor(v, OFF) returns, without the LDS crossbar.  hipcc
+// lowers __shfl_xor to ds_bpermute_b32 + s_waitcnt lgkmcnt(0) (~100+ cycles of latency per step, and with a run-time width
+// a loop of them): the per-edge chains of the backward kernels carried 15 such round trips per edge trip.  On gfx950 every
+// power-of-two exchange has a VALU form: quad_perm (1, 2), a row_shl / row_shr pair under bank masks (4), row_ror:8 (8),
+// v_permlane16_swap / v_permlane32_swap (16, 32).  Same values as the shuffle: sums built on it keep their bits.
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+template <int OFF>
+__device__ __forceinline__ float xor_lane(float v) {
+    static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8 || OFF == 16 || OFF == 32, "power of two below the wave size");
+    const int x = __float_as_int(v);
+    if constexpr (OFF == 1) return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true));       // quad_perm:[1,0,3,2]
+    else if constexpr (OFF == 2) return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true));  // quad_perm:[2,3,0,1]
+    else if constexpr (OFF == 4) {
+        const int t = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xf, 0x5, false);        // row_shl:4 -> lanes 0-3, 8-11 of a row read lane + 4
+        return __int_as_float(__builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false));   // row_shr:4 -> lanes 4-7, 12-15 read lane - 4
+    } else if constexpr (OFF == 8) return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, true));   // row_ror:8
+    else if constexpr (OFF == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);   // r[0] = even rows twice, r[1] = odd rows twice
+        return __int_as_float((int)((lane_id() & 16) ? r[0] : r[1]));
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);   // r[0] = lower half twice, r[1] = upper half twice
+        return __int_as_float((int)((lane_id() & 32) ? r[0] : r[1]));
+    }
+}
+// v + xor_lane<OFF>(v) (commutative: the swap forms need no select)
+template <int OFF>
+__device__ __forceinline__ float xor_add(float v) {
+    if constexpr (OFF == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return (lane_id() & 16) ? __uint_as_float(r[1]) + __uint_as_float(r[0]) : __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else if constexpr (OFF == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return (lane_id() & 32) ? __uint_as_float(r[1]) + __uint_as_float(r[0]) : __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else return v + xor_lane<OFF>(v);
+}
+
+// Sum over aligned groups of `width` lanes (power of two, <= 64, wave-uniform); every lane gets its group's sum.
 __device__ __forceinline__ float group_sum(float v, int width) {
-    for (int o = 1; o < width; o <<= 1) v += __shfl_xor(v, o, GN_WAVE);
+    if (width > 1) v = xor_add<1>(v);
+    if (width > 2) v = xor_add<2>(v);
+    if (width > 4) v = xor_add<4>(v);
+    if (width > 8) v = xor_add<8>(v);
+    if (width > 16) v = xor_add<16>(v);
+    if (width > 32) v = xor_add<32>(v);
     return v;
 }
 // Sum over the lanes of a slot and store, for slots that may be WIDER than a wave (F = 512 / 1024: 128 / 256 lanes per
@@ -148,39 +190,78 @@ __device__ __forceinline__ void slot_sum_store(float v, int lps, int lp, float* 
 }
 
 // Sum K values (K a power of two, K <= width) over aligned groups of `width` lanes with a
-// value-halving butterfly: ~K + log2(width) shuffles instead of K log2(width).  On return the lane
+// value-halving butterfly: ~K + log2(width) exchanges instead of K log2(width).  On return the lane
 // whose in-group index lp satisfies lp % (width / K) == 0 holds the total of value lp / (width / K) in v[0].
 // (every register index below is a compile-time constant: a formulation with a run-time trip count made the
 //  compiler index v[] dynamically -- a 16-way v_cmp/v_cndmask chain per element, ~900 VALU instructions per edge.)
-template <int LIVE, int K>
-__device__ __forceinline__ void mgs_halve(float (&v)[K], int off, int lp) {   // LIVE live values -> LIVE / 2
-    const bool up = (lp & off) != 0;
+template <int LIVE, int OFF, int K>
+__device__ __forceinline__ void mgs_halve(float (&v)[K], int lp) {   // LIVE live values -> LIVE / 2, partner = lane ^ OFF
 #pragma unroll
     for (int i = 0; i < LIVE / 2; ++i) {
         const float a = v[i], b = v[i + LIVE / 2];
-        const float keep = up ? b : a;
-        const float send = up ? a : b;
-        v[i] = keep + __shfl_xor(send, off, GN_WAVE);
+        if constexpr (OFF == 32 || OFF == 16) {
+            // lower lanes keep a and need the partner's a, upper lanes keep b and need the partner's b: ONE two-register swap
+            // puts each lane's kept value in one result and the received one in the other (keep + received, as below)
+            const auto r = OFF == 32 ? __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false)
+                                     : __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+            v[i] = (lp & OFF) ? __uint_as_float(r[1]) + __uint_as_float(r[0]) : __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        } else {
+            const bool up = (lp & OFF) != 0;
+            const float keep = up ? b : a;
+            const float send = up ? a : b;
+            v[i] = keep + xor_lane<OFF>(send);
+        }
     }
 }
+template <int K, int W>
+__device__ __forceinline__ void multi_group_sum_w(float (&v)[K], int lp) {   // compile-time group width W >= K
+    if constexpr (K >= 32) mgs_halve<32, W / 2>(v, lp);
+    if constexpr (K >= 16) mgs_halve<16, (W >> 1) / (K >= 32 ? 2 : 1)>(v, lp);
+    if constexpr (K >= 8) mgs_halve<8, (W >> 1) / (K >= 32 ? 4 : (K >= 16 ? 2 : 1))>(v, lp);
+    if constexpr (K >= 4) mgs_halve<4, (W >> 1) / (K >= 32 ? 8 : (K >= 16 ? 4 : (K >= 8 ? 2 : 1)))>(v, lp);
+    mgs_halve<2, W / K>(v, lp);
+    // the remaining in-group sum over W / K lanes
+    if constexpr (W / K > 32) v[0] = xor_add<32>(v[0]);
+    if constexpr (W / K > 16) v[0] = xor_add<16>(v[0]);
+    if constexpr (W / K > 8) v[0] = xor_add<8>(v[0]);
+    if constexpr (W / K > 4) v[0] = xor_add<4>(v[0]);
+    if constexpr (W / K > 2) v[0] = xor_add<2>(v[0]);
+    if constexpr (W / K > 1) v[0] = xor_add<1>(v[0]);
+}
 template <int K>
-__device__ __forceinline__ void multi_group_sum(float (&v)[K], int width, int lp) {   // requires width >= K
+__device__ __forceinline__ void multi_group_sum(float (&v)[K], int width, int lp) {   // requires width >= K (wave-uniform)
     static_assert(K == 2 || K == 4 || K == 8 || K == 16 || K == 32, "K must be a power of two <= 32");
-    int off = width >> 1;
-    if constexpr (K >= 32) { mgs_halve<32>(v, off, lp); off >>= 1; }
-    if constexpr (K >= 16) { mgs_halve<16>(v, off, lp); off >>= 1; }
-    if constexpr (K >= 8) { mgs_halve<8>(v, off, lp); off >>= 1; }
-    if constexpr (K >= 4) { mgs_halve<4>(v, off, lp); off >>= 1; }
-    mgs_halve<2>(v, off, lp);
-    for (off >>= 1; off > 0; off >>= 1) v[0] += __shfl_xor(v[0], off, GN_WAVE);
+    if (width == 64) { multi_group_sum_w<K, 64>(v, lp); return; }
+    if constexpr (K <= 32) if (width == 32) { multi_group_sum_w<K, 32>(v, lp); return; }
+    if constexpr (K <= 16) if (width == 16) { multi_group_sum_w<K, 16>(v, lp); return; }
+    if constexpr (K <= 8) if (width == 8) { multi_group_sum_w<K, 8>(v, lp); return; }
+    if constexpr (K <= 4) if (width == 4) { multi_group_sum_w<K, 4>(v, lp); return; }
+    if constexpr (K <= 2) if (width == 2) { multi_group_sum_w<K, 2>(v, lp); return; }
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-    for (int o = 1; o < GN_WAVE; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, GN_WAVE));
+    v = fmaxf(v, xor_lane<1>(v)); v = fmaxf(v, xor_lane<2>(v)); v = fmaxf(v, xor_lane<4>(v));
+    v = fmaxf(v, xor_lane<8>(v)); v = fmaxf(v, xor_lane<16>(v)); v = fmaxf(v, xor_lane<32>(v));
     return v;
 }
-__device__ __forceinline__ float wave_sum(float v) {
-    for (int o = 1; o < GN_WAVE; o <<= 1) v += __shfl_xor(v, o, GN_WAVE);
+__device__ __forceinline__ float wave_sum(float v) { return group_sum(v, GN_WAVE); }
+// reductions over the lanes that share (lane % stride): the exchanges at offsets stride, 2 stride, ..., 32 (stride a power of two)
+__device__ __forceinline__ float stride_sum(float v, int stride) {
+    if (stride <= 1) v = xor_add<1>(v);
+    if (stride <= 2) v = xor_add<2>(v);
+    if (stride <= 4) v = xor_add<4>(v);
+    if (stride <= 8) v = xor_add<8>(v);
+    if (stride <= 16) v = xor_add<16>(v);
+    if (stride <= 32) v = xor_add<32>(v);
+    return v;
+}
+__device__ __forceinline__ float stride_max(float v, int stride) {
+    if (stride <= 1) v = fmaxf(v, xor_lane<1>(v));
+    if (stride <= 2) v = fmaxf(v, xor_lane<2>(v));
+    if (stride <= 4) v = fmaxf(v, xor_lane<4>(v));
+    if (stride <= 8) v = fmaxf(v, xor_lane<8>(v));
+    if (stride <= 16) v = fmaxf(v, xor_lane<16>(v));
+    if (stride <= 32) v = fmaxf(v, xor_lane<32>(v));
     return v;
 }
 

@@ -148,14 +148,14 @@ __device__ __forceinline__ void attn_softmax_wave_body(
     // per-head max and sum over the strip; lane's head = lane % H in every pass
     float mx = -INFINITY;
     for (int idx = lane; idx < n; idx += 64) mx = fmaxf(mx, S[idx]);
-    for (int o = H; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mx = stride_max(mx, H);
     float sm = 0.f;
     for (int idx = lane; idx < n; idx += 64) {
         const float ex = fast_exp(S[idx] - mx);
         S[idx] = ex;
         sm += ex;
     }
-    for (int o = H; o < 64; o <<= 1) sm += __shfl_xor(sm, o, 64);
+    sm = stride_sum(sm, H);
     const float rsm = __builtin_amdgcn_rcpf(sm + 1e-16f);
     if constexpr (!IN_LDS) __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
