@@ -28,21 +28,21 @@ namespace gn {
 // degree-sliced kernels of gn_highl.hip, which carry the kind as a run-time value.
 // =========================================================================== HTR backward
 // w = sum_l [ A.B - (2 - r.r)(A.r)(B.r) ],  A = EQ_i block, B = EK_j block, r = rl block
-template <int LMAX>
+template <int LMAX, int FC = 0>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT) void htr_bwd_target_kernel(
     const float* __restrict__ gtp, const float* __restrict__ pre_t, const float* __restrict__ w,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
-    const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F,
+    const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F_rt,
     float* __restrict__ gEQ, float* __restrict__ g_rl, float* __restrict__ g_pre_t, int /* act: GN_ACT_SILU on this path, see gn_htr_backward */) {
     constexpr int act = GN_ACT_SILU;
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int KP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));
     constexpr int CH = D < 9 ? D : 9;
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
+    const int F = FC ? FC : F_rt;
     const int i = xcd_item(blockIdx.x, N);
     if (i < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
+    GN_SLOT_GEOMETRY(FC);
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
     float4 eq[D], acc[D];
 #pragma unroll
@@ -101,20 +101,20 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT) void htr_bwd_target_kerne
     reduce_rows<D>(acc, red, slot, c0, F, ns, [&](int row, float4 s) { st4(gEQ + ((size_t)i * D + row) * F + c0, s); });
 }
 
-template <int LMAX>
+template <int LMAX, int FC = 0>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_SRC) void htr_bwd_source_kernel(
     const float* __restrict__ gtp, const float* __restrict__ pre_t,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
-    const int* __restrict__ colptr, const int* __restrict__ perm, const int* __restrict__ dst, int N, int F,
+    const int* __restrict__ colptr, const int* __restrict__ perm, const int* __restrict__ dst, int N, int F_rt,
     float* __restrict__ gEK, int /* act: GN_ACT_SILU on this path, see gn_htr_backward */) {
     constexpr int act = GN_ACT_SILU;
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int CH = D < 9 ? D : 9;
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
+    const int F = FC ? FC : F_rt;
     const int j = xcd_item(blockIdx.x, N);
     if (j < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    GN_SLOT_GEOMETRY(FC);
     const int p0 = colptr[j], p1 = colptr[j + 1];
     float4 ek[D], acc[D];
 #pragma unroll
@@ -172,16 +172,15 @@ struct MsgShape {
 constexpr int GS_CAP = 2048;
 // FIRST: X_in is identically zero (first interaction): every tensor-gate term vanishes -- those blocks of eproj / x / v
 // are not read, their g_eproj columns not written (the W_e^T product that follows takes the K-prefix).
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, bool GS_LDS, bool FIRST>
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, bool GS_LDS, bool FIRST, int FC>
 __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, float* gsl, float* red, float* hsum, const float* __restrict__ x_, const float* __restrict__ v_, const float* __restrict__ eproj_, const float* __restrict__ a_, const float* __restrict__ qk_, const float* __restrict__ X_in_, const float* __restrict__ rl_, const float* __restrict__ cut_, const int* __restrict__ outdeg_, const float* __restrict__ g_h1_, const float* __restrict__ g_X1_, const int* __restrict__ rowptr_, const int* __restrict__ src_, float* __restrict__ g_eproj_, float* __restrict__ g_s_, float* __restrict__ g_nproj_, float* __restrict__ g_rl_, float* __restrict__ g_cut_) {
     using S = MsgShape<LMAX, SEP_DIR, SEP_TENSOR>;
     constexpr int D = S::D, M = S::M;
     constexpr int KP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));      // D rl sums, padded to a power of two
-    const int N = p.N, F = p.F, H = p.H;
+    const int N = p.N, F = FC ? FC : p.F, H = p.H;
     const int i = xcd_item(blockIdx.x, N);
     if (i < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
+    GN_SLOT_GEOMETRY(FC);
     const int e0 = rowptr_[i], e1 = rowptr_[i + 1];
     const int per_head = (M * F) / H;
     int hb[M];
@@ -327,7 +326,7 @@ __device__ __forceinline__ void msg_bwd_target_body(const MsgBwdArgs& p, float* 
     if (slot == 0) st4(g_nproj_ + (size_t)i * p.ldn + c0, red4(red, c0, F, ns));
 }
 
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, bool FIRST = false>
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, bool FIRST = false, int FC = 0>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_TGT) void msg_bwd_target_kernel(const MsgBwdArgs p) {
     __shared__ __attribute__((aligned(16))) float red[1024];
     __shared__ float hsum[256 * MsgShape<LMAX, SEP_DIR, SEP_TENSOR>::M];
@@ -335,14 +334,14 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_TGT) void msg_bwd_target_kerne
     const int i = xcd_item(blockIdx.x, p.N);
     if (i < 0) return;
     if ((p.rowptr[i + 1] - p.rowptr[i]) * p.H <= GS_CAP)      // workgroup-uniform, decided once
-        msg_bwd_target_body<LMAX, SEP_DIR, SEP_TENSOR, true, FIRST>(p, gsl, red, hsum, p.x, p.v, p.eproj, p.a, p.qk, p.X_in, p.rl, p.cut, p.outdeg, p.g_h1, p.g_X1, p.rowptr, p.src, p.g_eproj, p.g_s, p.g_nproj, p.g_rl, p.g_cut);
+        msg_bwd_target_body<LMAX, SEP_DIR, SEP_TENSOR, true, FIRST, FC>(p, gsl, red, hsum, p.x, p.v, p.eproj, p.a, p.qk, p.X_in, p.rl, p.cut, p.outdeg, p.g_h1, p.g_X1, p.rowptr, p.src, p.g_eproj, p.g_s, p.g_nproj, p.g_rl, p.g_cut);
     else
-        msg_bwd_target_body<LMAX, SEP_DIR, SEP_TENSOR, false, FIRST>(p, gsl, red, hsum, p.x, p.v, p.eproj, p.a, p.qk, p.X_in, p.rl, p.cut, p.outdeg, p.g_h1, p.g_X1, p.rowptr, p.src, p.g_eproj, p.g_s, p.g_nproj, p.g_rl, p.g_cut);
+        msg_bwd_target_body<LMAX, SEP_DIR, SEP_TENSOR, false, FIRST, FC>(p, gsl, red, hsum, p.x, p.v, p.eproj, p.a, p.qk, p.X_in, p.rl, p.cut, p.outdeg, p.g_h1, p.g_X1, p.rowptr, p.src, p.g_eproj, p.g_s, p.g_nproj, p.g_rl, p.g_cut);
 }
 
 // by-source pass: g_x, g_v, g_k, and g_X (tensor-gate path) of the gathered source rows
 // FIRST (X_in == 0): no g_X rows (nothing consumes the gradient of a constant), tensor-gate blocks of g_x / g_v are zero
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, bool FIRST = false>
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, bool FIRST = false, int FC = 0>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kernel(const MsgBwdArgs p) {
     using S = MsgShape<LMAX, SEP_DIR, SEP_TENSOR>;
     constexpr int D = S::D, M = S::M;
@@ -350,11 +349,10 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kerne
     constexpr int ROWS = 2 * M + XD + 1;
     constexpr int CH = ROWS < 9 ? ROWS : 9;
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
-    const int N = p.N, F = p.F, H = p.H;
+    const int N = p.N, F = FC ? FC : p.F, H = p.H;
     const int j = xcd_item(blockIdx.x, N);
     if (j < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    GN_SLOT_GEOMETRY(FC);
     const int p0 = p.colptr[j], p1 = p.colptr[j + 1];
     const int per_head = (M * F) / H;
     const int hq = c0 / (F / H);
@@ -428,7 +426,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kerne
 // g_X (per source) -- leaves this kernel; t_filter is read ONCE (the two-kernel form reads it in both passes: 1.50 x the
 // algorithmic traffic).  The softmax / scores backward then runs by target (attn_bwd_kernel, as in the degree-group form)
 // and g_k by source (msg_bwd_gk_kernel).  lmax <= 2, general launches (X_in != NULL), SiLU.
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR>
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int FC = 0>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG) void msg_bwd_merged_kernel(const MsgBwdArgs p, float* __restrict__ ga) {
     using S = MsgShape<LMAX, SEP_DIR, SEP_TENSOR>;
     constexpr int D = S::D, M = S::M;
@@ -437,11 +435,10 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG) void msg_bwd_merged_kerne
     constexpr int CH = ROWS < 9 ? ROWS : 9;
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
     __shared__ float hsum[256 * M];
-    const int N = p.N, F = p.F, H = p.H;
+    const int N = p.N, F = FC ? FC : p.F, H = p.H;
     const int j = xcd_item(blockIdx.x, N);
     if (j < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
+    GN_SLOT_GEOMETRY(FC);
     const int p0 = p.colptr[j], p1 = p.colptr[j + 1];
     const int per_head = (M * F) / H;
     int hb[M];
@@ -538,13 +535,13 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG) void msg_bwd_merged_kerne
 }
 
 // g_k of the gathered source rows, after the softmax backward:  g_k_j = sum_e g_s[e, head] q_i SiLU(t_attn pre-activation)
+template <int FC = 0>
 __global__ __launch_bounds__(256) void msg_bwd_gk_kernel(const MsgBwdArgs p) {
     __shared__ __attribute__((aligned(16))) float red[1024];
-    const int N = p.N, F = p.F, H = p.H;
+    const int N = p.N, F = FC ? FC : p.F, H = p.H;
     const int j = xcd_item(blockIdx.x, N);
     if (j < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    GN_SLOT_GEOMETRY(FC);
     const int hq = c0 / (F / H);
     float4 gk[1] = {zero4()};
     for (int pp = p.colptr[j] + slot; pp < p.colptr[j + 1]; pp += ns) {
@@ -564,12 +561,11 @@ __global__ __launch_bounds__(256) void msg_bwd_gk_kernel(const MsgBwdArgs p) {
 // backward launch (softmax backward needs the head sums of ALL groups) and one for g_k.
 // Value blocks: 0 scalar, l direction gate, LMAX + l tensor gate.
 // softmax backward over the summed head gradients of all groups, then scores backward (g_ta, g_q)
-template <bool GS_LDS>
+template <bool GS_LDS, int FC>
 __device__ __forceinline__ void attn_bwd_body(const MsgBwdArgs& p, const float* __restrict__ ga_parts, int G, size_t gstride,
                                               float* red, float* gsl, int i) {
-    const int F = p.F, H = p.H;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    const int F = FC ? FC : p.F, H = p.H;
+    GN_SLOT_GEOMETRY(FC);
     const int e0 = p.rowptr[i], e1 = p.rowptr[i + 1];
     auto GS = [&](int e, int h) -> float& {
         if constexpr (GS_LDS) return gsl[(e - e0) * H + h];
@@ -614,18 +610,19 @@ __device__ __forceinline__ void attn_bwd_body(const MsgBwdArgs& p, const float* 
     __syncthreads();
     if (slot == 0) st4(p.g_nproj + (size_t)i * p.ldn + c0, red4(red, c0, F, ns));
 }
+template <int FC = 0>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const MsgBwdArgs p, const float* __restrict__ ga_parts, int G, size_t gstride) {
     __shared__ __attribute__((aligned(16))) float red[1024];
     __shared__ float gsl[GS_CAP];
     const int i = xcd_item(blockIdx.x, p.N);
     if (i < 0) return;
-    if ((p.rowptr[i + 1] - p.rowptr[i]) * p.H <= GS_CAP) attn_bwd_body<true>(p, ga_parts, G, gstride, red, gsl, i);
-    else attn_bwd_body<false>(p, ga_parts, G, gstride, red, gsl, i);
+    if ((p.rowptr[i + 1] - p.rowptr[i]) * p.H <= GS_CAP) attn_bwd_body<true, FC>(p, ga_parts, G, gstride, red, gsl, i);
+    else attn_bwd_body<false, FC>(p, ga_parts, G, gstride, red, gsl, i);
 }
 
 // degree-group form of msg_bwd_merged_kernel: the by-source pass of a group with the group's per-edge work merged in
 // (g_tf of its blocks, its cut slice, its g_rl rows, its slice of the head sums); g_k is left to msg_bwd_gk_kernel.
-template <int LMAX, int LLO, int LHI, bool SCALAR>
+template <int LMAX, int LLO, int LHI, bool SCALAR, int FC = 0>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG_G) void msg_bwd_merged_group_kernel(const MsgBwdArgs p, float* __restrict__ ga_slice,
                                                                                        float* __restrict__ cut_slice) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
@@ -637,11 +634,10 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG_G) void msg_bwd_merged_gro
     constexpr int CH = ROWS < 9 ? ROWS : 9;
     constexpr int KP = (XR + 8) <= 16 ? 16 : 32;
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
-    const int N = p.N, F = p.F, H = p.H;
+    const int N = p.N, F = FC ? FC : p.F, H = p.H;
     const int j = xcd_item(blockIdx.x, N);
     if (j < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
+    GN_SLOT_GEOMETRY(FC);
     const int p0 = p.colptr[j], p1 = p.colptr[j + 1];
     const int per_head = (M * F) / H;
     auto vblock = [&](int k) { return SCALAR ? (k == 0 ? 0 : (k <= NL ? LLO + k - 1 : LMAX + LLO + k - 1 - NL))
@@ -735,11 +731,11 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG_G) void msg_bwd_merged_gro
 }
 
 // HTR backward per degree group (w = sum_l w_l: the degrees are independent)
-template <int LMAX, int LLO, int LHI, bool FIRST>
+template <int LMAX, int LLO, int LHI, bool FIRST, int FC = 0>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT_G) void htr_bwd_target_group_kernel(
     const float* __restrict__ gtp, const float* __restrict__ pre_t, const float* __restrict__ w,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
-    const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F,
+    const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F_rt,
     float* __restrict__ gEQ, float* __restrict__ g_rl, float* __restrict__ g_pre_t, int /* act: GN_ACT_SILU on this path, see gn_htr_backward */) {
     constexpr int act = GN_ACT_SILU;
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
@@ -747,10 +743,10 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT_G) void htr_bwd_target_gro
     constexpr int KP = XR <= 4 ? 4 : (XR <= 8 ? 8 : 16);
     constexpr int CH = XR < 9 ? XR : 9;
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
+    const int F = FC ? FC : F_rt;
     const int i = xcd_item(blockIdx.x, N);
     if (i < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
+    GN_SLOT_GEOMETRY(FC);
     float4 eq[XR], acc[XR];
 #pragma unroll
     for (int m = 0; m < XR; ++m) { eq[m] = ld4(EQ + ((size_t)i * D + M0 + m) * F + c0); acc[m] = zero4(); }
@@ -803,21 +799,21 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_TGT_G) void htr_bwd_target_gro
     reduce_rows<XR>(acc, red, slot, c0, F, ns, [&](int row, float4 sv) { st4(gEQ + ((size_t)i * D + M0 + row) * F + c0, sv); });
 }
 
-template <int LMAX, int LLO, int LHI>
+template <int LMAX, int LLO, int LHI, int FC = 0>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_SRC_G) void htr_bwd_source_group_kernel(
     const float* __restrict__ gtp, const float* __restrict__ pre_t,
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
-    const int* __restrict__ colptr, const int* __restrict__ perm, const int* __restrict__ dst, int N, int F,
+    const int* __restrict__ colptr, const int* __restrict__ perm, const int* __restrict__ dst, int N, int F_rt,
     float* __restrict__ gEK, int /* act: GN_ACT_SILU on this path, see gn_htr_backward */) {
     constexpr int act = GN_ACT_SILU;
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int XR = (LHI + 1) * (LHI + 1) - LLO * LLO, M0 = LLO * LLO - 1;
     constexpr int CH = XR < 9 ? XR : 9;
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
+    const int F = FC ? FC : F_rt;
     const int j = xcd_item(blockIdx.x, N);
     if (j < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    GN_SLOT_GEOMETRY(FC);
     float4 acc[XR];
 #pragma unroll
     for (int m = 0; m < XR; ++m) acc[m] = zero4();
@@ -897,8 +893,7 @@ __global__ __launch_bounds__(256) void edge_init_bwd_kernel(
     __shared__ __attribute__((aligned(16))) float red[1024];
     const int i = xcd_item(blockIdx.x, N);
     if (i < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    GN_SLOT_GEOMETRY(0);
     const float4 hi = ld4(h + (size_t)i * F + c0);
     float4 acc = zero4();
     for (int e = rowptr[i] + slot; e < rowptr[i + 1]; e += ns) {
@@ -927,8 +922,7 @@ __global__ __launch_bounds__(256) void node_init_bwd_kernel(
     float* __restrict__ g_feat, float* __restrict__ g_cut) {
     const int i = xcd_item(blockIdx.x, N);
     if (i < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, lp = threadIdx.x % lps, c0 = lp * 4;
+    GN_SLOT_GEOMETRY(0);
     const float4 gmi = ld4(g_ctx + (size_t)i * 2 * F + F + c0);
     for (int e = rowptr[i] + slot; e < rowptr[i + 1]; e += ns) {
         const int j = src[e];
@@ -1197,45 +1191,56 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
         return gn_htr_backward_general(g_t_out, pre_t, w, w_raw, EQ, EK, rl, rowptr, src, dst, colptr, perm, N, F, lmax,
                                        mode, gEQ, gEK, g_rl, g_pre_t, act, st);
     const dim3 grid(gn::xcd_grid(N)), block(256);
-#define GN_HTRB_T(L, LLO, LHI, FIRST)                                                                            \
-    hipLaunchKernelGGL((gn::htr_bwd_target_group_kernel<L, LLO, LHI, FIRST>), grid, block, 0, st, g_t_out, pre_t, w, \
+#define GN_HTRB_T(L, LLO, LHI, FIRST, FC)                                                                        \
+    hipLaunchKernelGGL((gn::htr_bwd_target_group_kernel<L, LLO, LHI, FIRST, FC>), grid, block, 0, st, g_t_out, pre_t, w, \
                        EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl, g_pre_t, act)
-#define GN_HTRB_S(L, LLO, LHI)                                                                                   \
-    hipLaunchKernelGGL((gn::htr_bwd_source_group_kernel<L, LLO, LHI>), grid, block, 0, st, g_t_out, pre_t, EQ, EK, \
+#define GN_HTRB_S(L, LLO, LHI, FC)                                                                               \
+    hipLaunchKernelGGL((gn::htr_bwd_source_group_kernel<L, LLO, LHI, FC>), grid, block, 0, st, g_t_out, pre_t, EQ, EK, \
                        rl, colptr, perm, dst, N, F, gEK, act)
-#define GN_HTRB(L, LLO, LHI, FIRST) GN_HTRB_T(L, LLO, LHI, FIRST); GN_HTRB_S(L, LLO, LHI)
-    if (lmax <= 2) {
-        GN_SWITCH_LMAX(htr_bwd_target_kernel, grid, block, st, g_t_out, pre_t, w, EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl, g_pre_t, act);
-        GN_LAUNCH_CHECK();
-        GN_SWITCH_LMAX(htr_bwd_source_kernel, grid, block, st, g_t_out, pre_t, EQ, EK, rl, colptr, perm, dst, N, F, gEK, act);
-    } else if (lmax == 3) {
-        GN_HTRB(3, 1, 2, true); GN_HTRB(3, 3, 3, false);
-    } else {
-        GN_HTRB(4, 1, 2, true);
-        GN_HTRB_T(4, 3, 3, false); GN_HTRB_T(4, 4, 4, false);
-        GN_HTRB_S(4, 3, 3); GN_HTRB_S(4, 4, 4);
+#define GN_HTRB(L, LLO, LHI, FIRST, FC) GN_HTRB_T(L, LLO, LHI, FIRST, FC); GN_HTRB_S(L, LLO, LHI, FC)
+    // F == 256: the instantiations with the width as a compile-time constant and wave-uniform slots (gn_common.h GN_SLOT_GEOMETRY)
+#define GN_HTRB_ALL(FC)                                                                                          \
+    if (lmax == 1) {                                                                                             \
+        hipLaunchKernelGGL((gn::htr_bwd_target_kernel<1, FC>), grid, block, 0, st, g_t_out, pre_t, w, EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl, g_pre_t, act); \
+        hipLaunchKernelGGL((gn::htr_bwd_source_kernel<1, FC>), grid, block, 0, st, g_t_out, pre_t, EQ, EK, rl, colptr, perm, dst, N, F, gEK, act); \
+    } else if (lmax == 2) {                                                                                      \
+        hipLaunchKernelGGL((gn::htr_bwd_target_kernel<2, FC>), grid, block, 0, st, g_t_out, pre_t, w, EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl, g_pre_t, act); \
+        hipLaunchKernelGGL((gn::htr_bwd_source_kernel<2, FC>), grid, block, 0, st, g_t_out, pre_t, EQ, EK, rl, colptr, perm, dst, N, F, gEK, act); \
+    } else if (lmax == 3) {                                                                                      \
+        GN_HTRB(3, 1, 2, true, FC); GN_HTRB(3, 3, 3, false, FC);                                                 \
+    } else {                                                                                                     \
+        GN_HTRB(4, 1, 2, true, FC);                                                                              \
+        GN_HTRB_T(4, 3, 3, false, FC); GN_HTRB_T(4, 4, 4, false, FC);                                            \
+        GN_HTRB_S(4, 3, 3, FC); GN_HTRB_S(4, 4, 4, FC);                                                          \
     }
+    if (F == 256) { GN_HTRB_ALL(256) } else { GN_HTRB_ALL(0) }
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
 
 // X_in == NULL: the zero-X_in instantiations (one target + one source launch at every lmax <= 4: without the tensor-gate
 // rows the register budget that forces the degree groups is gone; g_cut then uses ONE slice, the caller zeroes the rest)
-#define GN_MSGB_LAUNCH(L, SD, ST)                                                                        \
+#define GN_MSGB_LAUNCH_FC(L, SD, ST, FC)                                                                 \
     do {                                                                                                  \
         if (!X_in) {                                                                                      \
-            hipLaunchKernelGGL((gn::msg_bwd_target_kernel<L, SD, ST, true>), grid, block, 0, st, p);      \
-            hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST, true>), grid, block, 0, st, p);      \
+            hipLaunchKernelGGL((gn::msg_bwd_target_kernel<L, SD, ST, true, FC>), grid, block, 0, st, p);  \
+            hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST, true, FC>), grid, block, 0, st, p);  \
             break;                                                                                        \
         }                                                                                                 \
         if (GN_MSGB_MERGED && ga_parts != nullptr) {     /* general launches: t_filter read once (gn_tune.h) */ \
-            hipLaunchKernelGGL((gn::msg_bwd_merged_kernel<L, SD, ST>), grid, block, 0, st, p, ga_parts);  \
-            hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, 1, (size_t)0);       \
-            hipLaunchKernelGGL(gn::msg_bwd_gk_kernel, grid, block, 0, st, p);                             \
+            hipLaunchKernelGGL((gn::msg_bwd_merged_kernel<L, SD, ST, FC>), grid, block, 0, st, p, ga_parts); \
+            hipLaunchKernelGGL(gn::attn_bwd_kernel<FC>, grid, block, 0, st, p, ga_parts, 1, (size_t)0);   \
+            hipLaunchKernelGGL(gn::msg_bwd_gk_kernel<FC>, grid, block, 0, st, p);                         \
             break;                                                                                        \
         }                                                                                                 \
         hipLaunchKernelGGL((gn::msg_bwd_target_kernel<L, SD, ST>), grid, block, 0, st, p);                \
         hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST>), grid, block, 0, st, p);                \
+    } while (0)
+#define GN_MSGB_LAUNCH(L, SD, ST) GN_MSGB_LAUNCH_FC(L, SD, ST, 0)
+// the reference's defaults (sep_dir, sep_tensor) at F = 256: the compile-time-width instantiations
+#define GN_MSGB_LAUNCH_DEFAULT(L)                                                                        \
+    do {                                                                                                  \
+        if (F == 256) GN_MSGB_LAUNCH_FC(L, true, true, 256); else GN_MSGB_LAUNCH_FC(L, true, true, 0);    \
     } while (0)
 
 extern "C" int gn_message_backward_groups(int lmax_arg, int sep_dir, int sep_tensor, int act) {
@@ -1270,33 +1275,37 @@ extern "C" int gn_message_backward(
     if (X_in && gn_message_backward_groups(lmax_arg, sep_dir, sep_tensor, act) > 1) {
         if (ga_parts == nullptr || E <= 0) return GN_ERR_BAD_ARG;
         const size_t gs = (size_t)E * H;
-#define GN_MSGB_M(L, LLO, LHI, SC, G)                                                                        \
-    hipLaunchKernelGGL((gn::msg_bwd_merged_group_kernel<L, LLO, LHI, SC>), grid, block, 0, st, p,            \
+#define GN_MSGB_M(L, LLO, LHI, SC, G, FC)                                                                    \
+    hipLaunchKernelGGL((gn::msg_bwd_merged_group_kernel<L, LLO, LHI, SC, FC>), grid, block, 0, st, p,        \
                        ga_parts + (size_t)(G) * gs, g_cut + (size_t)(G) * E)
         // by-source group kernels with the per-edge work merged in (t_filter read once; head sums and cut slices per group)
         // -> attention backward over the summed head gradients -> g_k
-        if (lmax == 3) { GN_MSGB_M(3, 1, 2, true, 0); GN_MSGB_M(3, 3, 3, false, 1); }
-        else { GN_MSGB_M(4, 1, 2, true, 0); GN_MSGB_M(4, 3, 3, false, 1); GN_MSGB_M(4, 4, 4, false, 2); }
-        hipLaunchKernelGGL(gn::attn_bwd_kernel, grid, block, 0, st, p, ga_parts, lmax - 1, gs);
-        hipLaunchKernelGGL(gn::msg_bwd_gk_kernel, grid, block, 0, st, p);
+#define GN_MSGB_GROUPS(FC)                                                                                       \
+        if (lmax == 3) { GN_MSGB_M(3, 1, 2, true, 0, FC); GN_MSGB_M(3, 3, 3, false, 1, FC); }                    \
+        else { GN_MSGB_M(4, 1, 2, true, 0, FC); GN_MSGB_M(4, 3, 3, false, 1, FC); GN_MSGB_M(4, 4, 4, false, 2, FC); } \
+        hipLaunchKernelGGL(gn::attn_bwd_kernel<FC>, grid, block, 0, st, p, ga_parts, lmax - 1, gs);              \
+        hipLaunchKernelGGL(gn::msg_bwd_gk_kernel<FC>, grid, block, 0, st, p);
+        if (F == 256) { GN_MSGB_GROUPS(256) } else { GN_MSGB_GROUPS(0) }
         GN_LAUNCH_CHECK();
         return GN_OK;
     }
     const int key = lmax * 4 + (sep_dir ? 2 : 0) + (sep_tensor ? 1 : 0);
     switch (key) {
-        case 4: case 5: case 6: case 7: GN_MSGB_LAUNCH(1, false, false); break;
+        case 4: case 5: case 6: case 7:
+            if (F == 256) GN_MSGB_LAUNCH_FC(1, false, false, 256); else GN_MSGB_LAUNCH(1, false, false);
+            break;
         case 8: GN_MSGB_LAUNCH(2, false, false); break;
         case 9: GN_MSGB_LAUNCH(2, false, true); break;
         case 10: GN_MSGB_LAUNCH(2, true, false); break;
-        case 11: GN_MSGB_LAUNCH(2, true, true); break;
+        case 11: GN_MSGB_LAUNCH_DEFAULT(2); break;
         case 12: GN_MSGB_LAUNCH(3, false, false); break;
         case 13: GN_MSGB_LAUNCH(3, false, true); break;
         case 14: GN_MSGB_LAUNCH(3, true, false); break;
-        case 15: GN_MSGB_LAUNCH(3, true, true); break;
+        case 15: GN_MSGB_LAUNCH_DEFAULT(3); break;
         case 16: GN_MSGB_LAUNCH(4, false, false); break;
         case 17: GN_MSGB_LAUNCH(4, false, true); break;
         case 18: GN_MSGB_LAUNCH(4, true, false); break;
-        default: GN_MSGB_LAUNCH(4, true, true); break;
+        default: GN_MSGB_LAUNCH_DEFAULT(4); break;
     }
     GN_LAUNCH_CHECK();
     return GN_OK;

@@ -265,6 +265,16 @@ __device__ __forceinline__ float stride_max(float v, int stride) {
     return v;
 }
 
+// Slot geometry of the per-node kernels (256 threads; an edge row of F floats is covered by lps = F / 4 lanes, ns = 256 / lps
+// rows per trip).  FC = 0: F is a run-time value.  FC = 256 (the reference's width, every benchmarked model): the width is a
+// compile-time constant and a slot IS a wave, so the slot index is wave-uniform (readfirstlane): edge indices, per-edge
+// scalars and row bases become scalar loads and SGPR arithmetic, and every width-dependent branch folds.  Round 5, merged
+// message backward alone: 262 -> 196 us.  Expects `F` in scope (const int F = FC ? FC : <run-time F>).
+#define GN_SLOT_GEOMETRY(FC)                                                                                          \
+    const int lps = F >> 2, ns = 256 / lps;                                                                           \
+    const int slot = (FC) == 256 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)threadIdx.x / lps;  \
+    const int lp = threadIdx.x % lps, c0 = lp * 4
+
 // XCD-aware block -> work-item map.  Blocks are dealt round-robin to the 8 XCDs
 // (block b -> XCD b % 8, observed, speed only); give every XCD a contiguous range of
 // items so the neighbours of a molecule are gathered through ONE L2.

@@ -109,14 +109,15 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_ATTN) void attn_softmax_kernel(
 // (H | 64), so the reductions are log2(64 / H) xor-shuffles, there is no barrier anywhere, and a[] is written once,
 // coalesced.  Targets whose scores exceed the strip use their a[] rows as the strip (same code, same order).
 constexpr int ATTN_W_STRIP = 512;                   // floats per wave: 64 incoming edges at 8 heads
-template <bool IN_LDS, bool ASILU>
+template <bool IN_LDS, bool ASILU, int FC>
 __device__ __forceinline__ void attn_softmax_wave_body(
     const float* __restrict__ q, const float* __restrict__ k, int ldqk, const float* __restrict__ ta, int ldt,
-    const int* __restrict__ src, const int* __restrict__ outdeg, int i, int e0, int e1, int F, int H, float inv_sqrt_f,
+    const int* __restrict__ src, const int* __restrict__ outdeg, int i, int e0, int e1, int F_rt, int H, float inv_sqrt_f,
     float* __restrict__ a, float* sc, int act) {
+    const int F = FC ? FC : F_rt;                   // FC = 256: one edge per step, every index of the walk is wave-uniform
     const int lane = threadIdx.x & 63;
     const int lps = F >> 2, ns = 64 / lps;          // lanes per edge, edges per step
-    const int slot = lane / lps, lp = lane % lps, c0 = lp * 4;
+    const int slot = FC == 256 ? 0 : lane / lps, lp = lane % lps, c0 = lp * 4;
     const int lph = lps / H;                        // lanes per head
     float* const S = IN_LDS ? sc : a + (size_t)e0 * H;            // strip: S[(e - e0) * H + h]
     const int n = (e1 - e0) * H;
@@ -165,7 +166,7 @@ __device__ __forceinline__ void attn_softmax_wave_body(
     }
 }
 
-template <bool ASILU>
+template <bool ASILU, int FC = 0>
 __global__ __launch_bounds__(256) void attn_softmax_wave_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int ldqk,
     const float* __restrict__ ta, int ldt,
@@ -175,16 +176,16 @@ __global__ __launch_bounds__(256) void attn_softmax_wave_kernel(
     const int act = ASILU ? (int)GN_ACT_SILU : act_rt;
     const int grp = xcd_item(blockIdx.x, (N + 3) >> 2);           // four consecutive targets per workgroup, one per wave
     if (grp < 0) return;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = 4 * grp + wave;
     if (i >= N) return;
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
     if (e1 == e0) return;
     float* sc = strips + wave * ATTN_W_STRIP;
     if ((e1 - e0) * H <= ATTN_W_STRIP)
-        attn_softmax_wave_body<true, ASILU>(q, k, ldqk, ta, ldt, src, outdeg, i, e0, e1, F, H, inv_sqrt_f, a, sc, act);
+        attn_softmax_wave_body<true, ASILU, FC>(q, k, ldqk, ta, ldt, src, outdeg, i, e0, e1, F, H, inv_sqrt_f, a, sc, act);
     else
-        attn_softmax_wave_body<false, ASILU>(q, k, ldqk, ta, ldt, src, outdeg, i, e0, e1, F, H, inv_sqrt_f, a, sc, act);
+        attn_softmax_wave_body<false, ASILU, FC>(q, k, ldqk, ta, ldt, src, outdeg, i, e0, e1, F, H, inv_sqrt_f, a, sc, act);
 }
 
 // ------------------------------------------------------------------ K6 message + aggregate (lmax <= 2: one launch)
@@ -193,14 +194,14 @@ __global__ __launch_bounds__(256) void attn_softmax_wave_kernel(
 // FIRST: X_in is identically zero (the first interaction of GotenNet.forward, gotennet.py:992): the tensor-gate blocks
 // of t_filter / x / v and the X_in rows are not read (0 * gate contributes nothing) and X_out = the aggregated update.
 // Same bits as the general kernel on a zero X_in.
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, bool FIRST = false>
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, bool FIRST = false, int FC = 0>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
     const float* __restrict__ x, const float* __restrict__ v, int ldxv,
     const float* __restrict__ tf, int ldt, const float* __restrict__ a,
     const float* __restrict__ rl, const float* __restrict__ cut,
     const int* __restrict__ rowptr, const int* __restrict__ src,
     const float* __restrict__ h_in, const float* __restrict__ X_in,
-    float* __restrict__ h_out, float* __restrict__ X_out, int N, int F, int H) {
+    float* __restrict__ h_out, float* __restrict__ X_out, int N, int F_rt, int H) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int ND = SEP_DIR ? LMAX : 1;
     constexpr int NT = SEP_TENSOR ? LMAX : 1;
@@ -209,10 +210,10 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
     constexpr int CH = ROWS < 9 ? ROWS : 9;         // rows reduced per LDS pass (<= 36 KiB)
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
 
+    const int F = FC ? FC : F_rt;
     const int i = xcd_item(blockIdx.x, N);
     if (i < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    GN_SLOT_GEOMETRY(FC);
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
     const int per_head = (M * F) / H;
 
@@ -287,14 +288,14 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6) void message_aggregate_kernel(
 // (1 + D) accumulator rows are cut into degree groups {scalar,1,2}, {3}, {4} so that every launch
 // keeps <= 9 float4 accumulators per lane (3+ waves/SIMD instead of 2 at 246 VGPRs).  Gates are
 // per degree, so the groups re-read nothing but the per-edge scalars.
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR>
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR, int FC>
 __device__ __forceinline__ void message_aggregate_group_body(
     const float* __restrict__ x, const float* __restrict__ v, int ldxv,
     const float* __restrict__ tf, int ldt, const float* __restrict__ a,
     const float* __restrict__ rl, const float* __restrict__ cut,
     const int* __restrict__ rowptr, const int* __restrict__ src,
     const float* __restrict__ h_in, const float* __restrict__ X_in,
-    float* __restrict__ h_out, float* __restrict__ X_out, int N, int F, int H) {
+    float* __restrict__ h_out, float* __restrict__ X_out, int N, int F_rt, int H) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int ND = SEP_DIR ? LMAX : 1;
     constexpr int NT = SEP_TENSOR ? LMAX : 1;
@@ -305,10 +306,10 @@ __device__ __forceinline__ void message_aggregate_group_body(
     constexpr int CH = ROWS < GN_K6G_CH ? ROWS : GN_K6G_CH;       // rows reduced per LDS pass (4 KiB each)
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
 
+    const int F = FC ? FC : F_rt;
     const int i = xcd_item(blockIdx.x, N);
     if (i < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    GN_SLOT_GEOMETRY(FC);
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
     const int per_head = (M * F) / H;
 
@@ -384,13 +385,13 @@ __device__ __forceinline__ void message_aggregate_group_body(
         float *__restrict__ h_out, float *__restrict__ X_out, int N, int F, int H
 #define GN_MSG_GROUP_PASS x, v, ldxv, tf, ldt, a, rl, cut, rowptr, src, h_in, X_in, h_out, X_out, N, F, H
 // one degree group per launch; the two-degree group {3,4} (16 accumulator rows) gets its own occupancy target
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR>
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR, int FC = 0>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G) void message_aggregate_group_kernel(GN_MSG_GROUP_ARGS) {
-    message_aggregate_group_body<LMAX, SEP_DIR, SEP_TENSOR, LLO, LHI, SCALAR>(GN_MSG_GROUP_PASS);
+    message_aggregate_group_body<LMAX, SEP_DIR, SEP_TENSOR, LLO, LHI, SCALAR, FC>(GN_MSG_GROUP_PASS);
 }
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR>
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int LLO, int LHI, bool SCALAR, int FC = 0>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G34) void message_aggregate_group34_kernel(GN_MSG_GROUP_ARGS) {
-    message_aggregate_group_body<LMAX, SEP_DIR, SEP_TENSOR, LLO, LHI, SCALAR>(GN_MSG_GROUP_PASS);
+    message_aggregate_group_body<LMAX, SEP_DIR, SEP_TENSOR, LLO, LHI, SCALAR, FC>(GN_MSG_GROUP_PASS);
 }
 
 // ------------------------------------------------------------------ K7 HTR edge weights
@@ -403,16 +404,16 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_K6_G34) void message_aggregate_gro
 // of 132 / 3); at lmax 4 the same code LOSES, 105.9 -> 140.4 us at the same 2 waves/SIMD (the literal form keeps all 24 row
 // loads of an edge in flight; the closed form's schedule does not).  LMAX >= GN_HTR_CLOSED_ALL (= 4): the closed form with
 // every row of the edge requested before the first use (a sched_barrier keeps the loads together): 108.4 -> 90 us.
-template <int LMAX>
+template <int LMAX, int FC = 0>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_EDGE) void htr_edge_kernel(
     const float* __restrict__ EQ, const float* __restrict__ EK, const float* __restrict__ rl,
-    const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F, float* __restrict__ w) {
+    const int* __restrict__ rowptr, const int* __restrict__ src, int N, int F_rt, float* __restrict__ w) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr bool CLOSED = LMAX == 3 && GN_HTR_CLOSED;
+    const int F = FC ? FC : F_rt;
     const int i = xcd_item(blockIdx.x, N);
     if (i < 0) return;
-    const int lps = F >> 2, ns = 256 / lps;
-    const int slot = threadIdx.x / lps, c0 = (threadIdx.x % lps) * 4;
+    GN_SLOT_GEOMETRY(FC);
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
     float4 eq[D];
 #pragma unroll
@@ -508,7 +509,10 @@ extern "C" int gn_attn_softmax(const float* q, const float* k, int ldqk, const f
     // builds the workgroup-per-target kernel only, for an A/B: tools/variants.py)
     if (GN_ATTN_WAVE && F <= 256 && H <= 64) {
         const dim3 grid(gn::xcd_grid((N + 3) / 4)), block(256);
-        if (act == GN_ACT_SILU)
+        if (act == GN_ACT_SILU && F == 256)            // width as a compile-time constant (gn_common.h GN_SLOT_GEOMETRY)
+            hipLaunchKernelGGL((gn::attn_softmax_wave_kernel<true, 256>), grid, block, 0, (hipStream_t)stream,
+                               q, k, ldqk, t_attn, ldt, rowptr, src, outdeg, N, F, H, inv_sqrt_f, a, act);
+        else if (act == GN_ACT_SILU)
             hipLaunchKernelGGL(gn::attn_softmax_wave_kernel<true>, grid, block, 0, (hipStream_t)stream,
                                q, k, ldqk, t_attn, ldt, rowptr, src, outdeg, N, F, H, inv_sqrt_f, a, act);
         else
@@ -527,35 +531,41 @@ extern "C" int gn_attn_softmax(const float* q, const float* k, int ldqk, const f
     return GN_OK;
 }
 
-#define GN_MSG_ONE(L, SD, ST, LLO, LHI, SC)                                                                     \
-    hipLaunchKernelGGL((gn::message_aggregate_group_kernel<L, SD, ST, LLO, LHI, SC>), dim3(gn::xcd_grid(N)), dim3(256), \
+#define GN_MSG_ONE(L, SD, ST, LLO, LHI, SC, FC)                                                                 \
+    hipLaunchKernelGGL((gn::message_aggregate_group_kernel<L, SD, ST, LLO, LHI, SC, FC>), dim3(gn::xcd_grid(N)), dim3(256), \
                        0, (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in,      \
                        h_out, X_out, N, F, H)
 // degree groups per lmax: {scalar,1..min(lmax,2)}, {3}, {4} (lmax = 4: {3,4} in one launch, GN_K6_MERGE34)
-#define GN_MSG_MONO(L, SD, ST)                                                                              \
+#define GN_MSG_MONO(L, SD, ST, FC)                                                                          \
     if (X_in)                                                                                                   \
-        hipLaunchKernelGGL((gn::message_aggregate_kernel<L, SD, ST, false>), dim3(gn::xcd_grid(N)), dim3(256), 0, \
+        hipLaunchKernelGGL((gn::message_aggregate_kernel<L, SD, ST, false, FC>), dim3(gn::xcd_grid(N)), dim3(256), 0, \
                            (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in, \
                            h_out, X_out, N, F, H);                                                              \
     else                                                                                                        \
-        hipLaunchKernelGGL((gn::message_aggregate_kernel<L, SD, ST, true>), dim3(gn::xcd_grid(N)), dim3(256), 0,  \
+        hipLaunchKernelGGL((gn::message_aggregate_kernel<L, SD, ST, true, FC>), dim3(gn::xcd_grid(N)), dim3(256), 0,  \
                            (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, h_in, X_in, \
                            h_out, X_out, N, F, H)
-#define GN_MSG_LAUNCH(L, SD, ST)                                          \
+#define GN_MSG_LAUNCH_FC(L, SD, ST, FC)                                   \
     do {                                                                  \
-        if (L <= 2 || !X_in) { GN_MSG_MONO(L, SD, ST); }  /* zero X_in: 1 + D rows of rl * o_d only, one launch */ \
+        if (L <= 2 || !X_in) { GN_MSG_MONO(L, SD, ST, FC); }  /* zero X_in: 1 + D rows of rl * o_d only, one launch */ \
         else {                                                            \
-            GN_MSG_ONE(L, SD, ST, 1, 2, true);                            \
+            GN_MSG_ONE(L, SD, ST, 1, 2, true, FC);                        \
             if constexpr (L >= 4 && GN_K6_MERGE34) {                      \
-                hipLaunchKernelGGL((gn::message_aggregate_group34_kernel<L, SD, ST, 3, 4, false>), dim3(gn::xcd_grid(N)), \
+                hipLaunchKernelGGL((gn::message_aggregate_group34_kernel<L, SD, ST, 3, 4, false, FC>), dim3(gn::xcd_grid(N)), \
                                    dim3(256), 0, (hipStream_t)stream, x, v, ldxv, t_filter, ldt, a, rl, cut, rowptr, src, \
                                    h_in, X_in, h_out, X_out, N, F, H);    \
             }                                                             \
             else {                                                        \
-                GN_MSG_ONE(L, SD, ST, 3, 3, false);                       \
-                if constexpr (L >= 4) { GN_MSG_ONE(L, SD, ST, 4, 4, false); } \
+                GN_MSG_ONE(L, SD, ST, 3, 3, false, FC);                   \
+                if constexpr (L >= 4) { GN_MSG_ONE(L, SD, ST, 4, 4, false, FC); } \
             }                                                             \
         }                                                                 \
+    } while (0)
+#define GN_MSG_LAUNCH(L, SD, ST) GN_MSG_LAUNCH_FC(L, SD, ST, 0)
+// the reference's defaults (sep_dir, sep_tensor) at F = 256: the compile-time-width instantiations
+#define GN_MSG_LAUNCH_DEFAULT(L)                                                                 \
+    do {                                                                                          \
+        if (F == 256) GN_MSG_LAUNCH_FC(L, true, true, 256); else GN_MSG_LAUNCH_FC(L, true, true, 0); \
     } while (0)
 
 extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, const float* t_filter, int ldt,
@@ -578,19 +588,21 @@ extern "C" int gn_message_aggregate(const float* x, const float* v, int ldxv, co
                                 lmax, sep_dir, sep_tensor, aggr, (hipStream_t)stream);
     const int key = lmax * 4 + (sep_dir ? 2 : 0) + (sep_tensor ? 1 : 0);
     switch (key) {
-        case 4: case 5: case 6: case 7: GN_MSG_LAUNCH(1, false, false); break;   // lmax = 1: flags are no-ops
+        case 4: case 5: case 6: case 7:                                          // lmax = 1: flags are no-ops
+            if (F == 256) GN_MSG_LAUNCH_FC(1, false, false, 256); else GN_MSG_LAUNCH(1, false, false);
+            break;
         case 8: GN_MSG_LAUNCH(2, false, false); break;
         case 9: GN_MSG_LAUNCH(2, false, true); break;
         case 10: GN_MSG_LAUNCH(2, true, false); break;
-        case 11: GN_MSG_LAUNCH(2, true, true); break;
+        case 11: GN_MSG_LAUNCH_DEFAULT(2); break;
         case 12: GN_MSG_LAUNCH(3, false, false); break;
         case 13: GN_MSG_LAUNCH(3, false, true); break;
         case 14: GN_MSG_LAUNCH(3, true, false); break;
-        case 15: GN_MSG_LAUNCH(3, true, true); break;
+        case 15: GN_MSG_LAUNCH_DEFAULT(3); break;
         case 16: GN_MSG_LAUNCH(4, false, false); break;
         case 17: GN_MSG_LAUNCH(4, false, true); break;
         case 18: GN_MSG_LAUNCH(4, true, false); break;
-        default: GN_MSG_LAUNCH(4, true, true); break;
+        default: GN_MSG_LAUNCH_DEFAULT(4); break;
     }
     GN_LAUNCH_CHECK();
     return GN_OK;
@@ -606,12 +618,14 @@ extern "C" int gn_htr_edge(const float* EQ, const float* EK, const float* rl, co
     if (gn_use_highl(lmax_arg)) return gn_highl_htr_edge(EQ, EK, rl, rowptr, src, N, F, lmax, mode, w_raw, w, st);
     if (mode) return gn_htr_edge_general(EQ, EK, rl, rowptr, src, N, F, lmax, mode, w_raw, w, st);
     const dim3 grid(gn::xcd_grid(N)), block(256);
-    switch (lmax) {
-        case 1: hipLaunchKernelGGL(gn::htr_edge_kernel<1>, grid, block, 0, st, EQ, EK, rl, rowptr, src, N, F, w); break;
-        case 2: hipLaunchKernelGGL(gn::htr_edge_kernel<2>, grid, block, 0, st, EQ, EK, rl, rowptr, src, N, F, w); break;
-        case 3: hipLaunchKernelGGL(gn::htr_edge_kernel<3>, grid, block, 0, st, EQ, EK, rl, rowptr, src, N, F, w); break;
-        default: hipLaunchKernelGGL(gn::htr_edge_kernel<4>, grid, block, 0, st, EQ, EK, rl, rowptr, src, N, F, w); break;
+#define GN_HTR_EDGE(FC)                                                                                                  \
+    switch (lmax) {                                                                                                      \
+        case 1: hipLaunchKernelGGL((gn::htr_edge_kernel<1, FC>), grid, block, 0, st, EQ, EK, rl, rowptr, src, N, F, w); break; \
+        case 2: hipLaunchKernelGGL((gn::htr_edge_kernel<2, FC>), grid, block, 0, st, EQ, EK, rl, rowptr, src, N, F, w); break; \
+        case 3: hipLaunchKernelGGL((gn::htr_edge_kernel<3, FC>), grid, block, 0, st, EQ, EK, rl, rowptr, src, N, F, w); break; \
+        default: hipLaunchKernelGGL((gn::htr_edge_kernel<4, FC>), grid, block, 0, st, EQ, EK, rl, rowptr, src, N, F, w); break; \
     }
+    if (F == 256) { GN_HTR_EDGE(256) } else { GN_HTR_EDGE(0) }
     GN_LAUNCH_CHECK();
     return GN_OK;
 }
