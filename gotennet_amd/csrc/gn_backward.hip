@@ -534,6 +534,155 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG) void msg_bwd_merged_kerne
     });
 }
 
+// Second form of the merged kernel (GN_MSGB_OWN_LDS): what changes is WHERE the operands of an edge come from and WHEN they
+// are asked for, not the arithmetic (same expressions, same order: bit-identical gradients).
+//  * the source's own rows x_j, v_j, X_j (2M + D rows, loop invariants that do not fit in registers next to the 2M + D
+//    accumulators) are staged in LDS once per workgroup and read with ds_read_b128: the first form re-read them through the
+//    vector-memory path on every edge -- 18 of the 33 16-byte row loads of an edge at lmax 2, i.e. more than half of the
+//    L1 / texture-addresser time of the kernel (64 B per clock per CU: 38 KiB per edge = 61 us of the launch);
+//  * the pointers are __restrict__ parameters of a forceinline body, and all rows of the edge (D rows of g_X1[i], M rows of
+//    t_filter, g_h1[i]) are requested at the top of the trip: the first form had them in the argument struct, so every
+//    g_eproj store fenced the next block's loads -- five dependent round trips per edge;
+//  * the (edge, target) indices of the NEXT trip are requested while this one computes.
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int FC>
+__device__ __forceinline__ void msg_bwd_merged2_body(
+    const float* __restrict__ x, const float* __restrict__ v, int ldxv, const float* __restrict__ X_in,
+    const float* __restrict__ eproj, int lde, const float* __restrict__ a, const float* __restrict__ rl,
+    const float* __restrict__ cut, const float* __restrict__ g_h1, const float* __restrict__ g_X1,
+    const int* __restrict__ dst, const int* __restrict__ colptr, const int* __restrict__ perm,
+    float* __restrict__ g_eproj, float* __restrict__ g_x, float* __restrict__ g_v, float* __restrict__ g_X_out,
+    float* __restrict__ g_rl, float* __restrict__ g_cut, float* __restrict__ ga, int N, int F_rt, int H) {
+    using S = MsgShape<LMAX, SEP_DIR, SEP_TENSOR>;
+    constexpr int D = S::D, M = S::M;
+    constexpr int KP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));
+    constexpr int ROWS = 2 * M + D;                   // [0,M) g_x, [M,2M) g_v, [2M, 2M+D) g_X
+    constexpr int CH = ROWS < 9 ? ROWS : 9;
+    __shared__ __attribute__((aligned(16))) float red[CH * 1024];
+    __shared__ __attribute__((aligned(16))) float own[ROWS * 256];     // x_j | v_j | X_j rows of this source
+    __shared__ float hsum[256 * M];
+    const int F = FC ? FC : F_rt;
+    const int j = xcd_item(blockIdx.x, N);
+    if (j < 0) return;
+    GN_SLOT_GEOMETRY(FC);
+    const int p0 = colptr[j], p1 = colptr[j + 1];
+    for (int idx = threadIdx.x * 4; idx < ROWS * F; idx += 1024) {
+        const int r = idx / F, c = idx - r * F;
+        const float* g = r < M ? x + (size_t)j * ldxv + r * F : (r < 2 * M ? v + (size_t)j * ldxv + (r - M) * F
+                                                                             : X_in + ((size_t)j * D + (r - 2 * M)) * F);
+        st4(own + idx, ld4(g + c));
+    }
+    const int per_head = (M * F) / H;
+    int hb[M];
+#pragma unroll
+    for (int b = 0; b < M; ++b) hb[b] = (b * F + c0) / per_head;
+    float4 acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = zero4();
+    __syncthreads();
+
+    int pp = p0 + slot;
+    int e_n = 0, i_n = 0;
+    if (pp < p1) { e_n = perm[pp]; i_n = dst[pp]; }
+    for (; pp < p1; pp += ns) {
+        const int e = e_n, i = i_n;
+        if (pp + ns < p1) { e_n = perm[pp + ns]; i_n = dst[pp + ns]; }
+        const float* tr = eproj + (size_t)e * lde + F + c0;
+        float* gtr = g_eproj + (size_t)e * lde + F + c0;
+        const float* ar = a + (size_t)e * H;
+        const float* re = rl + (size_t)e * D;
+        const float* gXi = g_X1 + (size_t)i * D * F + c0;
+        int oc = c0;
+        asm volatile("" : "+v"(oc));                  // own rows: read from LDS per edge, not hoisted into 72 registers
+        const float* ox = own + oc;
+        const float* ov = own + M * F + oc;
+        const float* oX = own + 2 * M * F + oc;
+        // every global row of the edge, before the first store
+        float4 tf[M], gx[D];
+#pragma unroll
+        for (int b = 0; b < M; ++b) tf[b] = ld4_nt(tr + b * F);
+#pragma unroll
+        for (int m = 0; m < D; ++m) gx[m] = ld4(gXi + (size_t)m * F);
+        const float4 gh = ld4(g_h1 + (size_t)i * F + c0);
+        const float ce = cut[e];
+        float ab_[M];
+#pragma unroll
+        for (int b = 0; b < M; ++b) ab_[b] = ar[hb[b]];
+        float pa_h[M], rlp[D];
+        float cutp = 0.f;
+#pragma unroll
+        for (int b = 0; b < M; ++b) {
+            const float4 tfb = tf[b], xb = ld4(ox + b * F), vb = ld4(ov + b * F);
+            const float ab = ab_[b];
+            const float4 fw = fma4(ab, vb, (tfb * xb) * ce);       // the forward gate of this block
+            float4 go;
+            if (b == 0) {
+                go = gh;
+            } else {
+                go = zero4();
+#pragma unroll
+                for (int l = S::lo(b); l <= S::hi(b); ++l)
+#pragma unroll
+                    for (int m = S::first_row(l); m < S::first_row(l) + 2 * l + 1; ++m) {
+                        if (S::is_dir(b)) {
+                            go = fma4(re[m], gx[m], go);
+                            rlp[m] = hsum4(gx[m] * fw);
+                        } else {
+                            go = fma4(gx[m], ld4(oX + (size_t)m * F), go);
+                            acc[2 * M + m] = fma4(gx[m], fw, acc[2 * M + m]);
+                        }
+                    }
+            }
+            st4_nt(gtr + b * F, (go * xb) * ce);
+            cutp += hsum4(go * tfb * xb);
+            pa_h[b] = hsum4(go * vb);
+            acc[b] = fma4(go, tfb * ce, acc[b]);
+            acc[M + b] = fma4(ab, go, acc[M + b]);
+        }
+        cutp = group_sum(cutp, lps);
+        if (lp == 0) g_cut[e] = cutp;
+        {   // head sums of g_a (same staging as msg_bwd_target_body: a slot never spans waves, wave-ordered LDS accesses)
+            float* hrow = hsum + slot * (M * lps);
+#pragma unroll
+            for (int b = 0; b < M; ++b) hrow[b * lps + lp] = pa_h[b];
+            const int rpl = lps / H, hh = lp / rpl, part = lp - hh * rpl;
+            const float* hp = hrow + hh * (M * rpl) + part * M;
+            float hv = hp[0];
+#pragma unroll
+            for (int k = 1; k < M; ++k) hv += hp[k];
+            hv = group_sum(hv, rpl);
+            if (part == 0) ga[(size_t)e * H + hh] = hv;
+        }
+        if (lps >= KP) {                             // D rl sums in one butterfly
+            float vals[KP];
+#pragma unroll
+            for (int m = 0; m < KP; ++m) vals[m] = m < D ? rlp[m] : 0.f;
+            multi_group_sum<KP>(vals, lps, lp);
+            const int stride = lps / KP;
+            if ((lp & (stride - 1)) == 0 && lp / stride < D) g_rl[(size_t)e * D + lp / stride] = vals[0];
+        } else {
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                const float sv = group_sum(rlp[m], lps);
+                if (lp == 0) g_rl[(size_t)e * D + m] = sv;
+            }
+        }
+    }
+    reduce_rows<ROWS>(acc, red, slot, c0, F, ns, [&](int row, float4 sv) {
+        if (row < M) st4(g_x + (size_t)j * ldxv + row * F + c0, sv);
+        else if (row < 2 * M) st4(g_v + (size_t)j * ldxv + (row - M) * F + c0, sv);
+        else {
+            const size_t off = ((size_t)j * D + (row - 2 * M)) * F + c0;
+            st4(g_X_out + off, ld4(g_X1 + off) + sv);
+        }
+    });
+}
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int FC = 0>
+__global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG) void msg_bwd_merged2_kernel(const MsgBwdArgs p, float* __restrict__ ga) {
+    msg_bwd_merged2_body<LMAX, SEP_DIR, SEP_TENSOR, FC>(p.x, p.v, p.ldxv, p.X_in, p.eproj, p.lde, p.a, p.rl, p.cut, p.g_h1, p.g_X1,
+                                                        p.dst, p.colptr, p.perm, p.g_eproj, p.g_x, p.g_v, p.g_X_out, p.g_rl,
+                                                        p.g_cut, ga, p.N, p.F, p.H);
+}
+
 // g_k of the gathered source rows, after the softmax backward:  g_k_j = sum_e g_s[e, head] q_i SiLU(t_attn pre-activation)
 template <int FC = 0>
 __global__ __launch_bounds__(256) void msg_bwd_gk_kernel(const MsgBwdArgs p) {
@@ -1228,7 +1377,8 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
             break;                                                                                        \
         }                                                                                                 \
         if (GN_MSGB_MERGED && ga_parts != nullptr) {     /* general launches: t_filter read once (gn_tune.h) */ \
-            hipLaunchKernelGGL((gn::msg_bwd_merged_kernel<L, SD, ST, FC>), grid, block, 0, st, p, ga_parts); \
+            if (GN_MSGB_OWN_LDS) hipLaunchKernelGGL((gn::msg_bwd_merged2_kernel<L, SD, ST, FC>), grid, block, 0, st, p, ga_parts); \
+            else hipLaunchKernelGGL((gn::msg_bwd_merged_kernel<L, SD, ST, FC>), grid, block, 0, st, p, ga_parts); \
             hipLaunchKernelGGL(gn::attn_bwd_kernel<FC>, grid, block, 0, st, p, ga_parts, 1, (size_t)0);   \
             hipLaunchKernelGGL(gn::msg_bwd_gk_kernel<FC>, grid, block, 0, st, p);                         \
             break;                                                                                        \
