@@ -425,117 +425,9 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kerne
 // computed once, here, and everything that needs them -- g_tf, g_cut, g_rl, the head sums of g_a (per edge) and g_x, g_v,
 // g_X (per source) -- leaves this kernel; t_filter is read ONCE (the two-kernel form reads it in both passes: 1.50 x the
 // algorithmic traffic).  The softmax / scores backward then runs by target (attn_bwd_kernel, as in the degree-group form)
-// and g_k by source (msg_bwd_gk_kernel).  lmax <= 2, general launches (X_in != NULL), SiLU.
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int FC = 0>
-__global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG) void msg_bwd_merged_kernel(const MsgBwdArgs p, float* __restrict__ ga) {
-    using S = MsgShape<LMAX, SEP_DIR, SEP_TENSOR>;
-    constexpr int D = S::D, M = S::M;
-    constexpr int KP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));
-    constexpr int ROWS = 2 * M + D;                   // [0,M) g_x, [M,2M) g_v, [2M, 2M+D) g_X
-    constexpr int CH = ROWS < 9 ? ROWS : 9;
-    __shared__ __attribute__((aligned(16))) float red[CH * 1024];
-    __shared__ float hsum[256 * M];
-    const int N = p.N, F = FC ? FC : p.F, H = p.H;
-    const int j = xcd_item(blockIdx.x, N);
-    if (j < 0) return;
-    GN_SLOT_GEOMETRY(FC);
-    const int p0 = p.colptr[j], p1 = p.colptr[j + 1];
-    const int per_head = (M * F) / H;
-    int hb[M];
-#pragma unroll
-    for (int b = 0; b < M; ++b) hb[b] = (b * F + c0) / per_head;
-    float4 acc[ROWS];
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r] = zero4();
-
-    for (int pp = p0 + slot; pp < p1; pp += ns) {
-        const int e = p.perm[pp];
-        const int i = p.dst[pp];
-        const float ce = p.cut[e];
-        const float* xr = p.x + (size_t)j * p.ldxv + c0;          // own rows, re-read per edge (L1-resident)
-        const float* vr = p.v + (size_t)j * p.ldxv + c0;
-        const float* Xj = p.X_in + (size_t)j * D * F + c0;
-        asm volatile("" : "+v"(xr), "+v"(vr), "+v"(Xj));
-        const float* tr = p.eproj + (size_t)e * p.lde + F + c0;
-        float* gtr = p.g_eproj + (size_t)e * p.lde + F + c0;
-        const float* ar = p.a + (size_t)e * H;
-        const float* re = p.rl + (size_t)e * D;
-        const float* gXi = p.g_X1 + (size_t)i * D * F + c0;
-        float4 gx[D];
-#pragma unroll
-        for (int m = 0; m < D; ++m) gx[m] = ld4(gXi + (size_t)m * F);
-        float pa_h[M], rlp[D];
-        float cutp = 0.f;
-#pragma unroll
-        for (int b = 0; b < M; ++b) {
-            const float4 tfb = ld4_nt(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
-            const float ab = ar[hb[b]];
-            const float4 fw = fma4(ab, vb, (tfb * xb) * ce);       // the forward gate of this block
-            float4 go;
-            if (b == 0) {
-                go = ld4(p.g_h1 + (size_t)i * F + c0);
-            } else {
-                go = zero4();
-#pragma unroll
-                for (int l = S::lo(b); l <= S::hi(b); ++l)
-#pragma unroll
-                    for (int m = S::first_row(l); m < S::first_row(l) + 2 * l + 1; ++m) {
-                        if (S::is_dir(b)) {
-                            go = fma4(re[m], gx[m], go);
-                            rlp[m] = hsum4(gx[m] * fw);
-                        } else {
-                            go = fma4(gx[m], ld4(Xj + (size_t)m * F), go);
-                            acc[2 * M + m] = fma4(gx[m], fw, acc[2 * M + m]);
-                        }
-                    }
-            }
-            st4_nt(gtr + b * F, (go * xb) * ce);
-            cutp += hsum4(go * tfb * xb);
-            pa_h[b] = hsum4(go * vb);
-            acc[b] = fma4(go, tfb * ce, acc[b]);
-            acc[M + b] = fma4(ab, go, acc[M + b]);
-        }
-        cutp = group_sum(cutp, lps);
-        if (lp == 0) p.g_cut[e] = cutp;
-        {   // head sums of g_a (same staging as msg_bwd_target_body: a slot never spans waves, wave-ordered LDS accesses)
-            float* hrow = hsum + slot * (M * lps);
-#pragma unroll
-            for (int b = 0; b < M; ++b) hrow[b * lps + lp] = pa_h[b];
-            const int rpl = lps / H, hh = lp / rpl, part = lp - hh * rpl;
-            const float* hp = hrow + hh * (M * rpl) + part * M;
-            float hv = hp[0];
-#pragma unroll
-            for (int k = 1; k < M; ++k) hv += hp[k];
-            hv = group_sum(hv, rpl);
-            if (part == 0) ga[(size_t)e * H + hh] = hv;
-        }
-        if (lps >= KP) {                             // D rl sums in one butterfly
-            float vals[KP];
-#pragma unroll
-            for (int m = 0; m < KP; ++m) vals[m] = m < D ? rlp[m] : 0.f;
-            multi_group_sum<KP>(vals, lps, lp);
-            const int stride = lps / KP;
-            if ((lp & (stride - 1)) == 0 && lp / stride < D) p.g_rl[(size_t)e * D + lp / stride] = vals[0];
-        } else {
-#pragma unroll
-            for (int m = 0; m < D; ++m) {
-                const float sv = group_sum(rlp[m], lps);
-                if (lp == 0) p.g_rl[(size_t)e * D + m] = sv;
-            }
-        }
-    }
-    reduce_rows<ROWS>(acc, red, slot, c0, F, ns, [&](int row, float4 sv) {
-        if (row < M) st4(p.g_x + (size_t)j * p.ldxv + row * F + c0, sv);
-        else if (row < 2 * M) st4(p.g_v + (size_t)j * p.ldxv + (row - M) * F + c0, sv);
-        else {
-            const size_t off = ((size_t)j * D + (row - 2 * M)) * F + c0;
-            st4(p.g_X_out + off, ld4(p.g_X1 + off) + sv);
-        }
-    });
-}
-
-// Second form of the merged kernel (GN_MSGB_OWN_LDS): what changes is WHERE the operands of an edge come from and WHEN they
-// are asked for, not the arithmetic (same expressions, same order: bit-identical gradients).
+// and g_k by source (msg_bwd_gk_kernel).  General launches (X_in != NULL), SiLU.
+// Where the operands of an edge come from and when they are asked for (second form of the round; the first re-read the own
+// rows through L1 per edge and fenced every block's loads behind the previous block's store: 252 -> 195 us per launch):
 //  * the source's own rows x_j, v_j, X_j (2M + D rows, loop invariants that do not fit in registers next to the 2M + D
 //    accumulators) are staged in LDS once per workgroup and read with ds_read_b128: the first form re-read them through the
 //    vector-memory path on every edge -- 18 of the 33 16-byte row loads of an edge at lmax 2, i.e. more than half of the
@@ -545,7 +437,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG) void msg_bwd_merged_kerne
 //    g_eproj store fenced the next block's loads -- five dependent round trips per edge;
 //  * the (edge, target) indices of the NEXT trip are requested while this one computes.
 template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int FC>
-__device__ __forceinline__ void msg_bwd_merged2_body(
+__device__ __forceinline__ void msg_bwd_merged_body(
     const float* __restrict__ x, const float* __restrict__ v, int ldxv, const float* __restrict__ X_in,
     const float* __restrict__ eproj, int lde, const float* __restrict__ a, const float* __restrict__ rl,
     const float* __restrict__ cut, const float* __restrict__ g_h1, const float* __restrict__ g_X1,
@@ -677,8 +569,8 @@ __device__ __forceinline__ void msg_bwd_merged2_body(
     });
 }
 template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int FC = 0>
-__global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG) void msg_bwd_merged2_kernel(const MsgBwdArgs p, float* __restrict__ ga) {
-    msg_bwd_merged2_body<LMAX, SEP_DIR, SEP_TENSOR, FC>(p.x, p.v, p.ldxv, p.X_in, p.eproj, p.lde, p.a, p.rl, p.cut, p.g_h1, p.g_X1,
+__global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG) void msg_bwd_merged_kernel(const MsgBwdArgs p, float* __restrict__ ga) {
+    msg_bwd_merged_body<LMAX, SEP_DIR, SEP_TENSOR, FC>(p.x, p.v, p.ldxv, p.X_in, p.eproj, p.lde, p.a, p.rl, p.cut, p.g_h1, p.g_X1,
                                                         p.dst, p.colptr, p.perm, p.g_eproj, p.g_x, p.g_v, p.g_X_out, p.g_rl,
                                                         p.g_cut, ga, p.N, p.F, p.H);
 }
@@ -771,9 +663,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const MsgBwdArgs p, const
 
 // degree-group form of msg_bwd_merged_kernel: the by-source pass of a group with the group's per-edge work merged in
 // (g_tf of its blocks, its cut slice, its g_rl rows, its slice of the head sums); g_k is left to msg_bwd_gk_kernel.
-template <int LMAX, int LLO, int LHI, bool SCALAR, int FC = 0>
-__global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG_G) void msg_bwd_merged_group_kernel(const MsgBwdArgs p, float* __restrict__ ga_slice,
-                                                                                       float* __restrict__ cut_slice) {
+// Like msg_bwd_merged_body: the group's own rows (its x / v blocks, its X rows) in LDS, every global row of the edge
+// requested before the first store, next trip's indices prefetched (lmax 4 step 13.15 -> 12.14 ms, C5 14.9 -> 13.83).
+template <int LMAX, int LLO, int LHI, bool SCALAR, int FC>
+__device__ __forceinline__ void msg_bwd_merged_group_body(
+    const float* __restrict__ x, const float* __restrict__ v, int ldxv, const float* __restrict__ X_in,
+    const float* __restrict__ eproj, int lde, const float* __restrict__ a, const float* __restrict__ rl,
+    const float* __restrict__ cut, const float* __restrict__ g_h1, const float* __restrict__ g_X1,
+    const int* __restrict__ dst, const int* __restrict__ colptr, const int* __restrict__ perm,
+    float* __restrict__ g_eproj, float* __restrict__ g_x, float* __restrict__ g_v, float* __restrict__ g_X_out,
+    float* __restrict__ g_rl, float* __restrict__ ga_slice, float* __restrict__ cut_slice, int N, int F_rt, int H) {
     constexpr int D = (LMAX + 1) * (LMAX + 1) - 1;
     constexpr int M = 1 + 2 * LMAX;
     constexpr int NL = LHI - LLO + 1;
@@ -783,40 +682,64 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG_G) void msg_bwd_merged_gro
     constexpr int CH = ROWS < 9 ? ROWS : 9;
     constexpr int KP = (XR + 8) <= 16 ? 16 : 32;
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
-    const int N = p.N, F = FC ? FC : p.F, H = p.H;
+    __shared__ __attribute__((aligned(16))) float own[ROWS * 256];     // x blocks | v blocks | X rows of this source (group order)
+    const int F = FC ? FC : F_rt;
     const int j = xcd_item(blockIdx.x, N);
     if (j < 0) return;
     GN_SLOT_GEOMETRY(FC);
-    const int p0 = p.colptr[j], p1 = p.colptr[j + 1];
+    const int p0 = colptr[j], p1 = colptr[j + 1];
     const int per_head = (M * F) / H;
     auto vblock = [&](int k) { return SCALAR ? (k == 0 ? 0 : (k <= NL ? LLO + k - 1 : LMAX + LLO + k - 1 - NL))
                                              : (k < NL ? LLO + k : LMAX + LLO + k - NL); };
+    for (int idx = threadIdx.x * 4; idx < ROWS * F; idx += 1024) {
+        const int r = idx / F, c = idx - r * F;
+        const float* g = r < NB ? x + (size_t)j * ldxv + vblock(r) * F
+                                : (r < 2 * NB ? v + (size_t)j * ldxv + vblock(r - NB) * F
+                                              : X_in + ((size_t)j * D + M0 + (r - 2 * NB)) * F);
+        st4(own + idx, ld4(g + c));
+    }
     float4 acc[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) acc[r] = zero4();
+    __syncthreads();
 
-    for (int pp = p0 + slot; pp < p1; pp += ns) {
-        const int e = p.perm[pp];
-        const int i = p.dst[pp];
-        const float ce = p.cut[e];
-        const float* xr = p.x + (size_t)j * p.ldxv + c0;
-        const float* vr = p.v + (size_t)j * p.ldxv + c0;
-        const float* Xj = p.X_in + (size_t)j * D * F + c0;
-        asm volatile("" : "+v"(xr), "+v"(vr), "+v"(Xj));      // own rows: re-read per edge, not pinned in registers
-        const float* tr = p.eproj + (size_t)e * p.lde + F + c0;
-        float* gtr = p.g_eproj + (size_t)e * p.lde + F + c0;
-        const float* ar = p.a + (size_t)e * H;
-        const float* re = p.rl + (size_t)e * D;
-        const float* gXi = p.g_X1 + (size_t)i * D * F + c0;
+    int pp = p0 + slot;
+    int e_n = 0, i_n = 0;
+    if (pp < p1) { e_n = perm[pp]; i_n = dst[pp]; }
+    for (; pp < p1; pp += ns) {
+        const int e = e_n, i = i_n;
+        if (pp + ns < p1) { e_n = perm[pp + ns]; i_n = dst[pp + ns]; }
+        const float* tr = eproj + (size_t)e * lde + F + c0;
+        float* gtr = g_eproj + (size_t)e * lde + F + c0;
+        const float* ar = a + (size_t)e * H;
+        const float* re = rl + (size_t)e * D;
+        const float* gXi = g_X1 + (size_t)i * D * F + c0;
+        int oc = c0;
+        asm volatile("" : "+v"(oc));                  // own rows: read from LDS per edge, not hoisted into registers
+        const float* ox = own + oc;
+        const float* ov = own + NB * F + oc;
+        const float* oX = own + 2 * NB * F + oc;
+        // every global row of the edge, before the first store
+        float4 tf[NB], gxa[XR];
+        float ab_[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) tf[k] = ld4_nt(tr + vblock(k) * F);
+#pragma unroll
+        for (int m = 0; m < XR; ++m) gxa[m] = ld4(gXi + (size_t)(M0 + m) * F);
+        float4 gh = zero4();
+        if (SCALAR) gh = ld4(g_h1 + (size_t)i * F + c0);
+        const float ce = cut[e];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) ab_[k] = ar[(vblock(k) * F + c0) / per_head];
         float cutp = 0.f;
         float vals[KP];
 #pragma unroll
         for (int k = 0; k < KP; ++k) vals[k] = 0.f;
         // one value block: gradient `go` of its gate -> g_tf, cut partial, head partial, g_x / g_v rows; returns the forward gate
         auto block = [&](int b, int k, float4 go) {
-            const float4 tfb = ld4_nt(tr + b * F), xb = ld4(xr + b * F), vb = ld4(vr + b * F);
+            const float4 tfb = tf[k], xb = ld4(ox + k * F), vb = ld4(ov + k * F);
             const int hb = (b * F + c0) / per_head;
-            const float ab = ar[hb];
+            const float ab = ab_[k];
             st4_nt(gtr + b * F, (go * xb) * ce);
             cutp += hsum4(go * tfb * xb);
             const float pa = hsum4(go * vb);
@@ -826,26 +749,24 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG_G) void msg_bwd_merged_gro
             acc[NB + k] = fma4(ab, go, acc[NB + k]);
             return fma4(ab, vb, (tfb * xb) * ce);
         };
-        if (SCALAR) block(0, 0, ld4(p.g_h1 + (size_t)i * F + c0));
+        if (SCALAR) block(0, 0, gh);
 #pragma unroll
         for (int l = LLO; l <= LHI; ++l) {
             const int kd = (SCALAR ? 1 : 0) + (l - LLO), kt = kd + NL;
-            float4 gx[2 * LHI + 1];
             float4 god = zero4(), got = zero4();
 #pragma unroll
             for (int mm = 0; mm < 2 * l + 1; ++mm) {
                 const int m = l * l - 1 + mm;
-                gx[mm] = ld4(gXi + (size_t)m * F);
-                god = fma4(re[m], gx[mm], god);
-                got = fma4(gx[mm], ld4(Xj + (size_t)m * F), got);
+                god = fma4(re[m], gxa[m - M0], god);
+                got = fma4(gxa[m - M0], ld4(oX + (size_t)(m - M0) * F), got);
             }
             const float4 od = block(l, kd, god);
             const float4 ot = block(LMAX + l, kt, got);
 #pragma unroll
             for (int mm = 0; mm < 2 * l + 1; ++mm) {
                 const int m = l * l - 1 + mm;
-                vals[m - M0] = hsum4(gx[mm] * od);
-                acc[2 * NB + m - M0] = fma4(gx[mm], ot, acc[2 * NB + m - M0]);
+                vals[m - M0] = hsum4(gxa[m - M0] * od);
+                acc[2 * NB + m - M0] = fma4(gxa[m - M0], ot, acc[2 * NB + m - M0]);
             }
         }
         cutp = group_sum(cutp, lps);
@@ -855,7 +776,7 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG_G) void msg_bwd_merged_gro
             const int stride = lps / KP;
             if ((lp & (stride - 1)) == 0) {
                 const int idx = lp / stride;
-                if (idx < XR) p.g_rl[(size_t)e * D + M0 + idx] = vals[0];
+                if (idx < XR) g_rl[(size_t)e * D + M0 + idx] = vals[0];
                 else if (idx - XR < H) ga_slice[(size_t)e * H + idx - XR] = vals[0];
             }
         } else {
@@ -863,20 +784,27 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG_G) void msg_bwd_merged_gro
             for (int k = 0; k < XR + 8; ++k) {
                 const float sv = group_sum(vals[k], lps);
                 if (lp == 0) {
-                    if (k < XR) p.g_rl[(size_t)e * D + M0 + k] = sv;
+                    if (k < XR) g_rl[(size_t)e * D + M0 + k] = sv;
                     else if (k - XR < H) ga_slice[(size_t)e * H + k - XR] = sv;
                 }
             }
         }
     }
     reduce_rows<ROWS>(acc, red, slot, c0, F, ns, [&](int row, float4 sv) {
-        if (row < NB) st4(p.g_x + (size_t)j * p.ldxv + vblock(row) * F + c0, sv);
-        else if (row < 2 * NB) st4(p.g_v + (size_t)j * p.ldxv + vblock(row - NB) * F + c0, sv);
+        if (row < NB) st4(g_x + (size_t)j * ldxv + vblock(row) * F + c0, sv);
+        else if (row < 2 * NB) st4(g_v + (size_t)j * ldxv + vblock(row - NB) * F + c0, sv);
         else {
             const size_t off = ((size_t)j * D + M0 + (row - 2 * NB)) * F + c0;
-            st4(p.g_X_out + off, ld4(p.g_X1 + off) + sv);
+            st4(g_X_out + off, ld4(g_X1 + off) + sv);
         }
     });
+}
+template <int LMAX, int LLO, int LHI, bool SCALAR, int FC = 0>
+__global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG_G) void msg_bwd_merged_group_kernel(const MsgBwdArgs p, float* __restrict__ ga_slice,
+                                                                                        float* __restrict__ cut_slice) {
+    msg_bwd_merged_group_body<LMAX, LLO, LHI, SCALAR, FC>(p.x, p.v, p.ldxv, p.X_in, p.eproj, p.lde, p.a, p.rl, p.cut, p.g_h1,
+                                                           p.g_X1, p.dst, p.colptr, p.perm, p.g_eproj, p.g_x, p.g_v, p.g_X_out,
+                                                           p.g_rl, ga_slice, cut_slice, p.N, p.F, p.H);
 }
 
 // HTR backward per degree group (w = sum_l w_l: the degrees are independent)
@@ -1367,6 +1295,12 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
     return GN_OK;
 }
 
+// (lmax >= 3 with sep_dir and sep_tensor never comes here -- the degree groups take it -- so that form is not instantiated)
+template <int L, bool SD, bool ST, int FC>
+static inline void gn_launch_msg_bwd_merged(dim3 grid, dim3 block, hipStream_t st, const gn::MsgBwdArgs& p, float* ga_parts) {
+    if constexpr (!(L >= 3 && SD && ST))
+        hipLaunchKernelGGL((gn::msg_bwd_merged_kernel<L, SD, ST, FC>), grid, block, 0, st, p, ga_parts);
+}
 // X_in == NULL: the zero-X_in instantiations (one target + one source launch at every lmax <= 4: without the tensor-gate
 // rows the register budget that forces the degree groups is gone; g_cut then uses ONE slice, the caller zeroes the rest)
 #define GN_MSGB_LAUNCH_FC(L, SD, ST, FC)                                                                 \
@@ -1377,8 +1311,7 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
             break;                                                                                        \
         }                                                                                                 \
         if (GN_MSGB_MERGED && ga_parts != nullptr) {     /* general launches: t_filter read once (gn_tune.h) */ \
-            if (GN_MSGB_OWN_LDS) hipLaunchKernelGGL((gn::msg_bwd_merged2_kernel<L, SD, ST, FC>), grid, block, 0, st, p, ga_parts); \
-            else hipLaunchKernelGGL((gn::msg_bwd_merged_kernel<L, SD, ST, FC>), grid, block, 0, st, p, ga_parts); \
+            gn_launch_msg_bwd_merged<L, SD, ST, FC>(grid, block, st, p, ga_parts);                        \
             hipLaunchKernelGGL(gn::attn_bwd_kernel<FC>, grid, block, 0, st, p, ga_parts, 1, (size_t)0);   \
             hipLaunchKernelGGL(gn::msg_bwd_gk_kernel<FC>, grid, block, 0, st, p);                         \
             break;                                                                                        \

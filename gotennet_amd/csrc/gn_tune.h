@@ -56,9 +56,6 @@
 #ifndef GN_MSGB_MERGED
 #define GN_MSGB_MERGED 1   // message backward at lmax <= 2 (general launches): 1 = by-source kernel with the per-edge work merged in
 #endif                     // (t_filter read once) + attention backward + g_k; 0 = the by-target / by-source pair
-#ifndef GN_MSGB_OWN_LDS
-#define GN_MSGB_OWN_LDS 1  // merged kernel: the source's own rows staged in LDS, all rows of an edge requested before the first store
-#endif
 #ifndef GN_W_MSG_MRG_G
 #define GN_W_MSG_MRG_G 2
 #endif
