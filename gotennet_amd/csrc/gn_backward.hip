@@ -1284,11 +1284,16 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
         hipLaunchKernelGGL((gn::htr_bwd_target_kernel<2, FC>), grid, block, 0, st, g_t_out, pre_t, w, EQ, EK, rl, rowptr, src, N, F, gEQ, g_rl, g_pre_t, act); \
         hipLaunchKernelGGL((gn::htr_bwd_source_kernel<2, FC>), grid, block, 0, st, g_t_out, pre_t, EQ, EK, rl, colptr, perm, dst, N, F, gEK, act); \
     } else if (lmax == 3) {                                                                                      \
-        GN_HTRB(3, 1, 2, true, FC); GN_HTRB(3, 3, 3, false, FC);                                                 \
+        if (GN_HTRB_TGT_MODE == 1) { GN_HTRB_T(3, 1, 3, true, FC); }                                             \
+        else { GN_HTRB_T(3, 1, 2, true, FC); GN_HTRB_T(3, 3, 3, false, FC); }                                    \
+        if (GN_HTRB_SRC_ONE) { GN_HTRB_S(3, 1, 3, FC); }                                                         \
+        else { GN_HTRB_S(3, 1, 2, FC); GN_HTRB_S(3, 3, 3, FC); }                                                 \
     } else {                                                                                                     \
-        GN_HTRB(4, 1, 2, true, FC);                                                                              \
-        GN_HTRB_T(4, 3, 3, false, FC); GN_HTRB_T(4, 4, 4, false, FC);                                            \
-        GN_HTRB_S(4, 3, 3, FC); GN_HTRB_S(4, 4, 4, FC);                                                          \
+        GN_HTRB_T(4, 1, 2, true, FC);                                                                            \
+        if (GN_HTRB_TGT_MODE == 1) { GN_HTRB_T(4, 3, 4, false, FC); }                                            \
+        else { GN_HTRB_T(4, 3, 3, false, FC); GN_HTRB_T(4, 4, 4, false, FC); }                                   \
+        if (GN_HTRB_SRC_ONE) { GN_HTRB_S(4, 1, 4, FC); }                                                         \
+        else { GN_HTRB_S(4, 1, 2, FC); GN_HTRB_S(4, 3, 3, FC); GN_HTRB_S(4, 4, 4, FC); }                         \
     }
     if (F == 256) { GN_HTRB_ALL(256) } else { GN_HTRB_ALL(0) }
     GN_LAUNCH_CHECK();

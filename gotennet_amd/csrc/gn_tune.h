@@ -56,6 +56,13 @@
 #ifndef GN_MSGB_MERGED
 #define GN_MSGB_MERGED 1   // message backward at lmax <= 2 (general launches): 1 = by-source kernel with the per-edge work merged in
 #endif                     // (t_filter read once) + attention backward + g_k; 0 = the by-target / by-source pair
+#ifndef GN_HTRB_SRC_ONE
+#define GN_HTRB_SRC_ONE 1  // HTR backward at lmax 3 / 4: ONE by-source launch for all degrees (its accumulators are the only rows it keeps)
+#endif
+#ifndef GN_HTRB_TGT_MODE
+#define GN_HTRB_TGT_MODE 1 // ... by-target launches: 0 = {1,2},{3},{4}; 1 = {1,2,3} at lmax 3, {1,2},{3,4} at lmax 4.  Nanotube (lmax 3)
+#endif                     // 300 -> 271 us per layer with both, lmax 4 273 either way (the gathered EQ / EK rows, 2 x 24 KiB per edge
+                           // through L2, bound it, not the re-read [E,F] streams); own EQ rows in LDS: no gain; a 3-wave hint: spills, 435 / 710 us
 #ifndef GN_W_MSG_MRG_G
 #define GN_W_MSG_MRG_G 2
 #endif
