@@ -436,7 +436,10 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_SRC) void msg_bwd_source_kerne
 //    t_filter, g_h1[i]) are requested at the top of the trip: the first form had them in the argument struct, so every
 //    g_eproj store fenced the next block's loads -- five dependent round trips per edge;
 //  * the (edge, target) indices of the NEXT trip are requested while this one computes.
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int FC>
+// FIRST: X_in is identically zero (first interaction): only the scalar and the direction-gate blocks exist -- the tensor-gate
+// blocks of eproj / x / v are not read, their g_eproj columns not written, those blocks of g_x / g_v are written as zeros,
+// no X rows, no g_X (as in the FIRST forms of the by-target / by-source pair, which this replaces when ga is given).
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int FC, bool FIRST>
 __device__ __forceinline__ void msg_bwd_merged_body(
     const float* __restrict__ x, const float* __restrict__ v, int ldxv, const float* __restrict__ X_in,
     const float* __restrict__ eproj, int lde, const float* __restrict__ a, const float* __restrict__ rl,
@@ -447,11 +450,13 @@ __device__ __forceinline__ void msg_bwd_merged_body(
     using S = MsgShape<LMAX, SEP_DIR, SEP_TENSOR>;
     constexpr int D = S::D, M = S::M;
     constexpr int KP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));
-    constexpr int ROWS = 2 * M + D;                   // [0,M) g_x, [M,2M) g_v, [2M, 2M+D) g_X
+    constexpr int MB = FIRST ? 1 + S::ND : M;         // value blocks this launch handles
+    constexpr int XR = FIRST ? 0 : D;                 // X rows / g_X rows
+    constexpr int ROWS = 2 * MB + XR;                 // [0,MB) g_x, [MB,2MB) g_v, [2MB, 2MB+D) g_X
     constexpr int CH = ROWS < 9 ? ROWS : 9;
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
     __shared__ __attribute__((aligned(16))) float own[ROWS * 256];     // x_j | v_j | X_j rows of this source
-    __shared__ float hsum[256 * M];
+    __shared__ float hsum[256 * MB];
     const int F = FC ? FC : F_rt;
     const int j = xcd_item(blockIdx.x, N);
     if (j < 0) return;
@@ -459,14 +464,14 @@ __device__ __forceinline__ void msg_bwd_merged_body(
     const int p0 = colptr[j], p1 = colptr[j + 1];
     for (int idx = threadIdx.x * 4; idx < ROWS * F; idx += 1024) {
         const int r = idx / F, c = idx - r * F;
-        const float* g = r < M ? x + (size_t)j * ldxv + r * F : (r < 2 * M ? v + (size_t)j * ldxv + (r - M) * F
-                                                                             : X_in + ((size_t)j * D + (r - 2 * M)) * F);
+        const float* g = r < MB ? x + (size_t)j * ldxv + r * F : (r < 2 * MB ? v + (size_t)j * ldxv + (r - MB) * F
+                                                                               : X_in + ((size_t)j * D + (r - 2 * MB)) * F);
         st4(own + idx, ld4(g + c));
     }
     const int per_head = (M * F) / H;
-    int hb[M];
+    int hb[MB];
 #pragma unroll
-    for (int b = 0; b < M; ++b) hb[b] = (b * F + c0) / per_head;
+    for (int b = 0; b < MB; ++b) hb[b] = (b * F + c0) / per_head;
     float4 acc[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) acc[r] = zero4();
@@ -486,23 +491,23 @@ __device__ __forceinline__ void msg_bwd_merged_body(
         int oc = c0;
         asm volatile("" : "+v"(oc));                  // own rows: read from LDS per edge, not hoisted into 72 registers
         const float* ox = own + oc;
-        const float* ov = own + M * F + oc;
-        const float* oX = own + 2 * M * F + oc;
+        const float* ov = own + MB * F + oc;
+        const float* oX = own + 2 * MB * F + oc;
         // every global row of the edge, before the first store
-        float4 tf[M], gx[D];
+        float4 tf[MB], gx[D];
 #pragma unroll
-        for (int b = 0; b < M; ++b) tf[b] = ld4_nt(tr + b * F);
+        for (int b = 0; b < MB; ++b) tf[b] = ld4_nt(tr + b * F);
 #pragma unroll
         for (int m = 0; m < D; ++m) gx[m] = ld4(gXi + (size_t)m * F);
         const float4 gh = ld4(g_h1 + (size_t)i * F + c0);
         const float ce = cut[e];
-        float ab_[M];
+        float ab_[MB];
 #pragma unroll
-        for (int b = 0; b < M; ++b) ab_[b] = ar[hb[b]];
-        float pa_h[M], rlp[D];
+        for (int b = 0; b < MB; ++b) ab_[b] = ar[hb[b]];
+        float pa_h[MB], rlp[D];
         float cutp = 0.f;
 #pragma unroll
-        for (int b = 0; b < M; ++b) {
+        for (int b = 0; b < MB; ++b) {
             const float4 tfb = tf[b], xb = ld4(ox + b * F), vb = ld4(ov + b * F);
             const float ab = ab_[b];
             const float4 fw = fma4(ab, vb, (tfb * xb) * ce);       // the forward gate of this block
@@ -520,7 +525,7 @@ __device__ __forceinline__ void msg_bwd_merged_body(
                             rlp[m] = hsum4(gx[m] * fw);
                         } else {
                             go = fma4(gx[m], ld4(oX + (size_t)m * F), go);
-                            acc[2 * M + m] = fma4(gx[m], fw, acc[2 * M + m]);
+                            acc[2 * MB + m] = fma4(gx[m], fw, acc[2 * MB + m]);
                         }
                     }
             }
@@ -528,19 +533,19 @@ __device__ __forceinline__ void msg_bwd_merged_body(
             cutp += hsum4(go * tfb * xb);
             pa_h[b] = hsum4(go * vb);
             acc[b] = fma4(go, tfb * ce, acc[b]);
-            acc[M + b] = fma4(ab, go, acc[M + b]);
+            acc[MB + b] = fma4(ab, go, acc[MB + b]);
         }
         cutp = group_sum(cutp, lps);
         if (lp == 0) g_cut[e] = cutp;
         {   // head sums of g_a (same staging as msg_bwd_target_body: a slot never spans waves, wave-ordered LDS accesses)
-            float* hrow = hsum + slot * (M * lps);
+            float* hrow = hsum + slot * (MB * lps);
 #pragma unroll
-            for (int b = 0; b < M; ++b) hrow[b * lps + lp] = pa_h[b];
+            for (int b = 0; b < MB; ++b) hrow[b * lps + lp] = pa_h[b];
             const int rpl = lps / H, hh = lp / rpl, part = lp - hh * rpl;
-            const float* hp = hrow + hh * (M * rpl) + part * M;
+            const float* hp = hrow + hh * (MB * rpl) + part * MB;
             float hv = hp[0];
 #pragma unroll
-            for (int k = 1; k < M; ++k) hv += hp[k];
+            for (int k = 1; k < MB; ++k) hv += hp[k];
             hv = group_sum(hv, rpl);
             if (part == 0) ga[(size_t)e * H + hh] = hv;
         }
@@ -560,17 +565,22 @@ __device__ __forceinline__ void msg_bwd_merged_body(
         }
     }
     reduce_rows<ROWS>(acc, red, slot, c0, F, ns, [&](int row, float4 sv) {
-        if (row < M) st4(g_x + (size_t)j * ldxv + row * F + c0, sv);
-        else if (row < 2 * M) st4(g_v + (size_t)j * ldxv + (row - M) * F + c0, sv);
+        if (row < MB) st4(g_x + (size_t)j * ldxv + row * F + c0, sv);
+        else if (row < 2 * MB) st4(g_v + (size_t)j * ldxv + (row - MB) * F + c0, sv);
         else {
-            const size_t off = ((size_t)j * D + (row - 2 * M)) * F + c0;
+            const size_t off = ((size_t)j * D + (row - 2 * MB)) * F + c0;
             st4(g_X_out + off, ld4(g_X1 + off) + sv);
         }
     });
+    if (FIRST)                                       // the tensor-gate blocks of g_x / g_v: zeros (their operands never reach a message)
+        for (int b = MB + slot; b < M; b += ns) {
+            st4(g_x + (size_t)j * ldxv + b * F + c0, zero4());
+            st4(g_v + (size_t)j * ldxv + b * F + c0, zero4());
+        }
 }
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int FC = 0>
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int FC = 0, bool FIRST = false>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG) void msg_bwd_merged_kernel(const MsgBwdArgs p, float* __restrict__ ga) {
-    msg_bwd_merged_body<LMAX, SEP_DIR, SEP_TENSOR, FC>(p.x, p.v, p.ldxv, p.X_in, p.eproj, p.lde, p.a, p.rl, p.cut, p.g_h1, p.g_X1,
+    msg_bwd_merged_body<LMAX, SEP_DIR, SEP_TENSOR, FC, FIRST>(p.x, p.v, p.ldxv, p.X_in, p.eproj, p.lde, p.a, p.rl, p.cut, p.g_h1, p.g_X1,
                                                         p.dst, p.colptr, p.perm, p.g_eproj, p.g_x, p.g_v, p.g_X_out, p.g_rl,
                                                         p.g_cut, ga, p.N, p.F, p.H);
 }
@@ -1311,6 +1321,12 @@ static inline void gn_launch_msg_bwd_merged(dim3 grid, dim3 block, hipStream_t s
 #define GN_MSGB_LAUNCH_FC(L, SD, ST, FC)                                                                 \
     do {                                                                                                  \
         if (!X_in) {                                                                                      \
+            if (GN_MSGB_MERGED_FIRST && ga_parts != nullptr) {   /* first interaction: merged form without the tensor-gate blocks */ \
+                hipLaunchKernelGGL((gn::msg_bwd_merged_kernel<L, SD, ST, FC, true>), grid, block, 0, st, p, ga_parts); \
+                hipLaunchKernelGGL(gn::attn_bwd_kernel<FC>, grid, block, 0, st, p, ga_parts, 1, (size_t)0); \
+                hipLaunchKernelGGL(gn::msg_bwd_gk_kernel<FC>, grid, block, 0, st, p);                     \
+                break;                                                                                    \
+            }                                                                                             \
             hipLaunchKernelGGL((gn::msg_bwd_target_kernel<L, SD, ST, true, FC>), grid, block, 0, st, p);  \
             hipLaunchKernelGGL((gn::msg_bwd_source_kernel<L, SD, ST, true, FC>), grid, block, 0, st, p);  \
             break;                                                                                        \

@@ -56,6 +56,9 @@
 #ifndef GN_MSGB_MERGED
 #define GN_MSGB_MERGED 1   // message backward at lmax <= 2 (general launches): 1 = by-source kernel with the per-edge work merged in
 #endif                     // (t_filter read once) + attention backward + g_k; 0 = the by-target / by-source pair
+#ifndef GN_MSGB_MERGED_FIRST
+#define GN_MSGB_MERGED_FIRST 1   // the first interaction (X_in == 0) through the merged kernel too (scalar + direction-gate blocks only)
+#endif
 #ifndef GN_HTRB_SRC_ONE
 #define GN_HTRB_SRC_ONE 1  // HTR backward at lmax 3 / 4: ONE by-source launch for all degrees (its accumulators are the only rows it keeps)
 #endif
