@@ -456,7 +456,7 @@ __device__ __forceinline__ void msg_bwd_merged_body(
     constexpr int CH = ROWS < 9 ? ROWS : 9;
     __shared__ __attribute__((aligned(16))) float red[CH * 1024];
     __shared__ __attribute__((aligned(16))) float own[ROWS * 256];     // x_j | v_j | X_j rows of this source
-    __shared__ float hsum[256 * MB];
+    __shared__ float hsum[256 * M];
     const int F = FC ? FC : F_rt;
     const int j = xcd_item(blockIdx.x, N);
     if (j < 0) return;
@@ -475,6 +475,10 @@ __device__ __forceinline__ void msg_bwd_merged_body(
     float4 acc[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) acc[r] = zero4();
+    if (FIRST) {
+#pragma unroll
+        for (int b = MB; b < M; ++b) hsum[slot * (M * lps) + b * lps + lp] = 0.f;
+    }
     __syncthreads();
 
     int pp = p0 + slot;
@@ -538,14 +542,14 @@ __device__ __forceinline__ void msg_bwd_merged_body(
         cutp = group_sum(cutp, lps);
         if (lp == 0) g_cut[e] = cutp;
         {   // head sums of g_a (same staging as msg_bwd_target_body: a slot never spans waves, wave-ordered LDS accesses)
-            float* hrow = hsum + slot * (MB * lps);
+            float* hrow = hsum + slot * (M * lps);  // (heads are cut from ALL M blocks of the value vector: FIRST leaves the rest zero)
 #pragma unroll
             for (int b = 0; b < MB; ++b) hrow[b * lps + lp] = pa_h[b];
             const int rpl = lps / H, hh = lp / rpl, part = lp - hh * rpl;
-            const float* hp = hrow + hh * (MB * rpl) + part * MB;
+            const float* hp = hrow + hh * (M * rpl) + part * M;
             float hv = hp[0];
 #pragma unroll
-            for (int k = 1; k < MB; ++k) hv += hp[k];
+            for (int k = 1; k < M; ++k) hv += hp[k];
             hv = group_sum(hv, rpl);
             if (part == 0) ga[(size_t)e * H + hh] = hv;
         }
