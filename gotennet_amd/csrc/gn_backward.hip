@@ -582,9 +582,18 @@ __device__ __forceinline__ void msg_bwd_merged_body(
             st4(g_v + (size_t)j * ldxv + b * F + c0, zero4());
         }
 }
-template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int FC = 0, bool FIRST = false>
+// (occupancy hints per form, gn_tune.h: the general launch runs best without one, the first-interaction form at 2 waves per SIMD)
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int FC = 0>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG) void msg_bwd_merged_kernel(const MsgBwdArgs p, float* __restrict__ ga) {
-    msg_bwd_merged_body<LMAX, SEP_DIR, SEP_TENSOR, FC, FIRST>(p.x, p.v, p.ldxv, p.X_in, p.eproj, p.lde, p.a, p.rl, p.cut, p.g_h1, p.g_X1,
+
+    msg_bwd_merged_body<LMAX, SEP_DIR, SEP_TENSOR, FC, false>(p.x, p.v, p.ldxv, p.X_in, p.eproj, p.lde, p.a, p.rl, p.cut, p.g_h1, p.g_X1,
+                                                        p.dst, p.colptr, p.perm, p.g_eproj, p.g_x, p.g_v, p.g_X_out, p.g_rl,
+                                                        p.g_cut, ga, p.N, p.F, p.H);
+}
+template <int LMAX, bool SEP_DIR, bool SEP_TENSOR, int FC = 0>
+__global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG_F) void msg_bwd_merged_first_kernel(const MsgBwdArgs p, float* __restrict__ ga) {
+
+    msg_bwd_merged_body<LMAX, SEP_DIR, SEP_TENSOR, FC, true>(p.x, p.v, p.ldxv, p.X_in, p.eproj, p.lde, p.a, p.rl, p.cut, p.g_h1, p.g_X1,
                                                         p.dst, p.colptr, p.perm, p.g_eproj, p.g_x, p.g_v, p.g_X_out, p.g_rl,
                                                         p.g_cut, ga, p.N, p.F, p.H);
 }
@@ -815,6 +824,14 @@ __device__ __forceinline__ void msg_bwd_merged_group_body(
 }
 template <int LMAX, int LLO, int LHI, bool SCALAR, int FC = 0>
 __global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG_G) void msg_bwd_merged_group_kernel(const MsgBwdArgs p, float* __restrict__ ga_slice,
+                                                                                        float* __restrict__ cut_slice) {
+    msg_bwd_merged_group_body<LMAX, LLO, LHI, SCALAR, FC>(p.x, p.v, p.ldxv, p.X_in, p.eproj, p.lde, p.a, p.rl, p.cut, p.g_h1,
+                                                           p.g_X1, p.dst, p.colptr, p.perm, p.g_eproj, p.g_x, p.g_v, p.g_X_out,
+                                                           p.g_rl, ga_slice, cut_slice, p.N, p.F, p.H);
+}
+// the {3} group (155 VGPRs) under its own occupancy hint
+template <int LMAX, int LLO, int LHI, bool SCALAR, int FC = 0>
+__global__ __launch_bounds__(256) GN_WPE(GN_W_MSG_MRG_G3) void msg_bwd_merged_group3_kernel(const MsgBwdArgs p, float* __restrict__ ga_slice,
                                                                                         float* __restrict__ cut_slice) {
     msg_bwd_merged_group_body<LMAX, LLO, LHI, SCALAR, FC>(p.x, p.v, p.ldxv, p.X_in, p.eproj, p.lde, p.a, p.rl, p.cut, p.g_h1,
                                                            p.g_X1, p.dst, p.colptr, p.perm, p.g_eproj, p.g_x, p.g_v, p.g_X_out,
@@ -1326,7 +1343,7 @@ static inline void gn_launch_msg_bwd_merged(dim3 grid, dim3 block, hipStream_t s
     do {                                                                                                  \
         if (!X_in) {                                                                                      \
             if (GN_MSGB_MERGED_FIRST && ga_parts != nullptr) {   /* first interaction: merged form without the tensor-gate blocks */ \
-                hipLaunchKernelGGL((gn::msg_bwd_merged_kernel<L, SD, ST, FC, true>), grid, block, 0, st, p, ga_parts); \
+                hipLaunchKernelGGL((gn::msg_bwd_merged_first_kernel<L, SD, ST, FC>), grid, block, 0, st, p, ga_parts); \
                 hipLaunchKernelGGL(gn::attn_bwd_kernel<FC>, grid, block, 0, st, p, ga_parts, 1, (size_t)0); \
                 hipLaunchKernelGGL(gn::msg_bwd_gk_kernel<FC>, grid, block, 0, st, p);                     \
                 break;                                                                                    \
@@ -1384,8 +1401,12 @@ extern "C" int gn_message_backward(
         if (ga_parts == nullptr || E <= 0) return GN_ERR_BAD_ARG;
         const size_t gs = (size_t)E * H;
 #define GN_MSGB_M(L, LLO, LHI, SC, G, FC)                                                                    \
-    hipLaunchKernelGGL((gn::msg_bwd_merged_group_kernel<L, LLO, LHI, SC, FC>), grid, block, 0, st, p,        \
-                       ga_parts + (size_t)(G) * gs, g_cut + (size_t)(G) * E)
+    if ((LLO) == 3 && (LHI) == 3)                                                                            \
+        hipLaunchKernelGGL((gn::msg_bwd_merged_group3_kernel<L, LLO, LHI, SC, FC>), grid, block, 0, st, p,   \
+                           ga_parts + (size_t)(G) * gs, g_cut + (size_t)(G) * E);                            \
+    else                                                                                                     \
+        hipLaunchKernelGGL((gn::msg_bwd_merged_group_kernel<L, LLO, LHI, SC, FC>), grid, block, 0, st, p,    \
+                           ga_parts + (size_t)(G) * gs, g_cut + (size_t)(G) * E)
         // by-source group kernels with the per-edge work merged in (t_filter read once; head sums and cut slices per group)
         // -> attention backward over the summed head gradients -> g_k
 #define GN_MSGB_GROUPS(FC)                                                                                       \

@@ -67,10 +67,16 @@
 #endif                     // 300 -> 271 us per layer with both, lmax 4 273 either way (the gathered EQ / EK rows, 2 x 24 KiB per edge
                            // through L2, bound it, not the re-read [E,F] streams); own EQ rows in LDS: no gain; a 3-wave hint: spills, 435 / 710 us
 #ifndef GN_W_MSG_MRG_G
-#define GN_W_MSG_MRG_G 2
+#define GN_W_MSG_MRG_G 2   // degree-group kernels {scalar,1,2} and {4} ...
+#endif
+#ifndef GN_W_MSG_MRG_G3
+#define GN_W_MSG_MRG_G3 3  // ... and {3} (155 VGPRs): nanotube message backward 440 -> 418 us per layer with 3 for every group, lmax 4 neutral
 #endif
 #ifndef GN_W_MSG_MRG
-#define GN_W_MSG_MRG 2     // waves per SIMD hint of that kernel
+#define GN_W_MSG_MRG 0     // merged kernel, general launches: no hint (190 -> 186.5 us per layer at lmax 2 against 2)
+#endif
+#ifndef GN_W_MSG_MRG_F
+#define GN_W_MSG_MRG_F 2   // ... its first-interaction form (no hint: lmax 4 message backward 373 -> 382 us per layer on average)
 #endif
 #ifndef GN_MSGB_PF3
 #define GN_MSGB_PF3 4      // message backward, target pass: trips of the score-backward phase whose rows are requested before

@@ -65,6 +65,9 @@ class PackedWeights:
 
 #: A/B and test switch: False runs the first interaction through the general kernels on the zero tensor
 ZERO_X_FIRST = os.environ.get("GN_ZERO_X_FIRST", "1") != "0"
+#: test switch: True withholds the head-sum workspace from gn_message_backward where the entry point allows it (monolithic
+#: launches and every first interaction), which then runs the by-target / by-source kernel pair instead of the merged kernel
+MSG_BWD_PAIR = False
 
 
 def zero_X_in(cfg: "Config", li: int) -> bool:
@@ -872,7 +875,7 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
              ptr(gh1), ptr(gX1), ptr(g.rowptr), ptr(g.src), ptr(g.tgt_by_src), ptr(colptr), ptr(perm),
              ptr(g_eproj), ptr(g_s), ptr(g_nproj), 4 * F_, ptr(g_x), ptr(g_v), None if first else ptr(gX2),
              rl_slice(Wm * li), cut_slice(Wm * G * li),
-             ptr(ga_parts), E,
+             None if (MSG_BWD_PAIR and (first or G == 1)) else ptr(ga_parts), E,
              N, F_, H, cfg.lmax_arg_msg_bwd, int(cfg.sep_dir), int(cfg.sep_tensor), cfg.act, _stream())
         # the edge-sized W_e^T product leaves 0.7 of its last tile round idle: the two K-heavy atom-sized products
         # (g_x W_s2, g_v W_v2; 60 us as a launch of their own) ride there; W_n1^T needs their output and follows alone

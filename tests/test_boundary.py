@@ -529,6 +529,33 @@ def test_first_interaction_without_tensor_gate_blocks(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures("gemm_mode")
+@pytest.mark.parametrize("case", ["l1_nosep_scale_f32", "l2_sep_f32", "l2_mixed_f64ch", "c2_model_3mol_seeded", "l4_sep_f32"])
+def test_message_backward_merged_kernel_vs_kernel_pair(case):
+    """gn_message_backward with a head-sum workspace runs the merged by-source kernel (own rows in LDS, its first-interaction
+    form included); without one, the by-target / by-source pair (what direct callers of the C entry get when they pass
+    ga_parts = NULL).  Same gradients: forces agree at the level of a changed summation order, both match the reference."""
+    from tests.test_hip_forces import _head_from_case
+    from gotennet_amd import engine
+    from gotennet_amd.pipeline import EnergyForces
+    cfg, sd, head_sd, t = load_case(case)
+    net, head = _mirror(cfg, sd), _head_from_case(cfg, head_sd)
+    z, batch = t["z"].cuda(), t["batch"].cuda()
+    ei, ed, ev = t["edge_index"].cuda(), t["edge_diff"].cuda(), t["edge_vec"].cuda()
+    out = {}
+    for pair in (False, True):
+        engine.MSG_BWD_PAIR = pair
+        try:
+            e, f = EnergyForces(net, head, cache_topology=False)(z, ei, ed, ev, batch, cfg["n_mol"])
+            out[pair] = (e.cpu(), f.cpu())
+        finally:
+            engine.MSG_BWD_PAIR = False
+    assert torch.equal(out[False][0], out[True][0])
+    assert rel_err(out[True][1], out[False][1]) < 2e-6
+    assert rel_err(out[True][1], t["forces"]) < 1e-4 and rel_err(out[False][1], t["forces"]) < 1e-4
+
+
+@pytest.mark.gpu
 def test_gata_module_edge_cases():
     """GATA.forward: no edges -> the (normalised) inputs come back; an n_edges that is not the out-degree of the
     sources raises instead of being ignored."""
