@@ -1331,6 +1331,14 @@ extern "C" int gn_htr_backward(const float* g_t_out, const float* pre_t, const f
     return GN_OK;
 }
 
+// the {3} group runs under its own occupancy hint (gn_tune.h); only the forms that are launched are instantiated
+template <int L, int LLO, int LHI, bool SC, int FC>
+static inline void gn_launch_msg_bwd_group(dim3 grid, dim3 block, hipStream_t st, const gn::MsgBwdArgs& p, float* ga_slice, float* cut_slice) {
+    if constexpr (LLO == 3 && LHI == 3)
+        hipLaunchKernelGGL((gn::msg_bwd_merged_group3_kernel<L, LLO, LHI, SC, FC>), grid, block, 0, st, p, ga_slice, cut_slice);
+    else
+        hipLaunchKernelGGL((gn::msg_bwd_merged_group_kernel<L, LLO, LHI, SC, FC>), grid, block, 0, st, p, ga_slice, cut_slice);
+}
 // (lmax >= 3 with sep_dir and sep_tensor never comes here -- the degree groups take it -- so that form is not instantiated)
 template <int L, bool SD, bool ST, int FC>
 static inline void gn_launch_msg_bwd_merged(dim3 grid, dim3 block, hipStream_t st, const gn::MsgBwdArgs& p, float* ga_parts) {
@@ -1401,12 +1409,7 @@ extern "C" int gn_message_backward(
         if (ga_parts == nullptr || E <= 0) return GN_ERR_BAD_ARG;
         const size_t gs = (size_t)E * H;
 #define GN_MSGB_M(L, LLO, LHI, SC, G, FC)                                                                    \
-    if ((LLO) == 3 && (LHI) == 3)                                                                            \
-        hipLaunchKernelGGL((gn::msg_bwd_merged_group3_kernel<L, LLO, LHI, SC, FC>), grid, block, 0, st, p,   \
-                           ga_parts + (size_t)(G) * gs, g_cut + (size_t)(G) * E);                            \
-    else                                                                                                     \
-        hipLaunchKernelGGL((gn::msg_bwd_merged_group_kernel<L, LLO, LHI, SC, FC>), grid, block, 0, st, p,    \
-                           ga_parts + (size_t)(G) * gs, g_cut + (size_t)(G) * E)
+    gn_launch_msg_bwd_group<L, LLO, LHI, SC, FC>(grid, block, st, p, ga_parts + (size_t)(G) * gs, g_cut + (size_t)(G) * E)
         // by-source group kernels with the per-edge work merged in (t_filter read once; head sums and cut slices per group)
         // -> attention backward over the summed head gradients -> g_k
 #define GN_MSGB_GROUPS(FC)                                                                                       \
