@@ -324,7 +324,9 @@ int gn_message_backward(const float* x, const float* v, int ldxv, const float* e
  * and SiLU: {scalar,1,2}, {3}, {4}).  g_cut must then hold G consecutive [E] slices and ga_parts
  * G x [E,H] floats of workspace.  With G = 1, ga_parts ([E,H] floats) selects the single-read form of the register-tiled
  * kernels (the by-source kernel does the per-edge work, then attention backward, then g_k: t_filter is read once);
- * ga_parts = NULL keeps the by-target / by-source pair (t_filter read by both).
+ * ga_parts = NULL keeps the by-target / by-source pair (t_filter read by both).  The same holds for X_in == NULL (the first
+ * interaction) at every lmax <= 4: with ga_parts ([E,H] floats) the single-read kernel runs in its form without the tensor-gate
+ * blocks, without it the zero-X_in forms of the pair.  Same gradients either way (summation order aside).
  * GN_LMAX_MAX in `lmax` (the reference's aggr = "max", gotennet.py:638-639): ga_parts is instead a workspace of
  * E x (1 + D) x F floats -- the upstream gradient of every per-edge MESSAGE, routed to the arg-max edge(s) of each output
  * element (evenly among exact ties, as torch's amax) before the degree-sliced backward kernels run; G = 1, X_in required. */
