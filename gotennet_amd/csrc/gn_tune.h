@@ -8,7 +8,8 @@
 #define GN_WPE_ATTR(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 
 #ifndef GN_W_K6
-#define GN_W_K6 2          // message_aggregate_kernel: 117.5 -> 105.1 us (lmax=2)
+#define GN_W_K6 3          // message_aggregate_kernel: 117.5 -> 105.1 us (lmax=2) with 2 in round 2; re-swept on the compile-time-width kernel at the
+                           // end of round 5: none 137 us, 2 93.5, 3 90.5, 4 139 (message stage 108.0 -> 105.0 us)
 #endif
 #ifndef GN_W_K6_G
 #define GN_W_K6_G 3        // message_aggregate_group_kernel: 290 -> 250 (2) -> 234 us (3) per layer (lmax=4, three launches)
