@@ -144,7 +144,9 @@ def compact_line(full):
     ``full`` is the complete record (what round 3 printed); it is written to a side file by ``emit``."""
     out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                 "scaling", "vs_baseline", "dtype", "data", "config", "n_ranks_seen", "energy_vector_len",
-                                "energy_checksum", "rank_ms_per_step", "launch_mode", "batches_in_flight")
+                                "energy_checksum", "rank_ms_per_step", "launch_mode", "batches_in_flight",
+                                "value_one_at_a_time", "ms_per_batch_one_at_a_time", "roofline_target",
+                                "lanes_consistent", "lanes_fallback")
            if k in full and not (k == "rank_ms_per_step" and full[k] is None)}
     out["roofline"] = _roof_compact(full.get("roofline"))
     if out["roofline"] is not None:
@@ -332,6 +334,21 @@ def worker(a):
         if lt:
             LIVE_TRAFFIC.update(lt, _key=(a.workload, a.batch, a.lmax))
     res = measure(a, a.workload, a.batch, a.lmax, a.steps, a.warmup, rank, world, dev, dist)
+    one_at_a_time = None
+    if world > 1 and res["lanes"] > 1:
+        # N > 1: the same K steps one at a time as well (both figures in the record).  Should the laned run have lost a
+        # shard or a rank (verdict shared by all ranks: an all-reduced flag), the one-at-a-time run IS the headline.
+        import copy
+        a1 = copy.copy(a)
+        a1.lanes = 1
+        res1 = measure(a1, a.workload, a.batch, a.lmax, a.steps, a.warmup, rank, world, dev, dist)
+        if rank == 0:
+            one_at_a_time = {"value": res1["out"]["value"], "ms_per_batch": res1["out"]["ms_per_step"]}
+        if not res["lanes_ok"] or res["n_ranks_seen"] != world:
+            if rank == 0:
+                res1["out"]["lanes_fallback"] = (f"{res['lanes']} batches in flight failed the shard check "
+                                                 f"(value {res['out']['value']}): headline = one step at a time")
+            res = res1
     sides = world == 1                              # side measurements only on the single-GPU line
     side = lat = lat_batch = None
     wl = {}
@@ -363,6 +380,10 @@ def worker(a):
     inflight = None
     if sides and not a.no_static:                   # the same fresh-topology step at 1 / 2 / 3 batches in flight
         inflight = {str(n): in_flight(a, res["rep"], res["head"], dev, a.lmax, lanes=n) for n in (1, 2, 3)}
+    elif sides:                                     # the one-at-a-time (latency) figure is always in the record
+        inflight = {"1": in_flight(a, res["rep"], res["head"], dev, a.lmax, lanes=1)}
+    if inflight is not None and rank == 0:
+        one_at_a_time = {"value": inflight["1"]["value"], "ms_per_batch": inflight["1"]["ms_per_batch"]}
     fwd = None
     if sides and not a.no_forward_only:
         fwd = forward_only(a, res["rep"], res["head"], dev)
@@ -395,8 +416,16 @@ def worker(a):
             also.setdefault("other_projection_modes", {})[mode] = {
                 "dtype": so["dtype"], "value": so["value"], "unit": so["unit"], "ms_per_step": so["ms_per_step"],
                 "steps": so["steps"], "roofline": so["roofline"]}
+        if one_at_a_time is not None:               # top-level: the latency figure next to the in-flight throughput
+            out["value_one_at_a_time"] = one_at_a_time["value"]
+            out["ms_per_batch_one_at_a_time"] = one_at_a_time["ms_per_batch"]
         if side is not None:
             also["lmax4"] = sub(side["out"])
+            # top-level copy of the north-star TARGET shape's record (n_atom_basis=256, lmax=4): >= 0.40 of the HBM roofline
+            # on the edge gather / scatter is the stated target; the headline line is the reference's default lmax=2
+            out["roofline_target"] = {"config": side["out"]["config"]["workload"][:120], **{
+                k: v for k, v in _side_compact(side["out"]).items() if k in
+                ("gather_frac", "gather_frac_general", "htr_frac", "msg_bwd_frac", "htr_bwd_frac", "ms_per_step", "value")}}
         for k, v in wl.items():
             also[k] = sub(v["out"])
         if not a.no_cpu_baseline and world == 1:
@@ -567,20 +596,25 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
     # the first one's power-capped matrix kernels.  Every step is still one batch of B molecules through the
     # whole path incl. its all-reduce; the event-bracketed steps at the end of the timed region run ALONE (lanes drained).
     lanes = 1 if (a.replay or a.lanes < 2) else a.lanes
-    fl = lane_e_all = None
+    fl = reducer = None
     if lanes > 1:
         from gotennet_amd.pipeline import InFlight
         fl = InFlight(rep, head, lanes=lanes, check_edges=False, cache_topology=not fresh)
-        lane_e_all = [torch.zeros(B * world, dtype=torch.float32, device=dev) for _ in range(lanes)]
+        if dist is not None:
+            # every lane's all-reduce leaves from ONE communication stream in submission order (parallel.OrderedReducer):
+            # ranks whose lanes drift against each other still issue the same sequence of collectives
+            from gotennet_amd.parallel import OrderedReducer
+            reducer = OrderedReducer(B * world, rank * B, dev, slots=lanes)
 
     def step_lane():
-        buf = lane_e_all[fl.next_lane]
-        then = (lambda e_, f_: reduce_energies(e_[:, 0], rank * B, B * world, out=buf)) if dist is not None else None
+        then = (lambda e_, f_: reducer.submit(e_[:, 0])) if reducer is not None else None
         return fl(z, ei, ed, ev, batch, B, mol_ptr=None if fresh else mol_ptr, _then=then)
 
     def fence():
         if fl is not None:
             fl.wait()
+        if reducer is not None:
+            reducer.wait()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -628,6 +662,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
     ev_steps = min(1 if lanes > 1 else 3, steps)
     kt = KernelTimer(wanted=set())
     _lib.TIMER = kt
+    lane_last = None
     fence()
     t0 = time.perf_counter()
     for it in range(steps):
@@ -640,6 +675,8 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
             e, f = step()
         else:
             e, f = step_lane() if fl is not None else step()
+            if reducer is not None:
+                lane_last = (e, reducer.bufs[(reducer.submitted - 1) % len(reducer.bufs)])
     fence()
     dt = time.perf_counter() - t0
     step_fn.replay = replay
@@ -659,8 +696,18 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
     # what the collective produced: every rank's shard present exactly once in the all-reduced vector
     n_ranks_seen = dist.get_world_size() if dist is not None else 1
     e_vec = e_all if dist is not None else e[:, 0]
+    lanes_ok = True
     if dist is not None:
         assert torch.equal(e_all[rank * B:(rank + 1) * B], e[:, 0]), "all-reduced energy vector lost this rank's shard"
+        # the same for the LAST laned step (its collective left from the reducer's communication stream), and the count of
+        # non-zero entries of its vector = every rank's shard arrived in THAT collective; the verdict is shared by all ranks
+        ok = 1.0
+        if lane_last is not None:
+            e_l, buf = lane_last
+            ok = float(torch.equal(buf[rank * B:(rank + 1) * B], e_l[:, 0]) and int((buf != 0).sum()) == B * world)
+        flag = torch.tensor([ok], dtype=torch.float32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        lanes_ok = bool(flag.item() == 1.0)
     energy_checksum = float(e_vec.double().sum())
 
     tot, cnt = kt.summary()
@@ -833,7 +880,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
                               if fresh else "eager launches; static topology (index arrays cached across steps)")
                              + (f"; {lanes} batches in flight on {lanes} HIP streams for the first {steps - ev_steps} timed steps, the last "
                                 f"{ev_steps} (HIP-event brackets) one at a time" if lanes > 1 else "; one step at a time"))),
-            "batches_in_flight": lanes,
+            "batches_in_flight": lanes, "lanes_consistent": lanes_ok,
             "roofline": roof_gemm_family() if dominant == "gn_gemm" else
             (roof_message() if dominant in MSG_STAGE else roof_other(dominant)),
             "roofline_gather_scatter": roof_message(),
@@ -855,7 +902,7 @@ def measure(a, workload, B, lmax, steps, warmup, rank, world, dev, dist):
             "2 x FETCH + WRITE KiB per the gfx950 note), per-launch averages" if live else
             "committed rocprofv3 --pmc passes of this workload (profiles/pmc_traffic.json, FETCH_SIZE x2 + WRITE_SIZE per "
             "the gfx950 note), not re-measured in this run")
-    return {"out": out, "rep": rep, "head": head}
+    return {"out": out, "rep": rep, "head": head, "lanes": lanes, "lanes_ok": lanes_ok, "n_ranks_seen": n_ranks_seen}
 
 
 #: HBM bytes per launch measured IN THIS RUN (tag -> bytes), filled by live_traffic() before the headline record is built

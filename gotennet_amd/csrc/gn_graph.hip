@@ -76,9 +76,10 @@ __global__ void csc_count_kernel(const int* __restrict__ src, int E, int* __rest
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < E) atomicAdd(cnt + src[e], 1);
 }
-// one workgroup: colptr = exclusive scan of cnt (N + 1 entries), cursor = a copy of colptr[0..N) for the scatter
-__global__ __launch_bounds__(1024) void csc_scan_kernel(const int* __restrict__ cnt, int N, int* __restrict__ colptr,
-                                                        int* __restrict__ cursor) {
+// one workgroup: colptr = exclusive scan of cnt (N + 1 entries), cursor = a copy of colptr[0..N) for the scatter.
+// `cursor` MAY alias `cnt` (the launcher scans in place: a thread reads cnt[n] before it writes cursor[n], and no other
+// thread touches entry n) -- neither pointer is __restrict__
+__global__ __launch_bounds__(1024) void csc_scan_kernel(const int* cnt, int N, int* __restrict__ colptr, int* cursor) {
     __shared__ int part[16];
     __shared__ int carry;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -126,11 +127,15 @@ __global__ __launch_bounds__(256) void csc_rank_kernel(const int* __restrict__ c
     }
 }
 
-// offsets of the molecules in a SORTED batch vector: mol_ptr[m] = first atom with batch >= m  (m = 0 .. n_mol)
+// offsets of the molecules in a SORTED batch vector: mol_ptr[m] = first atom with batch >= m  (m = 0 .. n_mol).
+// Precondition: batch non-decreasing (molecules contiguous, what a PyG Batch gives).  For ANY input every entry 0 .. n_mol is
+// written with a value in [0, N] (the sequence -1, batch[0], .., batch[N-1], n_mol crosses every m at least once; negative and
+// too-large entries are clamped), so a bad batch vector gives wrong molecule sums, never an out-of-bounds access
 __global__ void molecule_ptr_kernel(const int64_t* __restrict__ batch, int N, int n_mol, int* __restrict__ mol_ptr) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n > N) return;
-    const int64_t lo = n == 0 ? 0 : batch[n - 1] + 1;            // molecules lo .. hi start at atom n
+    int64_t lo = n == 0 ? 0 : batch[n - 1] + 1;                  // molecules lo .. hi start at atom n
+    if (lo < 0) lo = 0;
     const int64_t hi = n == N ? n_mol : batch[n];
     for (int64_t m = lo; m <= hi && m <= n_mol; ++m) mol_ptr[m] = n;
 }

@@ -447,7 +447,9 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
     if save:
         tape.feat, tape.y_pre, tape.h0 = feat, y_pre, h
 
-    X = torch.zeros((N, D, F_), **f32)            # gotennet.py:992
+    # gotennet.py:992: X starts as the zero tensor.  Where the first interaction runs the zero-X_in kernels nothing ever reads
+    # it (message stage and message backward get a null X_in): no fill launch
+    X = new(N, D, F_) if (zero_X_in(cfg, 0) and pw.layers) else torch.zeros((N, D, F_), **f32)
     lde = (1 + M) * F_
     nact, g1act = new(N, 4 * F_), new(N, F_)       # activated copies (scratch, shared by all layers)
     eq_fused, eq_arith = eqff_fused_ok(cfg, N), (1 if proj.mode == "split" else 2)

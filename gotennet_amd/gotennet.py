@@ -442,8 +442,8 @@ class GotenNet(nn.Module):
         ``packed_weights`` notices parameter updates through autograd's version counter (optimizer steps,
         ``load_state_dict``, ``copy_`` / ``fill_`` under ``torch.no_grad()``) and through ``data_ptr`` (``.to()``,
         ``.cuda()``).  A write through ``param.data`` (``p.data.copy_(...)``, EMA weight swaps written that way) bumps
-        NEITHER: call this method after such a write.  (A replaced parameter OBJECT is noticed: every slot of the module
-        tree is checked for identity on each call.)"""
+        NEITHER: call this method after such a write.  (A replaced parameter or submodule OBJECT is noticed: every parameter,
+        buffer and submodule slot of the module tree is checked for identity on each call.)"""
         self._packed = self._packed_key = self._packed_params = None
 
     def load_state_dict(self, *args, **kwargs):
@@ -506,26 +506,37 @@ class GotenNet(nn.Module):
                              fuse_eqff=self.fuse_eqff, aggr=g0.aggr_kind)
 
     def _param_slots(self):
-        """(owner's ``_parameters`` / ``_buffers`` dict, name, tensor) of every parameter and buffer of the tree."""
+        """(owner's ``_parameters`` / ``_buffers`` / ``_modules`` dict, name, object) of every parameter, buffer AND
+        submodule slot of the tree: a replaced submodule (``net.gata_list[i] = new_layer``) leaves the old module's own
+        dicts intact, so the parent's ``_modules`` slot is what has to be checked for it."""
         out = []
         for m in self.modules():
             out += [(m._parameters, n, t) for n, t in m._parameters.items() if t is not None]
             out += [(m._buffers, n, t) for n, t in m._buffers.items() if t is not None]
+            out += [(m._modules, n, c) for n, c in m._modules.items() if c is not None]
         return out
+
+    def packed_is_current(self) -> bool:
+        """True when ``packed_weights()`` would return the cached pack (no rebuild, no allocation, no launch)."""
+        slots = self._packed_params
+        if slots is None or self._packed is None or any(d.get(n) is not t for d, n, t in slots):
+            return False
+        return self._packed_key == tuple((t.data_ptr(), t._version) for _, _, t in slots if isinstance(t, Tensor))
 
     def packed_weights(self) -> engine.PackedWeights:
         """Concatenate the projections that share an input into single GEMM operands
         (cached; rebuilt when any parameter is modified or moved)."""
         # (walking the module tree costs 0.3 ms -- a sixth of the host time of a one-molecule eager step: the walk is kept as
-        #  (owner dict, name, tensor) triples.  Every call checks that each slot still holds THAT tensor object -- a replaced
-        #  Parameter (torch.func.functional_call, a parent module's load_state_dict(assign=True), parametrize,
-        #  ``layer.weight = nn.Parameter(...)``) fails the identity test and triggers a new walk -- and compares the
+        #  (owner dict, name, object) triples over the parameter, buffer and submodule slots.  Every call checks that each
+        #  slot still holds THAT object -- a replaced Parameter (torch.func.functional_call, a parent module's
+        #  load_state_dict(assign=True), parametrize, ``layer.weight = nn.Parameter(...)``) or a replaced submodule
+        #  (``net.gata_list[i] = layer``) fails the identity test and triggers a new walk -- and compares the
         #  addresses / version counters of the kept tensors: O(P) dictionary look-ups, no tree walk)
         slots = self._packed_params
         if slots is None or any(d.get(n) is not t for d, n, t in slots):
             slots = self._packed_params = self._param_slots()
             self._packed = None
-        key = tuple((t.data_ptr(), t._version) for _, _, t in slots)
+        key = tuple((t.data_ptr(), t._version) for _, _, t in slots if isinstance(t, Tensor))
         if self._packed is not None and key == self._packed_key:
             return self._packed
         c = lambda *ts: torch.cat([t.detach() for t in ts], dim=0).contiguous()

@@ -56,7 +56,10 @@ class ScaleShift(nn.Module):
 
 
 def molecule_ptr(batch: torch.Tensor, n_mol: int) -> torch.Tensor:
-    """int32 [n_mol+1] offsets of each molecule in the (sorted) batch vector -- index plumbing."""
+    """int32 [n_mol+1] offsets of each molecule in the batch vector -- index plumbing.  Precondition: ``batch`` is
+    non-decreasing (each molecule's atoms contiguous: what a PyG ``Batch`` carries and ``radius_graph(batch=batch)`` assumes).
+    An unsorted vector gives wrong per-molecule sums (in-bounds by construction, gn_graph.hip); ``EnergyForces(check_edges=True)``
+    validates it."""
     out = torch.empty(n_mol + 1, dtype=torch.int32, device=batch.device)
     if batch.is_cuda and batch.dtype == torch.int64:           # one launch, no host read (torch.bincount synchronises)
         call("gn_molecule_ptr", ptr(batch.contiguous()), batch.shape[0], n_mol, ptr(out), engine._stream())

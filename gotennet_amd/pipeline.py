@@ -17,7 +17,8 @@ from .outputs import Atomwise, molecule_ptr
 class EnergyForces:
     """``check_edges`` (default on): validate the caller's edge list on the device (index range, target-major order;
     one host sync per call) and stable-sort it by target when needed -- energies and forces are per molecule / per atom,
-    so the order of the edge list never shows in the result.  Callers that pass radius-graph output
+    so the order of the edge list never shows in the result; the ``batch`` vector must be non-decreasing (molecules
+    contiguous) and is checked too.  Callers that pass radius-graph output
     (``gotennet_amd.graph.distance``: target-major by construction) switch it off and stay sync-free."""
 
     def __init__(self, representation: GotenNet, head: Atomwise, check_edges: bool = True, cache_topology: bool = True,
@@ -93,6 +94,9 @@ class EnergyForces:
             if mkey is not None and self._mol_ptr is not None and self._mol_ptr[0] == mkey and self._mol_ptr[1] is batch:
                 mol_ptr = self._mol_ptr[2]
             else:
+                if self.check_edges and N > 1 and bool((batch[1:] < batch[:-1]).any()):
+                    # (a host read, like the edge validation; not repeated for a cached batch vector)
+                    raise ValueError("batch must be non-decreasing (each molecule's atoms contiguous)")
                 mol_ptr = molecule_ptr(batch, n_mol)
                 self._mol_ptr = (mkey, batch, mol_ptr) if mkey is not None else None
         gs = self._graph_state
@@ -181,13 +185,30 @@ class InFlight:
         lanes.wait()                      # the CURRENT stream now waits for every lane: results are safe to read
 
     Inputs must be ready on the current stream when a call is made (each lane waits for the current stream first).
-    Every lane keeps its own topology cache; tensors a lane returns were allocated on that lane's stream."""
+    Every lane keeps its own topology cache.
+
+    Memory lifetime across the streams (PyTorch's caching allocator hands a freed block back to the stream it was
+    allocated on, without waiting for OTHER streams that still read it):
+      * every tensor argument of a call is ``record_stream``-ed on the lane's stream, so the caller may drop or overwrite-by-
+        reallocation its inputs right after the call returns (the normal data-loader loop);
+      * the tensors a call returns were allocated on the lane's stream; the object keeps a reference to them until the next
+        ``wait()``, which marks them as used on the stream that waits -- read results only after ``wait()``, on that stream;
+      * a weight update (a stale pack) makes the call wait for ALL lanes before the old pack's operands are freed."""
 
     def __init__(self, representation: GotenNet, head: Atomwise, lanes: int = 2, **kw):
         dev = next(representation.parameters()).device
         self.lanes = [EnergyForces(representation, head, **kw) for _ in range(max(1, int(lanes)))]
         self.streams = [torch.cuda.Stream(device=dev) for _ in self.lanes]
         self._k, self._seen = 0, set()
+        self._pending = []                           # tensors returned since the last wait()
+
+    @staticmethod
+    def _tensors(objs):
+        for o in objs:
+            if isinstance(o, torch.Tensor):
+                yield o
+            elif isinstance(o, (tuple, list)):
+                yield from InFlight._tensors(o)
 
     def __call__(self, *args, _then=None, **kw):
         """``_then(energy, forces)`` (optional) runs inside the lane's stream context right after the step is enqueued -- e.g. the
@@ -195,8 +216,16 @@ class InFlight:
         k = self._k % len(self.lanes)
         self._k += 1
         st = self.streams[k]
-        pack_id = id(self.lanes[k].rep.packed_weights())     # (a stale pack is rebuilt HERE, on the caller's stream, before the lane waits for it)
+        rep = self.lanes[k].rep
+        if not rep.packed_is_current():
+            # a weight update: the old pack's operands (cat'ed weights, fp16 planes, transposes) may still be read by kernels
+            # queued on other lanes -- everything drains into the current stream before the rebuild frees them
+            self.wait()
+        pack_id = id(rep.packed_weights())           # (a stale pack is rebuilt HERE, on the caller's stream, before the lane waits for it)
         st.wait_stream(torch.cuda.current_stream(st.device))
+        for t in self._tensors(list(args) + list(kw.values())):
+            if t.is_cuda:
+                t.record_stream(st)                  # read on the lane's stream: not reusable by the caller's stream before that
         # The first call of a kind (with / without forces) builds lazily cached operands that ALL lanes share -- packed
         # weights, their fp16 planes, the transposes of the backward -- on THIS lane's stream: it runs alone, fenced against
         # the other lanes on both sides.  Later calls find the caches filled and overlap freely.
@@ -215,6 +244,7 @@ class InFlight:
             for other in self.streams:
                 if other is not st:
                     other.wait_stream(st)
+        self._pending.extend(self._tensors(out))
         return out
 
     @property
@@ -222,9 +252,14 @@ class InFlight:
         return self._k % len(self.lanes)
 
     def wait(self):
+        """The CURRENT stream waits for every lane; the tensors returned since the last ``wait()`` are marked as used on it."""
         cur = torch.cuda.current_stream(self.streams[0].device)
         for st in self.streams:
             cur.wait_stream(st)
+        for t in self._pending:
+            if t.is_cuda:
+                t.record_stream(cur)
+        self._pending = []
 
     def clear_cache(self):
         for ef in self.lanes:

@@ -128,6 +128,27 @@ def test_packed_cache_sees_replaced_parameter_objects():
     assert torch.equal(net.packed_weights().layers[0].Wn1[:32], net.gata_list[0].W_q.weight)
 
 
+def test_packed_cache_sees_replaced_submodules():
+    """``net.gata_list[i] = new_layer`` (or a swapped node_init) leaves the OLD module's parameter dicts intact,
+    so an identity check of parameter slots alone keeps the stale pack forever.  The submodule slots are part of the key."""
+    import gotennet_amd
+    mk = lambda: gotennet_amd.GotenNet(n_atom_basis=32, n_interactions=2, n_rbf=8, cutoff_fn=gotennet_amd.CosineCutoff(5.0), lmax=2)
+    net, donor = mk(), mk()
+    pw0 = net.packed_weights()
+    assert net.packed_is_current()
+    net.gata_list[0] = donor.gata_list[0]
+    assert not net.packed_is_current()
+    pw1 = net.packed_weights()
+    assert pw1 is not pw0 and torch.equal(pw1.layers[0].Wn1[:32], donor.gata_list[0].W_q.weight)
+    assert net.packed_is_current() and net.packed_weights() is pw1
+    net.node_init = donor.node_init
+    pw2 = net.packed_weights()
+    assert pw2 is not pw1 and torch.equal(pw2.A_nbr, donor.node_init.A_nbr.weight)
+    with torch.no_grad():
+        net.eqff_list[1].W_vu.weight.add_(1.0)
+    assert not net.packed_is_current()
+
+
 # --------------------------------------------------------------------------------------------------- GPU
 def _mirror(cfg, sd):
     from tests.test_hip_parity import _net_from_case
@@ -210,6 +231,14 @@ def test_energy_forces_accepts_any_edge_order_and_rejects_bad_indices():
         CapturedStep(ef, z, bad, batch, cfg["n_mol"])
     with pytest.raises(ValueError):
         net(z, bad, ed, ev)
+    if cfg["n_mol"] > 1:                                         # an unsorted batch vector is rejected, not mis-summed
+        with pytest.raises(ValueError):
+            ef(z, ei, ed, ev, batch.flip(0).contiguous(), cfg["n_mol"])
+    # the molecule-offset kernel stays in bounds on ANY batch vector (negative / too large / unsorted entries)
+    from gotennet_amd.outputs import molecule_ptr
+    for bv in ([3, -2, 9, 0, 1], [5, 5, 5], [-1, -1], [0, 2, 1, 2, 0]):
+        mp_ = molecule_ptr(torch.tensor(bv, dtype=torch.int64).cuda(), 3).cpu()
+        assert mp_.shape == (4,) and int(mp_.min()) >= 0 and int(mp_.max()) <= len(bv)
     # CapturedStep on a shuffled list: same result as the eager path
     step = CapturedStep(ef, z, ei[:, order], batch, cfg["n_mol"])
     e3, f3 = step(t["pos"].cuda())
@@ -855,3 +884,49 @@ def test_in_flight_lanes_match_single_lane():
     ref = [plain(z, ei, ed, ev, batch, cfg["n_mol"]) for ei, ed, ev in cases]
     for (e0, f0), (e1, f1), (e2, _) in zip(ref, out, out_e):
         assert torch.equal(e0, e1) and torch.equal(f0, f1) and torch.equal(e0, e2)
+
+
+@pytest.mark.gpu
+def test_in_flight_inputs_may_be_freed_right_after_the_call():
+    """ADVICE r5 / VERDICT r5 item 5a: InFlight marks its tensor arguments as used on the lane's stream (record_stream) and the
+    returned tensors as used on the waiting stream, so a data-loader loop that drops each batch right after the call -- and whose
+    next batch lands in the recycled blocks -- still gets the bits of the keep-everything-alive run.  The caching allocator is
+    ON (the default); each iteration allocates fresh inputs of the same sizes, i.e. exactly the blocks just freed."""
+    from tests.test_hip_forces import _head_from_case
+    from gotennet_amd.graph import distance
+    from gotennet_amd.pipeline import EnergyForces, InFlight
+    cfg, sd, head_sd, t = load_case("l2_sep_f32")
+    net, head = _mirror(cfg, sd), _head_from_case(cfg, head_sd)
+    g = torch.Generator().manual_seed(3)
+    pos_all = [t["pos"] + 0.05 * torch.randn(t["pos"].shape, generator=g) for _ in range(12)]
+    plain = EnergyForces(net, head, check_edges=False, cache_topology=False)
+    ref = []
+    for pos in pos_all:
+        z, batch = t["z"].cuda(), t["batch"].cuda()
+        ref.append(plain(z, *distance(pos.cuda(), batch, cfg["cutoff"], 32), batch, cfg["n_mol"]))
+    torch.cuda.synchronize()
+    fl = InFlight(net, head, lanes=3, check_edges=False, cache_topology=False)
+    out = []
+    junk = None
+    for pos in pos_all:
+        z, batch = t["z"].cuda(), t["batch"].cuda()                 # fresh tensors every iteration ...
+        ei, ed, ev = distance(pos.cuda(), batch, cfg["cutoff"], 32)
+        out.append(fl(z, ei, ed, ev, batch, cfg["n_mol"]))
+        del z, batch, ei, ed, ev                                      # ... dropped at once: their blocks are up for reuse
+        junk = torch.full((1 << 16,), float("nan"), device="cuda")    # and something scribbles over recycled memory
+        del junk
+    fl.wait()
+    keep = [(e.clone(), f.clone()) for e, f in out]                   # consumed on the current stream after wait()
+    del out
+    torch.cuda.synchronize()
+    for (e0, f0), (e1, f1) in zip(ref, keep):
+        assert torch.equal(e0, e1) and torch.equal(f0, f1)
+    # a weight update between calls: the stale pack is rebuilt only after every lane has drained
+    with torch.no_grad():
+        net.gata_list[0].W_q.weight.mul_(1.0001)
+    z, batch = t["z"].cuda(), t["batch"].cuda()
+    ei, ed, ev = distance(pos_all[0].cuda(), batch, cfg["cutoff"], 32)
+    e_new, f_new = fl(z, ei, ed, ev, batch, cfg["n_mol"])
+    fl.wait()
+    e_ref, f_ref = plain(z, ei, ed, ev, batch, cfg["n_mol"])
+    assert torch.equal(e_new, e_ref) and torch.equal(f_new, f_ref)

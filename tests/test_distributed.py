@@ -130,3 +130,47 @@ def test_bench_eight_ranks_as_the_driver_launches_them():
     # and the self-launching form the driver falls back to: `python bench.py --gpus 8`
     eight = _bench_selftest(world, B)
     assert eight["n_ranks_seen"] == world and abs(eight["energy_checksum"] - d["energy_checksum"]) < 1e-6 * abs(d["energy_checksum"])
+
+
+def _ordered_worker(rank, world, port, B, steps, lanes, q):
+    """2 ranks x 3 lanes: the bench's laned step with CPU tensors standing in for the energies.  Each rank drives its lanes
+    round-robin; a lane's "energies" of step s are s-dependent, so a collective that paired step s of one rank with step
+    s' != s of the other would show in the sums."""
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gotennet_amd.parallel import OrderedReducer
+    red = OrderedReducer(B * world, rank * B, "cpu", slots=lanes)
+    seen = []
+    for s in range(steps):
+        if (s + rank) % 3 == 0:
+            time.sleep(0.01)                          # the ranks drift against each other
+        e_local = torch.arange(B, dtype=torch.float32) + 100.0 * s + 1000.0 * rank + 1.0
+        out = red.submit(e_local)
+        assert out is red.bufs[s % lanes]
+        seen.append(out.clone())
+    red.wait()
+    q.put((rank, [tuple(o) for o in red.order], torch.stack(seen)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ordered_reducer_two_ranks_three_lanes():
+    """for world > 1 every lane's all-reduce leaves in SUBMISSION order from one place
+    (parallel.OrderedReducer; on a GPU: one communication stream that waits on the lane's stream).  gloo, CPU tensors."""
+    B, world, steps, lanes = 4, 2, 7, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ordered_worker, args=(r, world, port, B, steps, lanes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = torch.stack([torch.cat([torch.arange(B, dtype=torch.float32) + 100.0 * s + 1000.0 * r + 1.0 for r in range(world)])
+                        for s in range(steps)])
+    for rank, order, seen in res:
+        assert order == [(s, s % lanes) for s in range(steps)]
+        assert torch.equal(seen, want)                # step s of rank 0 met step s of rank 1, every shard exactly once

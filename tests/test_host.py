@@ -182,6 +182,16 @@ def test_bench_line_fits_driver_tail():
         for k in ("value", "ms_per_step", "gather_frac", "htr_frac", "msg_bwd_frac", "gemm_frac"):
             assert k in out["also"][wl], (wl, k)
     assert out["value"] == full["value"] and out["ms_per_step"] == full["ms_per_step"]
+    # round 6: the latency figure and the north-star target shape's record are TOP-LEVEL keys of the line
+    full6 = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_full.json")))
+    full6.update(value_one_at_a_time=19341.0, ms_per_batch_one_at_a_time=6.618, lanes_consistent=True,
+                 roofline_target={"config": "rmd17_aspirin batch=128/GPU lmax=4", "gather_frac": 0.42, "gather_frac_general": 0.43,
+                                  "htr_frac": 0.31, "msg_bwd_frac": 0.44, "htr_bwd_frac": 0.23, "ms_per_step": 12.2, "value": 10500.0})
+    line6 = bench.compact_line(full6)
+    out6 = json.loads(line6)
+    assert len(line6) < bench.LINE_BUDGET and "also" in out6
+    assert out6["value_one_at_a_time"] == 19341.0 and out6["ms_per_batch_one_at_a_time"] == 6.618
+    assert out6["roofline_target"]["gather_frac"] == 0.42 and "lmax=4" in out6["roofline_target"]["config"]
     # a pathological record (a huge `also`) sheds `also`, never the contract keys
     fat = dict(full)
     fat["also"] = {f"w{i}": dict(full["also"]["lmax4"], config="x" * 80) for i in range(40)}
