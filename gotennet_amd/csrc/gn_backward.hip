@@ -953,7 +953,8 @@ __global__ __launch_bounds__(256) GN_WPE(GN_W_HTR_SRC_G) void htr_bwd_source_gro
 }
 
 // =========================================================================== EQFF backward
-// part a: gm = [gh' | sum_m gX' Xp],  gXp = gX' * m2
+// part a: gm = [gh' | sum_m gX' Xp],  gXp = gX' * m2.  gX == NULL: dL/dX' is identically zero (the output layer of an
+// energy head that reads h only): no zero-filled tensor is made or read
 __global__ void eqff_bwd_a_kernel(const float* __restrict__ gh, const float* __restrict__ gX,
                                   const float* __restrict__ mm, const float* __restrict__ Xp,
                                   int N, int F, int D, float* __restrict__ gm, float* __restrict__ gXp) {
@@ -965,8 +966,8 @@ __global__ void eqff_bwd_a_kernel(const float* __restrict__ gh, const float* __r
     float4 s = zero4();
     for (int m = 0; m < D; ++m) {
         const size_t off = ((size_t)n * D + m) * F + c0;
-        const float4 g = ld4(gX + off);
-        s = fma4(g, ld4(Xp + off), s);
+        const float4 g = gX ? ld4(gX + off) : zero4();
+        s = gX ? fma4(g, ld4(Xp + off), s) : s;
         st4(gXp + off, g * m2);
     }
     st4(gm + (size_t)n * 2 * F + c0, ld4(gh + (size_t)n * F + c0));

@@ -788,7 +788,12 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
         if gX is not None:
             gX = torch.zeros((N, D, F_), **f32).index_copy_(2, pw.emb_idx, gX.contiguous())
     gh = gh.contiguous()
-    gX = torch.zeros((N, D, F_), **f32) if gX is None else gX.contiguous()
+    # dL/dX = None (an energy head reads h only): the un-fused EQFF backward takes a null pointer for it (no zero-filled
+    # [N,D,F] tensor is made, written or read); the fused kernel wants the tensor
+    if gX is None:
+        gX = torch.zeros((N, D, F_), **f32) if eq_fused else None
+    else:
+        gX = gX.contiguous()
     gh_caller, gX_caller = gh, gX                  # read-only: never enter the work-buffer rotation below
     gt = None                                      # dL/dt of the layer output (None = 0)
 

@@ -333,7 +333,9 @@ int gn_message_backward(const float* x, const float* v, int ldxv, const float* e
 int gn_message_backward_groups(int lmax, int sep_dir, int sep_tensor, int act);
 
 /* EQFF (gotennet.py:716-748) backward, node-local halves around the two gamma_m GEMMs:
- * a: g_m = [g_h | sum_m g_X Xp], g_Xp = g_X * m2;   b: g_Xp += g_ctx[:,F:] Xp / n, g_h1 = g_h + g_ctx[:, :F]. */
+ * a: g_m = [g_h | sum_m g_X Xp], g_Xp = g_X * m2;   b: g_Xp += g_ctx[:,F:] Xp / n, g_h1 = g_h + g_ctx[:, :F].
+ * g_X == NULL in (a): dL/dX of the block's output is identically zero (an energy head that reads h only,
+ * outputs.py:333-346): g_m = [g_h | 0], g_Xp = 0, nothing is read in its place. */
 int gn_eqff_backward_a(const float* g_h, const float* g_X, const float* m, const float* Xp,
                        int N, int F, int D, float* g_m, float* g_Xp, void* stream);
 int gn_eqff_backward_b(const float* g_ctx, const float* ctx, const float* Xp, const float* g_h,

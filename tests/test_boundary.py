@@ -51,6 +51,7 @@ def test_oracle_deep_head_matches_reference_kat():
 def test_weight_init_names_of_the_reference():
     """Every init name the reference accepts (layers.py:426-452) builds a module (checkpoints carry them as strings)."""
     import gotennet_amd
+    torch.manual_seed(0)                                         # (the variance checks below are statistical: fixed draws)
     for name in ("xavier_uniform", "glo_orthogonal", "he_orthogonal", "zeros", ""):
         net = gotennet_amd.GotenNet(n_atom_basis=32, n_interactions=1, n_rbf=8, cutoff_fn=gotennet_amd.CosineCutoff(5.0),
                                     lmax=1, weight_init=name)
