@@ -735,6 +735,18 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     // the f16x2 small tile is 32 x 128 (waves 1 x 4: a row is split once per 128 columns) unless a problem is narrower than a tile
     bool wide = GN_F16_SMALL_WIDE && split == 2;
     for (int i = 0; i < n; ++i) wide = wide && g[i].N >= 128;
+    // f16x2, small-tile groups with many rows: 64 x 128 tiles (waves 1 x 4 of 2 x 1 MFMA tiles) -- a weight fragment serves two
+    // row tiles, half the L2 -> CU weight traffic of the 32 x 128 tile per output row (GN_F16_MID_ROWS, gn_tune.h; 0: never)
+    // Measured (round 6, MI355X): the gated residual launch [54368 x 256 x 256]g + rider 75 -> 68.8 us in the step (stand-alone 69.3
+    // -> 65.7, ungated 42.9 -> 37.5); the ungated launches of the step tie or lose 2 us (their riders have K = 512), so only
+    // groups with a gated residual epilogue take it
+    long rows_all = 0;
+    bool gated = false;
+    for (int i = 0; i < n; ++i) {
+        rows_all += g[i].M;
+        gated = gated || (g[i].gate != nullptr && g[i].res != nullptr);
+    }
+    const bool mid = wide && !use_big && gated && GN_F16_MID_ROWS > 0 && rows_all >= (long)GN_F16_MID_ROWS;
     long end = 0;
     // outputs of 100 MB and more (the [E, (1+M)F] edge projection) are stored non-temporally: they are consumed by
     // later kernels from HBM anyway and would only evict the node tables (K6 +5 %); GN_GEMM_NT_MB (gn_tune.h)
@@ -748,7 +760,8 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
         const int nt_lo = GN_GEMM_NT_LO >= 0 ? GN_GEMM_NT_LO : ga.g[i].K;
         ga.g[i].nt_store = (double)ga.g[i].M * ga.g[i].N * 4.0 >= nt_min ? (ga.g[i].N > nt_lo ? nt_lo : 0) : 0x7fffffff;
         if (i < n) end += use_big ? (long)((g[i].M + BMB - 1) / BMB) * ((g[i].N + BNB - 1) / BNB)
-                                  : (wide ? (long)((g[i].M + 31) / 32) * ((g[i].N + 127) / 128)
+                                  : (mid ? (long)((g[i].M + 63) / 64) * ((g[i].N + 127) / 128)
+                                  : wide ? (long)((g[i].M + 31) / 32) * ((g[i].N + 127) / 128)
                                                                      : (long)((g[i].M + 63) / 64) * ((g[i].N + 63) / 64));
         ga.tile_end[i] = (int)end;
     }
@@ -767,7 +780,7 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
     if (end == 0) return GN_OK;
     // persistent launch: at most 2 (big tiles) / 4 (small tiles) workgroups per CU walk the tile list (+2 %)
     long grid = 8L * ((end + 7) / 8);
-    const long cap = use_big ? cap_big : (wide ? (long)GN_F16_SMALL_CAP : 1024);
+    const long cap = use_big ? cap_big : (mid ? (long)GN_F16_MID_CAP : (wide ? (long)GN_F16_SMALL_CAP : 1024));
     if (grid > cap) grid = cap;
     bool silu = true;
     for (int i = 0; i < n; ++i) silu = silu && g[i].act_kind == GN_ACT_SILU;
@@ -795,6 +808,7 @@ int gn_gemm_launch(const gn::GemmArgs* g, int n, hipStream_t st, int split) {
 #endif
     if (split == 2) {
         if (use_big) { if (pro) GN_GEMM_GO_H(4, 1, 1, 4, true); else GN_GEMM_GO_H(4, 1, 1, 4, false); }
+        else if (mid) { if (pro) GN_GEMM_GO_H(2, 1, 1, 4, true); else GN_GEMM_GO_H(2, 1, 1, 4, false); }
         else if (wide) { if (pro) GN_GEMM_GO_H(1, 1, 1, 4, true); else GN_GEMM_GO_H(1, 1, 1, 4, false); }
         else { if (pro) GN_GEMM_GO_H(1, 1, 2, 2, true); else GN_GEMM_GO_H(1, 1, 2, 2, false); }
     } else if (split) {

@@ -110,6 +110,13 @@
                                 // (waves 2 x 2).  Stand-alone [54368 x 256 x 256] 50.6 -> 47.2 us, with the gated epilogue 58.5 -> 53.9; in the
                                 // step (HBM-bound: res, gate, pre_out) 67 -> 66 us
 #endif
+#ifndef GN_F16_MID_ROWS
+#define GN_F16_MID_ROWS 30000    // f16x2 small-tile groups with a gated residual epilogue and at least this many rows run 64 x 128 tiles
+                                 // instead of 32 x 128 (0: never): a weight fragment serves two row tiles
+#endif
+#ifndef GN_F16_MID_CAP
+#define GN_F16_MID_CAP 768       // persistent workgroups of that kernel
+#endif
 #ifndef GN_F16_SMALL_CAP
 #define GN_F16_SMALL_CAP 1024     // persistent workgroups of that kernel
 #endif
