@@ -174,6 +174,8 @@ def compact_line(full):
         elif k in ("single_molecule_latency", "hipgraph_replay_full_batch"):
             also[k] = {kk: v.get(kk) for kk in ("molecules", "eager_ms_per_step", "hipgraph_replay_ms_per_step",
                                                 "bit_identical_to_eager")}
+        elif k == "lmax4" and full.get("roofline_target"):
+            continue                                 # (the top-level roofline_target carries the same record)
         elif isinstance(v, dict) and "value" in v:
             also[k] = _side_compact(v)
             if isinstance(v.get("config"), str):

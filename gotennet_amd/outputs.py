@@ -78,8 +78,12 @@ class Atomwise(nn.Module):
                  create_graph: bool = True, mean=None, stddev=None, atomref=None, outnet=None,
                  return_vector: Optional[str] = None, standardize: bool = True):
         super().__init__()
-        if n_out != 1 or outnet is not None or return_vector:
-            raise NotImplementedError("accelerated Atomwise: n_out=1, default out_net, no return_vector")
+        if n_out < 1 or outnet is not None or return_vector:
+            raise NotImplementedError("accelerated Atomwise: the default out_net (SchnetMLP), no return_vector")
+        #: ``n_out`` properties per atom (reference outputs.py:241, SchnetMLP(n_in, n_out, ...)): the last layer has n_out rows;
+        #: each is one gn_head_energy launch on the shared hidden activations, the derivative is that of the SUM of the outputs
+        #: (``grad_outputs=torch.ones_like(y)``, outputs.py:365-375)
+        self.n_out = int(n_out)
         if aggregation_mode not in ("sum", "add", "mean", None):
             raise NotImplementedError(f"aggregation_mode={aggregation_mode!r}: 'sum', 'mean' or None on the accelerated path")
         self.aggregation_mode = aggregation_mode
@@ -125,6 +129,19 @@ class Atomwise(nn.Module):
             c = dict(key=key, scale=scale, shift=shift, b2=float(layers[-1].bias.detach().cpu()[0]),
                      w=[d.weight.detach() for d in layers], b=[d.bias.detach() for d in layers],
                      wt=[d.weight.detach().t().contiguous() for d in layers[:-1]])
+            if getattr(self, "n_out", 1) > 1:        # per-output host scalars and weight rows (n_out launches share the hidden layers)
+                n_out = self.n_out
+                per = lambda t: [float(v) for v in t.detach().reshape(-1).cpu().expand(n_out).tolist()]
+                sc_l, sh_l = [1.0] * n_out, [0.0] * n_out
+                if isinstance(self.standardize, ScaleShift):
+                    sc_l, sh_l = per(self.standardize.stddev), per(self.standardize.mean)
+                w_last = layers[-1].weight.detach()
+                c.update(scales=sc_l, shifts=sh_l, b2s=[float(v) for v in layers[-1].bias.detach().cpu().tolist()],
+                         w_rows=[w_last[o].contiguous() for o in range(n_out)],
+                         # d(sum of the outputs)/d(last hidden activation): sum_o stddev_o W_o
+                         w_sum=(w_last * torch.tensor(sc_l, dtype=w_last.dtype, device=w_last.device).unsqueeze(1)).sum(0).contiguous(),
+                         atomref_cols=([self.atomref.weight.detach()[:, o].contiguous() for o in range(n_out)]
+                                       if self.atomref is not None else None))
             self._cache = c
         return layers, c
 
@@ -155,24 +172,48 @@ class Atomwise(nn.Module):
             pres.append(pre)
         last_in = pres[-1] if pres else h.contiguous()
         act = self.act_kind if pres else 11          # GN_ACT_NONE: n_layers = 1, y = W h + b
-        y, e = new(N), new(n_mol, 1)
         mean = self.aggregation_mode == "mean"
         atom_scale = new(N) if mean else None
+        if getattr(self, "n_out", 1) > 1:
+            # n_out properties: one launch per output row of the last layer on the shared hidden activations
+            n_out = self.n_out
+            y_t, e_t = new(n_out, N), new(n_out, n_mol)
+            for o in range(n_out):
+                call("gn_head_energy", ptr(last_in), ptr(c["w_rows"][o]), c["b2s"][o], 1.0 if raw else c["scales"][o],
+                     0.0 if raw else c["shifts"][o], 0.0,
+                     ptr(c["atomref_cols"][o]) if (c["atomref_cols"] is not None and not raw) else None, ptr(z32), ptr(mol_ptr),
+                     n_mol, last_in.shape[1], ptr(y_t[o]), ptr(e_t[o]), int(mean), ptr(atom_scale), act, engine._stream())
+            return e_t.t().contiguous(), y_t.t().contiguous(), (pres, last_in, atom_scale)
+        y, e = new(N), new(n_mol, 1)
         call("gn_head_energy", ptr(last_in), ptr(c["w"][-1]), c["b2"], 1.0 if raw else c["scale"], 0.0 if raw else c["shift"],
              0.0 if raw else c.get("mol_shift", 0.0),
              ptr(self.atomref.weight.detach()) if (self.atomref is not None and not raw) else None, ptr(z32), ptr(mol_ptr),
              n_mol, last_in.shape[1], ptr(y), ptr(e), int(mean), ptr(atom_scale), act, engine._stream())
         return e, y, (pres, last_in, atom_scale)
 
-    def grad_h_raw(self, tape, Fd: int, mode: Optional[str] = None) -> torch.Tensor:
-        """d(sum over molecules of the aggregated property)/dh [N,F]."""
+    def grad_h_raw(self, tape, Fd: int, mode: Optional[str] = None, upstream: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """d(sum over molecules AND outputs of the aggregated property)/dh [N,F].  ``upstream`` [N, n_out] (n_out > 1 only): a
+        per-atom, per-output weight of that sum (an autograd caller's ``grad_output`` spread to the atoms)."""
         layers, c = self._packed()
         pres, last_in, atom_scale = tape
         N, Hd = last_in.shape
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=last_in.device)
         g = new(N, Hd)
-        call("gn_head_grad", ptr(last_in), ptr(c["w"][-1]), c["scale"], ptr(atom_scale), N, Hd, ptr(g),
-             self.act_kind if pres else 11, engine._stream())
+        act_last = self.act_kind if pres else 11
+        if getattr(self, "n_out", 1) > 1 and upstream is not None:
+            # sum_o upstream[n, o] stddev_o W_o act'(.): one launch per output with a per-atom scale, summed (linear from here on)
+            part = new(N, Hd)
+            for o in range(self.n_out):
+                a_o = upstream[:, o].contiguous() if atom_scale is None else (upstream[:, o] * atom_scale).contiguous()
+                call("gn_head_grad", ptr(last_in), ptr(c["w_rows"][o]), c["scales"][o], ptr(a_o), N, Hd,
+                     ptr(g if o == 0 else part), act_last, engine._stream())
+                if o:
+                    g.add_(part)
+        elif getattr(self, "n_out", 1) > 1:
+            call("gn_head_grad", ptr(last_in), ptr(c["w_sum"]), 1.0, ptr(atom_scale), N, Hd, ptr(g), act_last, engine._stream())
+        else:
+            call("gn_head_grad", ptr(last_in), ptr(c["w"][-1]), c["scale"], ptr(atom_scale), N, Hd, ptr(g),
+                 act_last, engine._stream())
         for k in range(len(pres) - 1, -1, -1):       # g is d/d(pre_k); through layer k's weight, then act'(pre_{k-1})
             d = layers[k]
             gi = new(N, d.in_features)
@@ -183,7 +224,7 @@ class Atomwise(nn.Module):
 
     def _per_atom_property(self, e: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         """aggregation_mode=None: the property IS the per-atom contributions."""
-        return y.reshape(-1, 1).clone()
+        return y.reshape(-1, getattr(self, "n_out", 1)).clone()
 
     # ---- reference-style call --------------------------------------------------------
     def forward(self, inputs):
@@ -200,7 +241,7 @@ class Atomwise(nn.Module):
         y = _AtomwiseFn.apply(h, self, z.to(torch.int32), molecule_ptr(batch, n_mol), n_mol)
         result = {self.property: y}                  # [n_mol,1], or the per-atom values [N,1] for aggregation_mode=None
         if self.contributions:
-            result[self.contributions] = self._last_y.reshape(-1, 1)
+            result[self.contributions] = self._last_y.reshape(-1, getattr(self, "n_out", 1))
         if self.derivative:
             sign = -1.0 if self.negative_dr else 1.0
             (dy,) = torch.autograd.grad(outputs=y, inputs=[pos], grad_outputs=torch.ones_like(y), retain_graph=True)
@@ -220,6 +261,8 @@ class AtomwiseV3(Atomwise):
                  contributions: Optional[str] = None, derivative: Optional[str] = None, negative_dr: bool = True,
                  create_graph: bool = True, mean=None, stddev=None, atomref=None, outnet=None,
                  return_vector: Optional[str] = None, standardize: bool = True):
+        if n_out != 1:
+            raise NotImplementedError("accelerated AtomwiseV3: n_out=1")
         mean = 0.0 if mean is None else mean
         stddev = 1.0 if stddev is None else stddev
         as_t = lambda v: v if isinstance(v, torch.Tensor) else torch.tensor([float(v)])
@@ -254,6 +297,12 @@ class _AtomwiseFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, ge):
+        if getattr(ctx.head, "n_out", 1) > 1:        # [n_mol or N, n_out] upstream: per-atom, per-output weights of the sum
+            ge = ge.reshape(-1, ctx.head.n_out).to(torch.float32)
+            if ctx.head.aggregation_mode is not None:
+                mp = ctx.mol_ptr.long()
+                ge = torch.repeat_interleave(ge, mp[1:] - mp[:-1], dim=0)
+            return ctx.head.grad_h_raw(ctx.tape, ctx.F, upstream=ge.contiguous()), None, None, None, None
         gh = ctx.head.grad_h_raw(ctx.tape, ctx.F)
         if ctx.head.aggregation_mode is None:        # per-atom outputs: upstream gradient per atom
             return gh * ge.reshape(-1, 1), None, None, None, None

@@ -134,7 +134,8 @@ class EnergyForces:
         incl. the ScaleShift buffers) and the host scalars that become kernel arguments."""
         packed = self.head._packed()
         c = packed[1] if isinstance(packed, tuple) else packed
-        return (id(self.head), c["key"], c.get("scale"), c.get("shift"), c.get("b2"), c.get("mol_shift"))
+        return (id(self.head), c["key"], c.get("scale"), c.get("shift"), c.get("b2"), c.get("mol_shift"),
+                tuple(c.get("scales") or ()), tuple(c.get("shifts") or ()), tuple(c.get("b2s") or ()))
 
     def _capture(self, cfg, pw, g, z32, edge_index, n_mol, mol_ptr):
         dev = z32.device

@@ -189,7 +189,7 @@ def test_bench_line_fits_driver_tail():
                                   "htr_frac": 0.31, "msg_bwd_frac": 0.44, "htr_bwd_frac": 0.23, "ms_per_step": 12.2, "value": 10500.0})
     line6 = bench.compact_line(full6)
     out6 = json.loads(line6)
-    assert len(line6) < bench.LINE_BUDGET and "also" in out6
+    assert len(line6) < bench.LINE_BUDGET - 300 and "also" in out6 and "lmax4" not in out6["also"]    # (headroom: the line never sheds `also`)
     assert out6["value_one_at_a_time"] == 19341.0 and out6["ms_per_batch_one_at_a_time"] == 6.618
     assert out6["roofline_target"]["gather_frac"] == 0.42 and "lmax=4" in out6["roofline_target"]["config"]
     # a pathological record (a huge `also`) sheds `also`, never the contract keys
