@@ -202,6 +202,7 @@ class InFlight:
         self.streams = [torch.cuda.Stream(device=dev) for _ in self.lanes]
         self._k, self._seen = 0, set()
         self._pending = []                           # tensors returned since the last wait()
+        self._pack = None                            # the weight pack the lanes were last fed with (kept alive across a rebuild)
 
     @staticmethod
     def _tensors(objs):
@@ -218,11 +219,14 @@ class InFlight:
         self._k += 1
         st = self.streams[k]
         rep = self.lanes[k].rep
-        if not rep.packed_is_current():
+        pw = rep.packed_weights()                    # (a stale pack is rebuilt HERE, on the caller's stream, before the lane waits for it)
+        if pw is not self._pack:
             # a weight update: the old pack's operands (cat'ed weights, fp16 planes, transposes) may still be read by kernels
-            # queued on other lanes -- everything drains into the current stream before the rebuild frees them
+            # queued on other lanes.  This object holds the OLD pack until every lane has drained into the current stream, so
+            # its blocks are not handed to the rebuild above or to anything after it while they are in use
             self.wait()
-        pack_id = id(rep.packed_weights())           # (a stale pack is rebuilt HERE, on the caller's stream, before the lane waits for it)
+            self._pack = pw
+        pack_id = id(pw)
         st.wait_stream(torch.cuda.current_stream(st.device))
         for t in self._tensors(list(args) + list(kw.values())):
             if t.is_cuda:
