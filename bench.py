@@ -425,7 +425,7 @@ def worker(a):
             also["lmax4"] = sub(side["out"])
             # top-level copy of the north-star TARGET shape's record (n_atom_basis=256, lmax=4): >= 0.40 of the HBM roofline
             # on the edge gather / scatter is the stated target; the headline line is the reference's default lmax=2
-            out["roofline_target"] = {"config": side["out"]["config"]["workload"][:120], **{
+            out["roofline_target"] = {"config": f"{a.workload} batch={a.batch}/GPU, n_atom_basis=256, n_interactions=6, lmax=4, energy+forces", **{
                 k: v for k, v in _side_compact(side["out"]).items() if k in
                 ("gather_frac", "gather_frac_general", "htr_frac", "msg_bwd_frac", "htr_bwd_frac", "ms_per_step", "value")}}
         for k, v in wl.items():
