@@ -17,9 +17,12 @@ numbers on the embedded channels.  Two things do not embed and are handled here:
   * LayerNorm statistics (NodeInit, layers.py:1658-1675): that one intermediate stays COMPACT -- the product that feeds the
     norm writes F columns, the norm runs over F channels, the product after it reads K = F columns (engine: ``cfg.Fc``).
 ``GotenNet.forward`` returns (h, X) in the real layout (a column gather), the backward embeds the incoming gradients.
-Cost: the work of the padded width (F = 192 runs as 256: +33 %).  Options that normalise over channels inside the layers
-(``layernorm``, ``steerable_norm``, ``edge_ln``, the composed edge updates) and ``evec_dim`` / ``emlp_dim`` are not embedded:
-NotImplementedError before any launch."""
+  * the optional GATA input norms (``layernorm``: nn.LayerNorm on h, ``steerable_norm``: TensorLayerNorm on X; gotennet.py:397-398,
+    layers.py:1497-1563) take their statistics over the REAL channels: the engine gathers the real channels into a compact
+    tensor, runs gn_layernorm / gn_tensor_norm (and their input-gradients) at the model's own width and scatters the result
+    back into the padded layout (round 6; correct-first: two index launches per norm).
+Cost: the work of the padded width (F = 192 runs as 256: +33 %).  ``edge_ln``, the composed / gated edge updates and
+``evec_dim`` / ``emlp_dim`` are not embedded: NotImplementedError before any launch."""
 from __future__ import annotations
 
 import math
@@ -49,11 +52,11 @@ def channel_map(F: int, H: int, device=None) -> torch.Tensor:
 def check(F: int, H: int, cfg: "engine.Config") -> None:
     if F % H or F % 4 or F > 1024:
         raise NotImplementedError(f"n_atom_basis={F}: a multiple of 4 and of num_heads={H}, at most 1024, on the HIP path")
-    if (cfg.layernorm or cfg.steerable_norm or cfg.composed_update or cfg.evec not in (0, F) or cfg.emlp not in (0, F)
-            or (cfg.htr_mode >> 2)):
+    if (cfg.composed_update or cfg.evec not in (0, F) or cfg.emlp not in (0, F) or (cfg.htr_mode >> 2)):
         raise NotImplementedError(
             f"n_atom_basis={F} is not a power of two: it runs embedded in width {padded_width(F)}, which covers the default "
-            "layer family only (no layernorm / steerable_norm / edge_ln, no composed or gated edge update, no evec_dim / emlp_dim)")
+            "layer family and the GATA input norms (layernorm / steerable_norm), not edge_ln, composed or gated edge updates, "
+            "evec_dim / emlp_dim")
 
 
 def _emb(W: Optional[torch.Tensor], idx: torch.Tensor, F: int, Fp: int, row_blocks: int = 0, col_blocks: int = 0,
@@ -101,6 +104,9 @@ def embed_pack(pw: "engine.PackedWeights", F: int, H: int, M: int) -> "engine.Pa
         nl.Wvu = e(lw.Wvu, 1, 1)
         nl.Wm0, nl.bm0 = e(lw.Wm0, 1, 2), e(lw.bm0, 1, 0)
         nl.Wm1, nl.bm1 = e(lw.Wm1, 2, 1), e(lw.bm1, 2, 0)
+        # the GATA input norms (layernorm / steerable_norm) run on the COMPACT real channels (engine._input_norms): their
+        # parameters stay in the model's own layout
+        nl.ln_w, nl.ln_b, nl.tln_w = lw.ln_w, lw.ln_b, lw.tln_w
         if lw.Wt is not None:
             nl.Wt, nl.bt = e(lw.Wt, 1, 1), e(lw.bt, 1, 0)
             nl.Wvq = e(lw.Wvq, 1, 1)

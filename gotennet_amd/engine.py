@@ -464,13 +464,9 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
         last = lw.Wt is None
         h_raw, X_raw = h, X
         if cfg.layernorm:                          # gotennet.py:397-398: the layer (and its residuals) see the normalised values
-            hn = new(N, F_)
-            call("gn_layernorm", ptr(h), ptr(lw.ln_w), ptr(lw.ln_b), 1e-5, N, F_, ptr(hn), _stream())
-            h = hn
+            h = _norm_h(cfg, pw, lw, h)
         if cfg.steerable_norm:
-            Xn = new(N, D, F_)
-            call("gn_tensor_norm", ptr(X), ptr(lw.tln_w), 1e-12, N, F_, lmax, ptr(Xn), _stream())
-            X = Xn
+            X = _norm_X(cfg, pw, lw, X)
         if save:                                   # every layer keeps its own activations
             lt = LayerTape(h_in=h, X_in=X, t_in=t, h_raw=h_raw, X_raw=X_raw)
             tape.layers.append(lt)
@@ -553,6 +549,32 @@ def _forward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, s
     if pw.emb_idx is not None:                     # embedded model: the real channels, in the model's own order
         h, X = h.index_select(1, pw.emb_idx), X.index_select(2, pw.emb_idx)
     return h, X, tape
+
+
+def _norm_h(cfg: Config, pw: PackedWeights, lw: LayerWeights, h: torch.Tensor) -> torch.Tensor:
+    """nn.LayerNorm on h at the GATA input (gotennet.py:397).  Embedded model: over the real channels (embed.py)."""
+    N = h.shape[0]
+    if pw.emb_idx is None:
+        hn = torch.empty_like(h)
+        call("gn_layernorm", ptr(h), ptr(lw.ln_w), ptr(lw.ln_b), 1e-5, N, cfg.F, ptr(hn), _stream())
+        return hn
+    hc = h.index_select(1, pw.emb_idx)
+    yc = torch.empty_like(hc)
+    call("gn_layernorm", ptr(hc), ptr(lw.ln_w), ptr(lw.ln_b), 1e-5, N, cfg.F_model, ptr(yc), _stream())
+    return torch.zeros_like(h).index_copy_(1, pw.emb_idx, yc)
+
+
+def _norm_X(cfg: Config, pw: PackedWeights, lw: LayerWeights, X: torch.Tensor) -> torch.Tensor:
+    """TensorLayerNorm on X at the GATA input (gotennet.py:398, layers.py:1497-1563)."""
+    N = X.shape[0]
+    if pw.emb_idx is None:
+        Xn = torch.empty_like(X)
+        call("gn_tensor_norm", ptr(X), ptr(lw.tln_w), 1e-12, N, cfg.F, cfg.lmax, ptr(Xn), _stream())
+        return Xn
+    Xc = X.index_select(2, pw.emb_idx)
+    Yc = torch.empty_like(Xc)
+    call("gn_tensor_norm", ptr(Xc), ptr(lw.tln_w), 1e-12, N, cfg.F_model, cfg.lmax, ptr(Yc), _stream())
+    return torch.zeros_like(X).index_copy_(2, pw.emb_idx, Yc)
 
 
 def gata_input_norms(cfg: Config, lw: LayerWeights, h: torch.Tensor, X: torch.Tensor):
@@ -909,10 +931,22 @@ def _backward_impl(cfg: Config, pw: PackedWeights, z32: torch.Tensor, g: Graph, 
         gt, gt_b = gt_b, (gt if gt is not None else new(E, F_))
         # ---- optional input norms (gotennet.py:397-398): back to the un-normalised h / X
         if cfg.layernorm:
-            call("gn_layernorm_backward", ptr(lt.h_raw), ptr(lw.ln_w), 1e-5, ptr(gh), N, F_, ptr(gh2), _stream())
+            if pw.emb_idx is None:
+                call("gn_layernorm_backward", ptr(lt.h_raw), ptr(lw.ln_w), 1e-5, ptr(gh), N, F_, ptr(gh2), _stream())
+            else:                                  # statistics over the real channels: compact -> kernel -> padded layout
+                gc = torch.empty((N, cfg.F_model), **f32)
+                xc, gyc = lt.h_raw.index_select(1, pw.emb_idx), gh.index_select(1, pw.emb_idx)   # (named: alive until the launch)
+                call("gn_layernorm_backward", ptr(xc), ptr(lw.ln_w), 1e-5, ptr(gyc), N, cfg.F_model, ptr(gc), _stream())
+                gh2.zero_().index_copy_(1, pw.emb_idx, gc)
             gh, gh2 = gh2, gh
         if cfg.steerable_norm:
-            call("gn_tensor_norm_backward", ptr(lt.X_raw), ptr(lw.tln_w), ptr(gX), 1e-12, N, F_, lmax, ptr(gX2), _stream())
+            if pw.emb_idx is None:
+                call("gn_tensor_norm_backward", ptr(lt.X_raw), ptr(lw.tln_w), ptr(gX), 1e-12, N, F_, lmax, ptr(gX2), _stream())
+            else:
+                gc = torch.empty((N, D, cfg.F_model), **f32)
+                xc, gyc = lt.X_raw.index_select(2, pw.emb_idx), gX.index_select(2, pw.emb_idx)
+                call("gn_tensor_norm_backward", ptr(xc), ptr(lw.tln_w), ptr(gyc), 1e-12, N, cfg.F_model, lmax, ptr(gc), _stream())
+                gX2.zero_().index_copy_(2, pw.emb_idx, gc)
             gX, gX2 = gX2, gX
 
     # ---- init backward (layers.py:1658-1714) ------------------------------------------

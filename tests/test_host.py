@@ -245,8 +245,11 @@ def test_embedding_map_keeps_heads_and_blocks():
     Wv2 = pw.layers[0].Wv2                                                        # [M Fp, Fp], scaled by sqrt(Fp / F)
     blk = Wv2[256:512][idx][:, idx]
     assert torch.allclose(blk, g0.gamma_v[1].weight.detach()[192:384] * math.sqrt(256 / 192), rtol=0, atol=0)
-    with pytest.raises(NotImplementedError):                                     # channel norms inside the layers are not embedded
-        gotennet_amd.GotenNet(n_atom_basis=192, n_interactions=1, n_rbf=8, cutoff_fn=gotennet_amd.CosineCutoff(5.0), num_heads=8,
-                              layernorm="layer").config()
+    # the GATA input norms run on the compact real channels (round 6) ...
+    assert gotennet_amd.GotenNet(n_atom_basis=192, n_interactions=1, n_rbf=8, cutoff_fn=gotennet_amd.CosineCutoff(5.0), num_heads=8,
+                                 layernorm="layer", steerable_norm="layer").config().F == 256
+    with pytest.raises(NotImplementedError):                                     # ... the composed edge updates are not embedded
+        gotennet_amd.GotenNet(n_atom_basis=192, n_interactions=2, n_rbf=8, cutoff_fn=gotennet_amd.CosineCutoff(5.0), num_heads=8,
+                              edge_updates="mlp").config()
     with pytest.raises(NotImplementedError):
         gotennet_amd.GotenNet(n_atom_basis=100, n_interactions=1, n_rbf=8, cutoff_fn=gotennet_amd.CosineCutoff(5.0), num_heads=8).config()
